@@ -1,0 +1,643 @@
+/*
+ * mcx_oracle.c -- CPU restatement of the McCortex `build` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see mcx_oracle.h).  Written from scratch in plain
+ * C; each function names the reference file:line (under /root/reference) whose
+ * arithmetic it follows.  The reference itself cannot be built in this image
+ * (its libs/ submodules are empty) so this file is pinned against the
+ * reference's own known-answer/unit tests, the vendored libs/misc/lookup3.h
+ * compiled from where it lies (oracle/_ref), and the KATs recorded in
+ * SURVEY.md 8(c) -- see oracle/README.md.
+ */
+#include "mcx_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+#include <sched.h>
+
+#define ORC_REHASH_LIMIT 20    /* src/basic/hash_mem.h:4 */
+#define ORC_MAX_BUCKET   48    /* src/basic/hash_mem.h:8 */
+#define ORC_FLAG (1ULL << 63)  /* BKMER_SET_FLAG, src/graph/hash_table.h:41-46 */
+
+/* ------------------------------------------------------------------------ */
+/* Row A-C: k-mer primitives                                                 */
+/* ------------------------------------------------------------------------ */
+
+/* binary_kmer.h:10: NUM_BKMER_WORDS64(k) = (2k+63)/64.  For a legal k of a
+ * given MAXK build (MAXK-30 <= k <= MAXK) this equals the compile-time W. */
+int orc_words_for_k(int k) { return (2 * k + 63) / 64; }
+
+/* dna.c:8-25: A/a=0 C/c=1 G/g=2 T/t=3 N/n=4 other=8 */
+int orc_char_to_nuc(unsigned char c)
+{
+  switch(c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    case 'N': case 'n': return 4;
+    default: return 8;
+  }
+}
+static inline int is_acgt(char c) { return orc_char_to_nuc((unsigned char)c) < 4; }
+
+static inline int top_bits(int k) { return 2 * (k & 31); } /* binary_kmer.h:40-42 */
+
+/* binary_kmer.c:156-186: top word takes the first k&31 bases, each later word 32 */
+orc_bkmer orc_kmer_from_str(const char *seq, int k)
+{
+  orc_bkmer x; memset(&x, 0, sizeof(x));
+  const int W = orc_words_for_k(k);
+  int pos = 0, w, end = k & 31;
+  for(; pos < end; pos++) x.b[0] = (x.b[0] << 2) | (uint64_t)orc_char_to_nuc((unsigned char)seq[pos]);
+  for(w = 1; w < W; w++)
+    for(end += 32; pos < end; pos++)
+      x.b[w] = (x.b[w] << 2) | (uint64_t)orc_char_to_nuc((unsigned char)seq[pos]);
+  return x;
+}
+
+/* binary_kmer.h:139-146,160-167 and binary_kmer.c:80-97: shift every word left
+ * one base carrying from the word below, mask the top word, add nuc at the end */
+orc_bkmer orc_kmer_shift_add(orc_bkmer x, int k, int nuc)
+{
+  const int W = orc_words_for_k(k);
+  int w;
+  for(w = 0; w + 1 < W; w++) x.b[w] = (x.b[w] << 2) | (x.b[w + 1] >> 62);
+  x.b[W - 1] <<= 2;
+  x.b[0] &= UINT64_MAX >> (64 - top_bits(k));
+  x.b[W - 1] |= (uint64_t)nuc;
+  return x;
+}
+
+/* binary_kmer.c:102-133 */
+orc_bkmer orc_kmer_revcomp(orc_bkmer x, int k)
+{
+  const int W = orc_words_for_k(k);
+  const int tb = top_bits(k), unused = 64 - tb;
+  orc_bkmer r; memset(&r, 0, sizeof(r));
+  int i, j;
+  for(i = 0, j = W - 1; i < W; i++, j--) {
+    uint64_t w = __builtin_bswap64(x.b[i]);
+    w = ((w & 0x0303030303030303ULL) << 6) | ((w & 0x0c0c0c0c0c0c0c0cULL) << 2) |
+        ((w & 0x3030303030303030ULL) >> 2) | ((w & 0xc0c0c0c0c0c0c0c0ULL) >> 6);
+    r.b[j] = ~w;
+  }
+  for(i = W - 1; i > 0; i--) r.b[i] = (r.b[i] >> unused) | (r.b[i - 1] << tb);
+  r.b[0] >>= unused;
+  return r;
+}
+
+static inline int bkmer_lt(const orc_bkmer *a, const orc_bkmer *b, int W)
+{ /* binary_kmer.h:79-94: word 0 first, unsigned */
+  int i;
+  for(i = 0; i < W; i++) if(a->b[i] != b->b[i]) return a->b[i] < b->b[i];
+  return 0;
+}
+static inline int bkmer_eq(const orc_bkmer *a, const orc_bkmer *b, int W)
+{
+  int i;
+  for(i = 0; i < W; i++) if(a->b[i] != b->b[i]) return 0;
+  return 1;
+}
+
+/* binary_kmer.c:43-57 */
+orc_bkmer orc_kmer_get_key(orc_bkmer x, int k)
+{
+  const int W = orc_words_for_k(k);
+  unsigned first = (unsigned)(x.b[0] >> (top_bits(k) - 2)) & 3u;
+  unsigned last = (unsigned)x.b[W - 1] & 3u;
+  unsigned rev_last = ~last & 3u; /* dna.h:22 */
+  if(first < rev_last) return x;
+  orc_bkmer rc = orc_kmer_revcomp(x, k);
+  return bkmer_lt(&x, &rc, W) ? x : rc;
+}
+
+#define ROT(x, n) (((x) << (n)) | ((x) >> (32 - (n))))
+/* kmer_hash.h:89-97 */
+#define LK3_MIX(a, b, c) do { \
+  a -= c; a ^= ROT(c, 4);  c += b; b -= a; b ^= ROT(a, 6);  a += c; \
+  c -= b; c ^= ROT(b, 8);  b += a; a -= c; a ^= ROT(c, 16); c += b; \
+  b -= a; b ^= ROT(a, 19); a += c; c -= b; c ^= ROT(b, 4);  b += a; } while(0)
+/* kmer_hash.h:124-133 */
+#define LK3_FINAL(a, b, c) do { \
+  c ^= b; c -= ROT(b, 14); a ^= c; a -= ROT(c, 11); b ^= a; b -= ROT(a, 25); \
+  c ^= b; c -= ROT(b, 16); a ^= c; a -= ROT(c, 4);  b ^= a; b -= ROT(a, 14); \
+  c ^= b; c -= ROT(b, 24); } while(0)
+
+/* kmer_hash.h:162-211: lookup3 hashlittle over the W*8 key bytes in memory
+ * order (little-endian 32-bit halves of b[0], b[1], ...). */
+uint32_t orc_kmer_hash(orc_bkmer key, int k, uint32_t initval)
+{
+  const int W = orc_words_for_k(k);
+  const uint32_t nbytes = (uint32_t)W * 8u;
+  uint32_t w32[2 * ORC_MAX_W];
+  int i, n = 2 * W;
+  for(i = 0; i < W; i++) { w32[2 * i] = (uint32_t)key.b[i]; w32[2 * i + 1] = (uint32_t)(key.b[i] >> 32); }
+  uint32_t a, b, c;
+  a = b = c = 0xdeadbeefu + nbytes + initval;
+  const uint32_t *p = w32;
+  while(n > 3) { /* "i+12 < BKMER_BYTES" blocks */
+    a += p[0]; b += p[1]; c += p[2];
+    LK3_MIX(a, b, c);
+    p += 3; n -= 3;
+  }
+  if(n == 3) { a += p[0]; b += p[1]; c += p[2]; }
+  else if(n == 2) { a += p[0]; b += p[1]; }
+  else { a += p[0]; }
+  LK3_FINAL(a, b, c);
+  return c;
+}
+
+void orc_kmer_to_str(orc_bkmer x, int k, char *out)
+{
+  static const char nuc2c[4] = {'A', 'C', 'G', 'T'};
+  const int W = orc_words_for_k(k);
+  int i;
+  for(i = k - 1; i >= 0; i--) {
+    out[i] = nuc2c[x.b[W - 1] & 3];
+    int w; /* shift right one base across words */
+    for(w = W - 1; w > 0; w--) x.b[w] = (x.b[w] >> 2) | (x.b[w - 1] << 62);
+    x.b[0] >>= 2;
+  }
+  out[k] = '\0';
+}
+
+/* hash_mem.c:5-15 */
+uint64_t orc_hash_table_cap(uint64_t nkmers, uint64_t *nbuckets, uint8_t *bucket_size)
+{
+  uint64_t nbits = 10;
+  while(nkmers / (1ULL << nbits) > ORC_MAX_BUCKET) nbits++;
+  uint64_t nb = 1ULL << nbits;
+  uint64_t bs = (nkmers + nb - 1) / nb;
+  if(bs < 1) bs = 1;
+  if(nbuckets) *nbuckets = nb;
+  if(bucket_size) *bucket_size = (uint8_t)bs;
+  return nb * bs;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Row G: contig splitting                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* seq_reader.c:61-117 */
+size_t orc_contig_start(const char *seq, size_t seqlen, const char *qual, size_t quallen,
+                        size_t offset, size_t k, uint8_t qual_cutoff, uint8_t hp_cutoff)
+{
+  if(!qual || !quallen) { qual = NULL; quallen = 0; }
+  size_t pos = offset, kend;
+  while((kend = pos + k) <= seqlen) {
+    size_t i = kend;
+    while(i > pos && is_acgt(seq[i - 1])) i--;
+    if(i > pos) { pos = i; continue; }
+
+    if(qual && qual_cutoff > 0) {
+      i = kend < quallen ? kend : quallen;
+      while(i > pos && qual[i - 1] > qual_cutoff) i--;
+      if(i > pos) { pos = i; continue; }
+    }
+
+    if(hp_cutoff > 0) {
+      size_t run = 1;
+      for(i = kend - 1; i > pos; i--) {
+        if(seq[i - 1] == seq[i]) { run++; if(run == (size_t)hp_cutoff) break; }
+        else run = 1;
+      }
+      if(i > pos) { pos = i; continue; }
+    }
+    return pos;
+  }
+  return seqlen;
+}
+
+/* seq_reader.c:127-172 */
+size_t orc_contig_end(const char *seq, size_t seqlen, const char *qual, size_t quallen,
+                      size_t contig_start, size_t k, uint8_t qual_cutoff, uint8_t hp_cutoff,
+                      size_t *search_start)
+{
+  if(!qual || !quallen) { qual = NULL; quallen = 0; }
+  size_t end = contig_start + k;
+  size_t hp_run = 1;
+  if(hp_cutoff > 0)
+    while(hp_run < end && seq[end - 1 - hp_run] == seq[end - 1]) hp_run++;
+
+  for(; end < seqlen; end++) {
+    if(!is_acgt(seq[end]) || (end < quallen && qual[end] < qual_cutoff)) break;
+    if(hp_cutoff > 0) {
+      if(seq[end] == seq[end - 1]) { hp_run++; if(hp_run >= (size_t)hp_cutoff) break; }
+      else hp_run = 1;
+    }
+  }
+  if(hp_cutoff > 0 && hp_run >= (size_t)hp_cutoff) *search_start = end - (size_t)hp_cutoff + 1;
+  else *search_start = end;
+  return end;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Rows D-F: bucketed hash table + node arrays                               */
+/* ------------------------------------------------------------------------ */
+
+struct orc_graph {
+  int k, W, ncols;
+  /* HashTable: hash_table.h:18-31 */
+  uint64_t *table;         /* capacity * W words; slot word0 carries ORC_FLAG */
+  uint8_t *bsize;          /* items appended per bucket (== bitems: no deletes on build) */
+  volatile uint8_t *locks; /* one lock byte per bucket (reference: one bit) */
+  uint64_t nbuckets, capacity, hash_mask;
+  uint8_t bucket_size;
+  uint32_t seed;
+  volatile uint64_t num_kmers;
+  /* dBGraph arrays: db_graph.h, db_node.h:240-241 */
+  uint32_t *covgs; /* [capacity][ncols] */
+  uint8_t *edges;  /* [capacity][ncols] */
+  /* GraphInfo per colour: graph_info.h:20-27 */
+  uint32_t *mean_read_length;
+  uint64_t *total_sequence;
+  char (*sample)[256];
+  volatile int full;
+};
+
+orc_graph *orc_graph_new(int k, int ncols, uint64_t capacity_kmers, uint32_t seed)
+{
+  if(k < 3 || !(k & 1) || orc_words_for_k(k) > ORC_MAX_W || ncols < 1) return NULL;
+  orc_graph *g = calloc(1, sizeof(*g));
+  g->k = k; g->W = orc_words_for_k(k); g->ncols = ncols;
+  g->capacity = orc_hash_table_cap(capacity_kmers, &g->nbuckets, &g->bucket_size);
+  g->hash_mask = g->nbuckets - 1;
+  g->seed = seed; /* reference: rand(), hash_table.c:49 -- any value gives the same sorted graph */
+  g->table = calloc(g->capacity * (size_t)g->W, sizeof(uint64_t));
+  g->bsize = calloc(g->nbuckets, 1);
+  g->locks = calloc(g->nbuckets, 1);
+  g->covgs = calloc(g->capacity * (size_t)ncols, sizeof(uint32_t));
+  g->edges = calloc(g->capacity * (size_t)ncols, 1);
+  g->mean_read_length = calloc((size_t)ncols, sizeof(uint32_t));
+  g->total_sequence = calloc((size_t)ncols, sizeof(uint64_t));
+  g->sample = calloc((size_t)ncols, sizeof(*g->sample));
+  int c;
+  for(c = 0; c < ncols; c++) strcpy(g->sample[c], "undefined"); /* graph_info.c:62 */
+  if(!g->table || !g->bsize || !g->locks || !g->covgs || !g->edges) { orc_graph_free(g); return NULL; }
+  return g;
+}
+
+void orc_graph_free(orc_graph *g)
+{
+  if(!g) return;
+  free(g->table); free(g->bsize); free((void *)g->locks); free(g->covgs); free(g->edges);
+  free(g->mean_read_length); free(g->total_sequence); free(g->sample);
+  free(g);
+}
+
+int orc_graph_set_sample(orc_graph *g, int col, const char *name)
+{
+  if(col < 0 || col >= g->ncols || strlen(name) > 255) return -1;
+  strcpy(g->sample[col], name);
+  return 0;
+}
+uint64_t orc_graph_nkmers(const orc_graph *g) { return g->num_kmers; }
+uint64_t orc_graph_capacity(const orc_graph *g) { return g->capacity; }
+
+static inline void bkt_lock(volatile uint8_t *l)
+{ /* bitlock_yield_acquire: hash_table.c:260 */
+  while(__sync_lock_test_and_set(l, 1)) sched_yield();
+}
+static inline void bkt_unlock(volatile uint8_t *l) { __sync_lock_release(l); }
+
+#define ORC_NOT_FOUND (UINT64_MAX >> 1) /* hash_table.h:13 */
+
+/* hash_table.c:250-281 (find_or_insert_mt) with :78-91 (find_in_bucket) and
+ * :94-117 (insert_in_bucket).  Returns slot index or ORC_NOT_FOUND when all
+ * REHASH_LIMIT buckets are full (the reference dies: "Hash table is full"). */
+static uint64_t find_or_insert(orc_graph *g, const orc_bkmer *key, int *found)
+{
+  const int W = g->W;
+  int i, w;
+  for(i = 0; i < ORC_REHASH_LIMIT; i++) {
+    uint64_t h = orc_kmer_hash(*key, g->k, g->seed + (uint32_t)i) & g->hash_mask;
+    bkt_lock(&g->locks[h]);
+    uint64_t *slot = g->table + h * g->bucket_size * (uint64_t)W;
+    unsigned n = g->bsize[h], j;
+    for(j = 0; j < n; j++, slot += W) {
+      if(slot[0] != (key->b[0] | ORC_FLAG)) continue;
+      for(w = 1; w < W && slot[w] == key->b[w]; w++) {}
+      if(w == W) {
+        *found = 1;
+        bkt_unlock(&g->locks[h]);
+        return h * g->bucket_size + j;
+      }
+    }
+    if(n < g->bucket_size) {
+      slot[0] = key->b[0] | ORC_FLAG;
+      for(w = 1; w < W; w++) slot[w] = key->b[w];
+      g->bsize[h] = (uint8_t)(n + 1);
+      __sync_add_and_fetch(&g->num_kmers, 1);
+      *found = 0;
+      bkt_unlock(&g->locks[h]);
+      return h * g->bucket_size + n;
+    }
+    bkt_unlock(&g->locks[h]);
+  }
+  return ORC_NOT_FOUND;
+}
+
+/* db_node.c:139-144: saturating thread-safe +1 */
+static inline void covg_inc(uint32_t *p)
+{
+  uint32_t v;
+  while((v = *(volatile uint32_t *)p) < UINT32_MAX && !__sync_bool_compare_and_swap(p, v, v + 1)) {}
+}
+
+typedef struct { uint64_t hkey; int orient; } orc_node;
+
+/* db_graph.c:126-135 + :101-105 */
+static inline orc_node find_or_add_node(orc_graph *g, const orc_bkmer *bk, int colour, int *found)
+{
+  orc_bkmer key = orc_kmer_get_key(*bk, g->k);
+  orc_node n;
+  n.hkey = find_or_insert(g, &key, found);
+  n.orient = bkmer_eq(&key, bk, g->W) ? 0 : 1; /* db_node.h:109-110 */
+  if(n.hkey != ORC_NOT_FOUND) covg_inc(&g->covgs[n.hkey * (uint64_t)g->ncols + (uint64_t)colour]);
+  return n;
+}
+
+/* db_graph.c:152-166; nuc_orient_to_edge: db_node.h:180; set_col_edge_mt: db_node.h:273-274.
+ * The oriented first/last bases are read back from the stored key exactly as the
+ * reference does (bkmer_get_first_nuc / bkmer_get_last_nuc, db_node.h:115-121). */
+static inline void add_edge(orc_graph *g, int colour, orc_node src, orc_node tgt)
+{
+  const int W = g->W, tb = top_bits(g->k);
+  const uint64_t *ks = g->table + src.hkey * (uint64_t)W, *kt = g->table + tgt.hkey * (uint64_t)W;
+  unsigned s_first = (unsigned)((ks[0] & ~ORC_FLAG) >> (tb - 2)) & 3u, s_last = (unsigned)ks[W - 1] & 3u;
+  unsigned t_first = (unsigned)((kt[0] & ~ORC_FLAG) >> (tb - 2)) & 3u, t_last = (unsigned)kt[W - 1] & 3u;
+  unsigned lhs = src.orient == 0 ? s_first : (~s_last & 3u);
+  unsigned rhs = tgt.orient == 0 ? t_last : (~t_first & 3u);
+  unsigned lhs_rev = ~lhs & 3u;
+  uint8_t e_src = (uint8_t)(1u << (rhs + 4u * (unsigned)src.orient));
+  uint8_t e_tgt = (uint8_t)(1u << (lhs_rev + 4u * (unsigned)!tgt.orient));
+  __sync_fetch_and_or(&g->edges[src.hkey * (uint64_t)g->ncols + (uint64_t)colour], e_src);
+  __sync_fetch_and_or(&g->edges[tgt.hkey * (uint64_t)g->ncols + (uint64_t)colour], e_tgt);
+}
+
+/* build_graph.c:122-150 */
+static size_t build_from_str(orc_graph *g, int colour, const char *seq, size_t len)
+{
+  const int k = g->k;
+  size_t i, nonnovel = 0;
+  int found = 0;
+  orc_bkmer bk = orc_kmer_from_str(seq, k);
+  orc_node prev = find_or_add_node(g, &bk, colour, &found), curr;
+  if(prev.hkey == ORC_NOT_FOUND) { g->full = 1; return 0; }
+  nonnovel += (size_t)found;
+  for(i = (size_t)k; i < len; i++, prev = curr) {
+    bk = orc_kmer_shift_add(bk, k, orc_char_to_nuc((unsigned char)seq[i]));
+    curr = find_or_add_node(g, &bk, colour, &found);
+    if(curr.hkey == ORC_NOT_FOUND) { g->full = 1; return nonnovel; }
+    add_edge(g, colour, prev, curr);
+    nonnovel += (size_t)found;
+  }
+  return nonnovel;
+}
+
+/* build_graph.c:154-189 (load_read) + :192-231 (SE path of build_graph_from_reads_mt,
+ * no PCR-duplicate removal, must_exist_in_graph=false) */
+static void load_read(orc_graph *g, int colour, const char *seq, size_t len, const char *qual,
+                      uint8_t fq_cutoff, uint8_t hp_cutoff, orc_stats *st)
+{
+  const size_t k = (size_t)g->k;
+  size_t cs, ce, search = 0, ncontigs = 0;
+  const size_t qlen = qual ? len : 0;
+  st->total_bases_read += len;
+  st->num_se_reads += 1;
+  while((cs = orc_contig_start(seq, len, qual, qlen, search, k, fq_cutoff, hp_cutoff)) < len) {
+    ce = orc_contig_end(seq, len, qual, qlen, cs, k, fq_cutoff, hp_cutoff, &search);
+    size_t clen = ce - cs;
+    size_t nonnovel = build_from_str(g, colour, seq + cs, clen);
+    if(g->full) return;
+    size_t ckmers = clen + 1 - k;
+    st->total_bases_loaded += clen;
+    st->num_kmers_loaded += ckmers;
+    st->num_kmers_novel += ckmers - nonnovel;
+    ncontigs++;
+  }
+  st->contigs_parsed += ncontigs;
+  st->num_good_reads += (ncontigs > 0);
+  st->num_bad_reads += (ncontigs == 0);
+}
+
+typedef struct {
+  orc_graph *g; int colour; const char *bases, *quals; const uint64_t *off;
+  uint64_t lo, hi; uint8_t fq, hp; orc_stats st;
+} orc_job;
+
+static void *job_run(void *p)
+{
+  orc_job *j = p;
+  uint64_t r;
+  for(r = j->lo; r < j->hi && !j->g->full; r++) {
+    size_t len = (size_t)(j->off[r + 1] - j->off[r]);
+    load_read(j->g, j->colour, j->bases + j->off[r], len, j->quals ? j->quals + j->off[r] : NULL,
+              j->fq, j->hp, &j->st);
+  }
+  return NULL;
+}
+
+static void stats_merge(orc_stats *d, const orc_stats *s)
+{ /* seq_loading_stats.c merge */
+  d->num_se_reads += s->num_se_reads; d->num_good_reads += s->num_good_reads;
+  d->num_bad_reads += s->num_bad_reads; d->total_bases_read += s->total_bases_read;
+  d->total_bases_loaded += s->total_bases_loaded; d->contigs_parsed += s->contigs_parsed;
+  d->num_kmers_loaded += s->num_kmers_loaded; d->num_kmers_novel += s->num_kmers_novel;
+}
+
+int orc_graph_add_reads(orc_graph *g, int colour, const char *bases, const char *quals,
+                        const uint64_t *offsets, uint64_t nreads,
+                        uint8_t fq_cutoff, uint8_t hp_cutoff, int nthreads, orc_stats *stats_accum)
+{
+  if(colour < 0 || colour >= g->ncols) return -2;
+  if(nthreads < 1) nthreads = 1;
+  if((uint64_t)nthreads > nreads) nthreads = nreads ? (int)nreads : 1;
+  orc_job *jobs = calloc((size_t)nthreads, sizeof(orc_job));
+  pthread_t *th = calloc((size_t)nthreads, sizeof(pthread_t));
+  int t;
+  for(t = 0; t < nthreads; t++) {
+    orc_job *j = &jobs[t];
+    j->g = g; j->colour = colour; j->bases = bases; j->quals = quals; j->off = offsets;
+    j->lo = nreads * (uint64_t)t / (uint64_t)nthreads;
+    j->hi = nreads * (uint64_t)(t + 1) / (uint64_t)nthreads;
+    j->fq = fq_cutoff; j->hp = hp_cutoff;
+  }
+  if(nthreads == 1) job_run(&jobs[0]);
+  else {
+    for(t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, job_run, &jobs[t]);
+    for(t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  }
+  if(stats_accum) for(t = 0; t < nthreads; t++) stats_merge(stats_accum, &jobs[t].st);
+  free(jobs); free(th);
+  return g->full ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Row H: GraphInfo + .ctx v6 image                                          */
+/* ------------------------------------------------------------------------ */
+
+/* graph_info.c:116-133 */
+static void ginfo_update_contigs(uint32_t *mean, uint64_t *total, uint64_t added, uint64_t ncontigs)
+{
+  if(!added && !ncontigs) return;
+  size_t have = 0;
+  if(*total && *mean) have = (size_t)(((double)*total / *mean) + 0.5);
+  if(have + ncontigs > 0) *mean = (uint32_t)((double)(*total + added) / (double)(have + ncontigs));
+  *total += added;
+}
+
+/* graph_info.c:172-175 */
+void orc_graph_update_stats(orc_graph *g, int colour, const orc_stats *st)
+{
+  ginfo_update_contigs(&g->mean_read_length[colour], &g->total_sequence[colour],
+                       st->total_bases_loaded, st->contigs_parsed);
+}
+
+/* Header GraphInfo after graph_writer_mkhdr (graph_writer.c:11-30) merges the
+ * graph's ginfo into a freshly initialised one (graph_info.c:135-170). */
+static void hdr_ginfo(const orc_graph *g, int c, uint32_t *mean, uint64_t *total, long double *seq_err)
+{
+  /* dst: graph_info_init -> total 0, mean 0, seq_err 0.01 (double constant) */
+  uint32_t dmean = 0; uint64_t dtotal = 0; long double derr = 0.01;
+  /* src: the graph's ginfo; its seq_err was also initialised to (double)0.01 */
+  const long double serr = 0.01;
+  const uint64_t stotal = g->total_sequence[c];
+  const uint32_t smean = g->mean_read_length[c];
+  uint64_t tot = dtotal + stotal;
+  if(tot > 0) {
+    derr = (derr * dtotal + serr * stotal) / tot;
+    size_t src_contigs = 0;
+    if(stotal && smean) src_contigs = (size_t)(((double)stotal / smean) + 0.5);
+    ginfo_update_contigs(&dmean, &dtotal, stotal, src_contigs);
+  }
+  dtotal = tot;
+  *mean = dmean; *total = dtotal; *seq_err = derr;
+}
+
+size_t orc_graph_header_size(const orc_graph *g)
+{
+  size_t n = 6 + 16, c;
+  n += (size_t)g->ncols * 12;
+  for(c = 0; c < (size_t)g->ncols; c++) n += 4 + strlen(g->sample[c]);
+  n += (size_t)g->ncols * 16;
+  n += (size_t)g->ncols * (4 + 8 + 4 + 9);
+  return n + 6;
+}
+
+size_t orc_graph_ctx_size(const orc_graph *g)
+{
+  return orc_graph_header_size(g) + g->num_kmers * ((size_t)g->W * 8 + 5 * (size_t)g->ncols);
+}
+
+static int g_sort_W;
+static const uint64_t *g_sort_table;
+static int cmp_slots(const void *a, const void *b)
+{ /* binary_kmers_qcmp_ptrs: hash_table.c:371 (flag set on all, order unaffected) */
+  const uint64_t *x = g_sort_table + *(const uint64_t *)a * (uint64_t)g_sort_W;
+  const uint64_t *y = g_sort_table + *(const uint64_t *)b * (uint64_t)g_sort_W;
+  int i;
+  for(i = 0; i < g_sort_W; i++) if(x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
+  return 0;
+}
+
+#define PUT(ptr, val, type) do { type _v = (type)(val); memcpy(ptr, &_v, sizeof(type)); ptr += sizeof(type); } while(0)
+
+/* graph_writer.c:62-110 (header), :116-127 (record), :182-268 (iteration) */
+size_t orc_graph_write_ctx(const orc_graph *g, int sorted, uint8_t *out)
+{
+  uint8_t *p = out;
+  int c;
+  memcpy(p, "CORTEX", 6); p += 6;
+  PUT(p, 6, uint32_t); PUT(p, g->k, uint32_t); PUT(p, g->W, uint32_t); PUT(p, g->ncols, uint32_t);
+  uint32_t mean[64]; uint64_t total[64]; long double err[64];
+  if(g->ncols > 64) return 0;
+  for(c = 0; c < g->ncols; c++) hdr_ginfo(g, c, &mean[c], &total[c], &err[c]);
+  for(c = 0; c < g->ncols; c++) PUT(p, mean[c], uint32_t);
+  for(c = 0; c < g->ncols; c++) PUT(p, total[c], uint64_t);
+  for(c = 0; c < g->ncols; c++) {
+    uint32_t len = (uint32_t)strlen(g->sample[c]);
+    PUT(p, len, uint32_t); memcpy(p, g->sample[c], len); p += len;
+  }
+  for(c = 0; c < g->ncols; c++) { /* 10-byte x87 value + 6 zero bytes (calloc'd header) */
+    memset(p, 0, 16); memcpy(p, &err[c], 10); p += 16;
+  }
+  for(c = 0; c < g->ncols; c++) { /* write_error_cleaning_object: graph_writer.c:33-59 */
+    memset(p, 0, 4 + 8); p += 12;
+    PUT(p, 9, uint32_t); memcpy(p, "undefined", 9); p += 9;
+  }
+  memcpy(p, "CORTEX", 6); p += 6;
+
+  /* occupied slots in table order (HASH_ITERATE, hash_table.h:102-111) */
+  uint64_t n = 0, s, *order = malloc((g->num_kmers ? g->num_kmers : 1) * sizeof(uint64_t));
+  for(s = 0; s < g->capacity; s++) if(g->table[s * (uint64_t)g->W] & ORC_FLAG) order[n++] = s;
+  if(sorted) { g_sort_W = g->W; g_sort_table = g->table; qsort(order, n, sizeof(uint64_t), cmp_slots); }
+  for(s = 0; s < n; s++) {
+    uint64_t slot = order[s];
+    int w;
+    PUT(p, g->table[slot * (uint64_t)g->W] & ~ORC_FLAG & ~(1ULL << 62), uint64_t); /* hash_table_fetch */
+    for(w = 1; w < g->W; w++) PUT(p, g->table[slot * (uint64_t)g->W + (uint64_t)w], uint64_t);
+    memcpy(p, &g->covgs[slot * (uint64_t)g->ncols], 4 * (size_t)g->ncols); p += 4 * (size_t)g->ncols;
+    memcpy(p, &g->edges[slot * (uint64_t)g->ncols], (size_t)g->ncols); p += g->ncols;
+  }
+  free(order);
+  return (size_t)(p - out);
+}
+
+int orc_graph_lookup(const orc_graph *g, const char *kmer, uint32_t *covgs, uint8_t *edges)
+{
+  orc_bkmer key = orc_kmer_get_key(orc_kmer_from_str(kmer, g->k), g->k);
+  int i, w;
+  for(i = 0; i < ORC_REHASH_LIMIT; i++) { /* hash_table_find: hash_table.c:125-.. */
+    uint64_t h = orc_kmer_hash(key, g->k, g->seed + (uint32_t)i) & g->hash_mask;
+    const uint64_t *slot = g->table + h * g->bucket_size * (uint64_t)g->W;
+    unsigned j;
+    for(j = 0; j < g->bsize[h]; j++, slot += g->W) {
+      if(slot[0] != (key.b[0] | ORC_FLAG)) continue;
+      for(w = 1; w < g->W && slot[w] == key.b[w]; w++) {}
+      if(w < g->W) continue;
+      uint64_t hk = h * g->bucket_size + j;
+      if(covgs) memcpy(covgs, &g->covgs[hk * (uint64_t)g->ncols], 4 * (size_t)g->ncols);
+      if(edges) memcpy(edges, &g->edges[hk * (uint64_t)g->ncols], (size_t)g->ncols);
+      return 1;
+    }
+    if(g->bsize[h] < g->bucket_size) return 0;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Tuple stream: the closed form of SURVEY 0.3, derived from db_graph.c:152-166 */
+/* ------------------------------------------------------------------------ */
+uint64_t orc_tuples(int k, const char *bases, const char *quals, const uint64_t *offsets,
+                    uint64_t nreads, uint8_t fq_cutoff, uint8_t hp_cutoff,
+                    uint64_t *keys, uint8_t *edges)
+{
+  const int W = orc_words_for_k(k);
+  uint64_t n = 0, r;
+  for(r = 0; r < nreads; r++) {
+    const char *seq = bases + offsets[r];
+    const char *qual = quals ? quals + offsets[r] : NULL;
+    size_t len = (size_t)(offsets[r + 1] - offsets[r]), qlen = qual ? len : 0;
+    size_t cs, ce, search = 0;
+    while((cs = orc_contig_start(seq, len, qual, qlen, search, (size_t)k, fq_cutoff, hp_cutoff)) < len) {
+      ce = orc_contig_end(seq, len, qual, qlen, cs, (size_t)k, fq_cutoff, hp_cutoff, &search);
+      orc_bkmer bk = orc_kmer_from_str(seq + cs, k);
+      size_t i;
+      for(i = cs; i + (size_t)k <= ce; i++) {
+        if(i > cs) bk = orc_kmer_shift_add(bk, k, orc_char_to_nuc((unsigned char)seq[i + (size_t)k - 1]));
+        orc_bkmer key = orc_kmer_get_key(bk, k);
+        unsigned o = bkmer_eq(&key, &bk, W) ? 0u : 1u;
+        unsigned e = 0;
+        if(i + (size_t)k < ce) e |= 1u << ((unsigned)orc_char_to_nuc((unsigned char)seq[i + (size_t)k]) + 4u * o);
+        if(i > cs) e |= 1u << ((3u - (unsigned)orc_char_to_nuc((unsigned char)seq[i - 1])) + 4u * (1u - o));
+        if(keys) { int w; for(w = 0; w < W; w++) keys[n * (uint64_t)W + (uint64_t)w] = key.b[w]; }
+        if(edges) edges[n] = (uint8_t)e;
+        n++;
+      }
+    }
+  }
+  return n;
+}

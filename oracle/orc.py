@@ -1,0 +1,210 @@
+"""ctypes binding for the CPU oracle (oracle/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (mccortex_amd/) never
+imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+MAX_W = 4
+
+
+class BKmer(C.Structure):
+    _fields_ = [("b", C.c_uint64 * MAX_W)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "num_se_reads", "num_good_reads", "num_bad_reads", "total_bases_read",
+        "total_bases_loaded", "contigs_parsed", "num_kmers_loaded", "num_kmers_novel")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile liborc.so (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "liborc.so")
+    src = os.path.join(_HERE, "mcx_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    u64p = C.POINTER(C.c_uint64)
+    L.orc_words_for_k.restype = C.c_int
+    L.orc_kmer_from_str.restype = BKmer
+    L.orc_kmer_from_str.argtypes = [C.c_char_p, C.c_int]
+    L.orc_kmer_shift_add.restype = BKmer
+    L.orc_kmer_shift_add.argtypes = [BKmer, C.c_int, C.c_int]
+    L.orc_kmer_revcomp.restype = BKmer
+    L.orc_kmer_revcomp.argtypes = [BKmer, C.c_int]
+    L.orc_kmer_get_key.restype = BKmer
+    L.orc_kmer_get_key.argtypes = [BKmer, C.c_int]
+    L.orc_kmer_hash.restype = C.c_uint32
+    L.orc_kmer_hash.argtypes = [BKmer, C.c_int, C.c_uint32]
+    L.orc_kmer_to_str.argtypes = [BKmer, C.c_int, C.c_char_p]
+    L.orc_hash_table_cap.restype = C.c_uint64
+    L.orc_hash_table_cap.argtypes = [C.c_uint64, u64p, C.POINTER(C.c_uint8)]
+    L.orc_contig_start.restype = C.c_size_t
+    L.orc_contig_start.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t,
+                                   C.c_size_t, C.c_uint8, C.c_uint8]
+    L.orc_contig_end.restype = C.c_size_t
+    L.orc_contig_end.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t,
+                                 C.c_size_t, C.c_uint8, C.c_uint8, C.POINTER(C.c_size_t)]
+    L.orc_graph_new.restype = C.c_void_p
+    L.orc_graph_new.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32]
+    L.orc_graph_free.argtypes = [C.c_void_p]
+    L.orc_graph_set_sample.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    L.orc_graph_nkmers.restype = C.c_uint64
+    L.orc_graph_nkmers.argtypes = [C.c_void_p]
+    L.orc_graph_capacity.restype = C.c_uint64
+    L.orc_graph_capacity.argtypes = [C.c_void_p]
+    L.orc_graph_add_reads.restype = C.c_int
+    L.orc_graph_add_reads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint64, C.c_uint8, C.c_uint8, C.c_int, C.POINTER(Stats)]
+    L.orc_graph_update_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(Stats)]
+    L.orc_graph_ctx_size.restype = C.c_size_t
+    L.orc_graph_ctx_size.argtypes = [C.c_void_p]
+    L.orc_graph_header_size.restype = C.c_size_t
+    L.orc_graph_header_size.argtypes = [C.c_void_p]
+    L.orc_graph_write_ctx.restype = C.c_size_t
+    L.orc_graph_write_ctx.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_graph_lookup.restype = C.c_int
+    L.orc_graph_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]
+    L.orc_tuples.restype = C.c_uint64
+    L.orc_tuples.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                             C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p]
+    _LIB = L
+    return L
+
+
+def ref_lookup3():
+    """The reference's own libs/misc/lookup3.h, compiled into oracle/_ref (or None)."""
+    global _REF
+    if _REF is None:
+        so = os.path.join(_HERE, "_ref", "liblk3ref.so")
+        if not os.path.exists(so):
+            return None
+        _REF = C.CDLL(so)
+        _REF.ref_lk3_hashlittle.restype = C.c_uint32
+        _REF.ref_lk3_hashlittle.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+    return _REF
+
+
+def pack_reads(reads):
+    """list of bytes/str -> (bases uint8[total], offsets uint64[n+1]) without separators."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return bases, offs
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Graph:
+    """Oracle graph: reference-shaped bucketed table + covg/edge arrays."""
+
+    def __init__(self, k, ncols=1, capacity=1 << 20, seed=12345):
+        self.L = lib()
+        self.k, self.ncols = k, ncols
+        self.W = self.L.orc_words_for_k(k)
+        self.h = self.L.orc_graph_new(k, ncols, capacity, seed)
+        if not self.h:
+            raise ValueError("bad oracle graph parameters")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_graph_free(self.h)
+            self.h = None
+
+    def set_sample(self, col, name):
+        assert self.L.orc_graph_set_sample(self.h, col, name.encode()) == 0
+
+    def add_reads(self, colour, bases, offsets, quals=None, fq_cutoff=0, hp_cutoff=0, nthreads=1,
+                  stats=None):
+        st = stats if stats is not None else Stats()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        rc = self.L.orc_graph_add_reads(self.h, colour, _ptr(bases), _ptr(quals), _ptr(offsets),
+                                        len(offsets) - 1, fq_cutoff, hp_cutoff, nthreads, C.byref(st))
+        if rc != 0:
+            raise RuntimeError("Hash table is full" if rc == -1 else "oracle error %d" % rc)
+        return st
+
+    def update_stats(self, colour, st):
+        self.L.orc_graph_update_stats(self.h, colour, C.byref(st))
+
+    @property
+    def nkmers(self):
+        return int(self.L.orc_graph_nkmers(self.h))
+
+    def ctx_bytes(self, sorted_=True):
+        n = self.L.orc_graph_ctx_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        w = self.L.orc_graph_write_ctx(self.h, 1 if sorted_ else 0, _ptr(buf))
+        assert w == n, (w, n)
+        return buf.tobytes()
+
+    def header_size(self):
+        return int(self.L.orc_graph_header_size(self.h))
+
+    def lookup(self, kmer):
+        cov = np.zeros(self.ncols, np.uint32)
+        edg = np.zeros(self.ncols, np.uint8)
+        ok = self.L.orc_graph_lookup(self.h, kmer.encode(), _ptr(cov), _ptr(edg))
+        return (cov, edg) if ok else None
+
+
+def tuples(k, bases, offsets, quals=None, fq_cutoff=0, hp_cutoff=0):
+    """Per-occurrence (key words, edge byte) stream in read order."""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    nreads = len(offsets) - 1
+    n = L.orc_tuples(k, _ptr(bases), _ptr(quals), _ptr(offsets), nreads, fq_cutoff, hp_cutoff, None, None)
+    W = L.orc_words_for_k(k)
+    keys = np.zeros((n, W), dtype=np.uint64)
+    edges = np.zeros(n, dtype=np.uint8)
+    L.orc_tuples(k, _ptr(bases), _ptr(quals), _ptr(offsets), nreads, fq_cutoff, hp_cutoff, _ptr(keys), _ptr(edges))
+    return keys, edges
+
+
+def graph_from_tuples(keys, edges, colours=None, ncols=1):
+    """Reduce a tuple stream to the sorted record set {key: (covg[], edges[])} with numpy --
+    the order-independent definition of the graph."""
+    W = keys.shape[1]
+    if colours is None:
+        colours = np.zeros(len(keys), dtype=np.int64)
+    order = np.lexsort([keys[:, w] for w in range(W - 1, -1, -1)])
+    ks = keys[order]
+    es = edges[order]
+    cs = np.asarray(colours)[order]
+    if len(ks) == 0:
+        return ks, np.zeros((0, ncols), np.uint32), np.zeros((0, ncols), np.uint8)
+    new = np.ones(len(ks), dtype=bool)
+    new[1:] = np.any(ks[1:] != ks[:-1], axis=1)
+    gid = np.cumsum(new) - 1
+    ng = int(gid[-1]) + 1
+    cov = np.zeros((ng, ncols), dtype=np.uint64)
+    np.add.at(cov, (gid, cs), 1)
+    edg = np.zeros((ng, ncols), dtype=np.uint8)
+    np.bitwise_or.at(edg, (gid, cs), es)
+    return ks[new], np.minimum(cov, 0xFFFFFFFF).astype(np.uint32), edg
