@@ -1,0 +1,146 @@
+/*
+ * mcx_gpu.h -- C ABI of the MI355X (gfx950) backend for McCortex `build`.
+ *
+ * The reference has no plugin/FFI layer: `ctx_build` (src/commands/ctx_build.c:245)
+ * calls statically linked C functions.  This header is the set of entry points
+ * a C host (the reference's own `ctx_build`, or our `mccortex<K> build`) binds
+ * instead of those functions; every entry names the reference call it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only.
+ *
+ * Conventions: every function returns MCX_OK (0) or a negative mcx_status and
+ * sets a thread-local message readable with mcx_last_error().  No callbacks
+ * into the host except the export sink.  A handle is NOT thread-safe: one
+ * submitting host thread per handle (kernels run asynchronously on the
+ * handle's HIP stream).  The library never falls back to a CPU path: without
+ * a gfx950 device mcx_graph_create() fails with MCX_ERR_NODEVICE.
+ */
+#ifndef MCX_GPU_H_
+#define MCX_GPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MCX_OK = 0,
+  MCX_ERR_ARG = -1,       /* bad argument (even k, k out of range, colour >= ncols ...) */
+  MCX_ERR_NODEVICE = -2,  /* no usable HIP device */
+  MCX_ERR_NOMEM = -3,     /* device/host allocation failed */
+  MCX_ERR_FULL = -4,      /* "Hash table is full" (src/graph/hash_table.c:119-123) */
+  MCX_ERR_HIP = -5,       /* HIP runtime error, see mcx_last_error() */
+  MCX_ERR_SINK = -6       /* export sink returned non-zero */
+} mcx_status;
+
+/* Subset of SeqLoadingStats (src/basic/seq_loading_stats.h:5-14) that the
+ * build path fills (src/tools/build_graph.c:173-188,209-213). */
+typedef struct {
+  uint64_t num_se_reads;
+  uint64_t num_good_reads;      /* reads with >= 1 contig */
+  uint64_t num_bad_reads;       /* reads with no contig   */
+  uint64_t total_bases_read;
+  uint64_t total_bases_loaded;  /* sum of contig lengths  */
+  uint64_t contigs_parsed;
+  uint64_t num_kmers_loaded;    /* k-mer occurrences inserted */
+  uint64_t num_kmers_novel;     /* occurrences that created a new node */
+} mcx_load_stats;
+
+typedef struct mcx_graph mcx_graph;
+
+const char *mcx_last_error(void);
+const char *mcx_version(void);
+int mcx_device_count(void);
+
+/* Replaces db_graph_alloc (src/graph/db_graph.c:23) + hash_table_alloc
+ * (src/graph/hash_table.c:16-52) for the build path.
+ *   kmer_size       odd, 3..63 (W = 1 word for k<=31, 2 words for 33..63;
+ *                   src/graph/binary_kmer.h:10-18)
+ *   ncols           colours (>=1); coverage and edges are kept per colour
+ *   capacity_kmers  minimum number of k-mer slots (the reference's -n); the
+ *                   slot layout, probe sequence and seed are free because
+ *                   parity is on the sorted record set
+ *   device          HIP device ordinal */
+int mcx_graph_create(mcx_graph **g, int kmer_size, int ncols,
+                     uint64_t capacity_kmers, int device);
+void mcx_graph_destroy(mcx_graph *g);
+
+/* Empty the table and zero the statistics (graph stays allocated). */
+int mcx_graph_reset(mcx_graph *g);
+
+/* Slots actually allocated (>= capacity_kmers) and bytes of HBM held. */
+int mcx_graph_capacity(const mcx_graph *g, uint64_t *slots, uint64_t *bytes);
+
+/* Replaces build_graph_from_reads_mt (src/tools/build_graph.c:192-231, SE path
+ * without --remove-pcr) for a whole batch of reads held in host memory:
+ * contig split (src/basic/seq_reader.c:61-172), rolling k-mers, canonical key,
+ * find-or-insert, coverage +1, edge OR (src/tools/build_graph.c:122-150).
+ *   bases          concatenated read bases (ASCII, any case), no separators
+ *   quals          NULL, or quality bytes in the same layout (only read when
+ *                  fq_cutoff_abs > 0)
+ *   read_offsets   nreads+1 offsets into bases/quals
+ *   fq_cutoff_abs  prefs.fq_cutoff + FASTQ offset, 0 = off (build_graph.c:203-206)
+ *   hp_cutoff      homopolymer cutoff, 0 = off
+ *   stats_accum    optional; read-level counters are added immediately, the
+ *                  contig/k-mer counters after the batch has been processed
+ * The call returns once the batch is staged; use mcx_graph_sync() to drain. */
+int mcx_graph_add_reads(mcx_graph *g, int colour,
+                        const uint8_t *bases, const uint8_t *quals,
+                        const uint64_t *read_offsets, uint64_t nreads,
+                        uint8_t fq_cutoff_abs, uint8_t hp_cutoff,
+                        mcx_load_stats *stats_accum);
+
+/* Device-resident variant of the same step: `d_stream` is a byte stream in HBM
+ * in which reads are separated by at least one byte that is not one of
+ * ACGTacgt (e.g. '\n'); every maximal ACGT run of length >= k is one contig
+ * (what seq_contig_start/end yield with -Q/-H off).  Must be 16-byte aligned.
+ * Asynchronous on the handle's stream. */
+int mcx_graph_add_stream_dev(mcx_graph *g, int colour,
+                             const void *d_stream, uint64_t nbytes);
+
+/* Sharded build.  Step 1 on every rank: k-merise a device
+ * stream and bin the per-occurrence tuples (canonical key words, edge byte) by
+ * owner = lookup3-secondary-hash(key) % nparts.  d_keys holds nparts bins of
+ * bin_capacity tuples, W words each; d_edges likewise one byte per tuple;
+ * d_counts[nparts] (uint64) receives the fill of every bin (must be zeroed by
+ * the caller).  Overflowing a bin sets MCX_ERR_FULL at the next sync. */
+int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes,
+                                   int nparts, uint64_t bin_capacity,
+                                   void *d_keys, void *d_edges, void *d_counts);
+/* Step 2 on the owner, after the exchange: insert n tuples. */
+int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void *d_keys,
+                                const void *d_edges, uint64_t n);
+/* Owner of a canonical key (host-side helper for tests / the exchange). */
+uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts);
+
+/* Wait for all submitted work; reports MCX_ERR_FULL if any insert ran out of
+ * slots (the reference dies with "Hash table is full"). */
+int mcx_graph_sync(mcx_graph *g);
+
+/* hash_table_nkmers (src/graph/hash_table.h:37). Implies a sync. */
+int mcx_graph_nkmers(mcx_graph *g, uint64_t *n);
+/* Contig/k-mer counters accumulated by the device since create/reset. */
+int mcx_graph_device_stats(mcx_graph *g, mcx_load_stats *out);
+
+/* HIP stream the handle submits on (hipStream_t as void*), so callers can
+ * bracket it with their own events. */
+void *mcx_graph_stream(mcx_graph *g);
+
+/* Replaces graph_write_all_kmers_direct (src/graph/graph_writer.c:182-268):
+ * streams the records in .ctx v6 body layout (W x u64 key, ncols x u32 covg,
+ * ncols x u8 edges; src/graph/graph_writer.c:116-127) to `sink` in chunks.
+ * sorted != 0 orders records by key (hash_table_sorted, hash_table.c:362-374),
+ * which is the only order in which the reference output is reproducible. */
+typedef int (*mcx_sink_fn)(void *ctx, const void *records, size_t nbytes);
+int mcx_graph_export(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx);
+
+/* Host-side primitives exported for parity tests of rows A-C (no device). */
+void mcx_kmer_from_str(const char *seq, int kmer_size, uint64_t *words_out);
+void mcx_kmer_canonical(const uint64_t *words_in, int kmer_size, uint64_t *key_out, int *orient_out);
+uint32_t mcx_kmer_hash(const uint64_t *key_words, int kmer_size, uint32_t initval);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCX_GPU_H_ */

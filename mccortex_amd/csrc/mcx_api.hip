@@ -1,0 +1,612 @@
+// mcx_api.hip -- C ABI (include/mcx_gpu.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC mcx_api.hip -o libmcxgpu.so
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/mcx_gpu.h"
+#include "mcx_kernels.h"
+
+using namespace mcx;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s (%s:%d)",   \
+                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+
+constexpr uint64_t kCarry = 128;  // context bytes carried between chunks
+// New stream bytes per staged chunk (MCX_STAGE_BYTES overrides, for tests of the chunk seams).
+static uint64_t stage_bytes()
+{
+  static uint64_t v = 0;
+  if (!v) {
+    const char *e = getenv("MCX_STAGE_BYTES");
+    v = e ? strtoull(e, nullptr, 10) : (32ull << 20);
+    if (v < 1024) v = 1024;
+    v = (v + 63) / 64 * 64;
+  }
+  return v;
+}
+#define kStageBytes stage_bytes()
+
+struct mcx_graph {
+  int k = 0, W = 0, ncols = 0, device = 0;
+  hipStream_t stream = nullptr;
+  TableView t{};
+  uint64_t table_bytes = 0;
+  Counters *d_ctr = nullptr;
+  Counters *h_ctr = nullptr;  // pinned
+  // host staging (double buffered)
+  uint8_t *h_stage[2] = {nullptr, nullptr};
+  uint8_t *d_stage[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  uint64_t stage_alloc = 0;
+  int cur = 0;
+  int grid = 0;
+};
+
+extern "C" const char *mcx_last_error(void) { return g_err; }
+extern "C" const char *mcx_version(void) { return "mccortex_amd 0.1 (gfx950)"; }
+
+extern "C" int mcx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int check_k(int k)
+{
+  if (k < 3 || k > 63 || !(k & 1)) return fail(MCX_ERR_ARG, "kmer size must be odd and 3..63 (got %d)", k);
+  if (k == 32) return MCX_ERR_ARG;
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_create(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers, int device)
+{
+  if (!out) return fail(MCX_ERR_ARG, "null handle pointer");
+  *out = nullptr;
+  if (check_k(kmer_size) != MCX_OK) return MCX_ERR_ARG;
+  if (ncols < 1 || ncols > 4096) return fail(MCX_ERR_ARG, "ncols out of range: %d", ncols);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MCX_ERR_NODEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(MCX_ERR_NODEVICE, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  mcx_graph *g = new mcx_graph();
+  g->k = kmer_size;
+  g->W = words_for_k(kmer_size);
+  g->ncols = ncols;
+  g->device = device;
+  const uint64_t min_slots = 1024;
+  uint64_t slots = std::max(capacity_kmers, min_slots);
+  slots = (slots + 1023) / 1024 * 1024;
+  if (slots / kBucket > 0xFFFFFFFFull) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }
+  g->t.nslots = slots;
+  g->t.nbuckets = (uint32_t)(slots / kBucket);
+  g->t.S = (uint32_t)(g->W + ncols);
+  g->t.max_probe = (uint32_t)std::min<uint64_t>(slots, 8192);
+  g->table_bytes = slots * g->t.S * 8;
+
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  g->grid = prop.multiProcessorCount * 8;
+
+#define CREATE_TRY(expr)                                                            \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      int rc = fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+      mcx_graph_destroy(g);                                                         \
+      return rc;                                                                    \
+    }                                                                               \
+  } while (0)
+  CREATE_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc((void **)&g->t.rec, g->table_bytes));
+  CREATE_TRY(hipMalloc((void **)&g->d_ctr, sizeof(Counters)));
+  CREATE_TRY(hipHostMalloc((void **)&g->h_ctr, sizeof(Counters), hipHostMallocDefault));
+  CREATE_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
+  CREATE_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
+  CREATE_TRY(hipStreamSynchronize(g->stream));
+#undef CREATE_TRY
+  *out = g;
+  return MCX_OK;
+}
+
+extern "C" void mcx_graph_destroy(mcx_graph *g)
+{
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  for (int i = 0; i < 2; i++) {
+    if (g->h_stage[i]) (void)hipHostFree(g->h_stage[i]);
+    if (g->d_stage[i]) (void)hipFree(g->d_stage[i]);
+    if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+  }
+  if (g->t.rec) (void)hipFree(g->t.rec);
+  if (g->d_ctr) (void)hipFree(g->d_ctr);
+  if (g->h_ctr) (void)hipHostFree(g->h_ctr);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+}
+
+extern "C" int mcx_graph_reset(mcx_graph *g)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
+  HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_capacity(const mcx_graph *g, uint64_t *slots, uint64_t *bytes)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (slots) *slots = g->t.nslots;
+  if (bytes) *bytes = g->table_bytes;
+  return MCX_OK;
+}
+
+extern "C" void *mcx_graph_stream(mcx_graph *g) { return g ? (void *)g->stream : nullptr; }
+
+// ---------------------------------------------------------------------------
+// kernel dispatch
+// ---------------------------------------------------------------------------
+struct StreamLaunch {
+  const uint8_t *stream;
+  uint64_t nbytes, pos_lo, pos_hi;
+  unsigned char *flag;
+};
+
+template <int W, bool ONECOL, int MODE>
+static void launch_stream_t(mcx_graph *g, const StreamLaunch &L, int colour, const PartitionSink<W> &ps)
+{
+  StreamArgs a;
+  a.stream = L.stream;
+  a.nbytes = L.nbytes;
+  a.pos_lo = L.pos_lo;
+  a.pos_hi = L.pos_hi;
+  a.tile0 = L.pos_lo / kTile;
+  a.ntiles = (L.pos_hi + kTile - 1) / kTile;
+  a.k = g->k;
+  a.ctr = g->d_ctr;
+  a.flag = L.flag;
+  InsertSink<W, ONECOL> is;
+  is.t = g->t;
+  is.col = (uint32_t)colour;
+  const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
+  if (!nt) return;
+  const int grid = (int)std::min<uint64_t>(nt, (uint64_t)g->grid);
+  hipLaunchKernelGGL((k_stream<W, ONECOL, MODE>), dim3(grid), dim3(kThreads), 0, g->stream, a, is, ps);
+}
+
+static int launch_insert_stream(mcx_graph *g, const StreamLaunch &L, int colour)
+{
+  if (g->W == 1) {
+    PartitionSink<1> ps{};
+    if (g->ncols == 1) launch_stream_t<1, true, 0>(g, L, colour, ps);
+    else launch_stream_t<1, false, 0>(g, L, colour, ps);
+  } else {
+    PartitionSink<2> ps{};
+    if (g->ncols == 1) launch_stream_t<2, true, 0>(g, L, colour, ps);
+    else launch_stream_t<2, false, 0>(g, L, colour, ps);
+  }
+  HIP_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_add_stream_dev(mcx_graph *g, int colour, const void *d_stream, uint64_t nbytes)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+  if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  if (!nbytes) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
+  return launch_insert_stream(g, L, colour);
+}
+
+extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, int nparts,
+                                              uint64_t bin_capacity, void *d_keys, void *d_edges, void *d_counts)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (nparts < 1 || nparts > kMaxParts) return fail(MCX_ERR_ARG, "nparts must be 1..%d", kMaxParts);
+  if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  if (!nbytes) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
+  if (g->W == 1) {
+    PartitionSink<1> ps{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity, (uint32_t)nparts};
+    launch_stream_t<1, true, 1>(g, L, 0, ps);
+  } else {
+    PartitionSink<2> ps{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity, (uint32_t)nparts};
+    launch_stream_t<2, true, 1>(g, L, 0, ps);
+  }
+  HIP_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_edges, uint64_t n)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+  if (!n) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  const int grid = (int)std::min<uint64_t>((n + kThreads * kBatch - 1) / (kThreads * kBatch), (uint64_t)g->grid);
+  if (g->W == 1) {
+    if (g->ncols == 1) {
+      InsertSink<1, true> s{g->t, (uint32_t)colour};
+      hipLaunchKernelGGL((k_insert_tuples<1, true>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
+    } else {
+      InsertSink<1, false> s{g->t, (uint32_t)colour};
+      hipLaunchKernelGGL((k_insert_tuples<1, false>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
+    }
+  } else {
+    if (g->ncols == 1) {
+      InsertSink<2, true> s{g->t, (uint32_t)colour};
+      hipLaunchKernelGGL((k_insert_tuples<2, true>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
+    } else {
+      InsertSink<2, false> s{g->t, (uint32_t)colour};
+      hipLaunchKernelGGL((k_insert_tuples<2, false>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+extern "C" uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts)
+{
+  uint32_t h2 = 0;
+  if (words_for_k(kmer_size) == 1) {
+    Kmer<1> k{{key_words[0]}};
+    kmer_hash<1>(k, 0, &h2);
+  } else {
+    Kmer<2> k{{key_words[0], key_words[1]}};
+    kmer_hash<2>(k, 0, &h2);
+  }
+  return (uint32_t)(((uint64_t)h2 * (uint32_t)nparts) >> 32);
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer entry: stage reads as a '\n'-separated stream
+// ---------------------------------------------------------------------------
+static int ensure_stage(mcx_graph *g)
+{
+  if (g->stage_alloc) return MCX_OK;
+  // stream bytes + worst-case one offset per 2 bytes would be silly; offsets are
+  // staged in a second region sized for reads of >= 15 bytes on average and the
+  // filler stops a chunk when either region is full.
+  const uint64_t bytes = kCarry + kStageBytes + 256 + (kStageBytes / 16 + 2) * sizeof(uint64_t);
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(hipHostMalloc((void **)&g->h_stage[i], bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&g->d_stage[i], bytes));
+    HIP_TRY(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
+  }
+  g->stage_alloc = bytes;
+  return MCX_OK;
+}
+
+static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
+                        const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp);
+
+extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
+                                   const uint64_t *off, uint64_t nreads, uint8_t fq_cutoff_abs,
+                                   uint8_t hp_cutoff, mcx_load_stats *stats_accum)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+  if (nreads && (!bases || !off)) return fail(MCX_ERR_ARG, "null read buffers");
+  HIP_TRY(hipSetDevice(g->device));
+  if (stats_accum) {
+    stats_accum->num_se_reads += nreads;
+    stats_accum->total_bases_read += nreads ? off[nreads] - off[0] : 0;
+  }
+  if (!nreads) return MCX_OK;
+  if ((fq_cutoff_abs > 0 && quals) || hp_cutoff > 0)
+    return add_reads_qh(g, colour, bases, quals, off, nreads, fq_cutoff_abs, hp_cutoff);
+
+  int rc = ensure_stage(g);
+  if (rc != MCX_OK) return rc;
+
+  unsigned char *d_flags = nullptr;
+  HIP_TRY(hipMallocAsync((void **)&d_flags, nreads, g->stream));
+  HIP_TRY(hipMemsetAsync(d_flags, 0, nreads, g->stream));
+
+  const uint64_t off_region = kCarry + kStageBytes + 256;  // byte offset of the staged offsets (8-aligned)
+  const uint64_t max_offs = kStageBytes / 16;
+  uint64_t r = 0, r_pos = 0;  // next read, bytes of it already staged
+  uint8_t carry[kCarry];
+  memset(carry, '\n', kCarry);
+  while (r < nreads) {
+    const int b = g->cur;
+    g->cur ^= 1;
+    HIP_TRY(hipEventSynchronize(g->ev[b]));  // previous use of this buffer finished
+    uint8_t *hs = g->h_stage[b];
+    uint64_t *hoff = reinterpret_cast<uint64_t *>(hs + off_region);
+    memcpy(hs, carry, kCarry);
+    uint64_t L = 0, nwhole = 0;
+    const uint64_t r0 = r;
+    long long piece_of = -1;  // >= 0: chunk holds a piece of this (long) read only
+    while (r < nreads) {
+      const uint64_t len = off[r + 1] - off[r];
+      const uint64_t remain = len - r_pos;
+      if (r_pos == 0 && remain + 1 <= kStageBytes - L && nwhole < max_offs) {
+        hoff[nwhole++] = kCarry + L;
+        memcpy(hs + kCarry + L, bases + off[r], len);
+        L += len;
+        hs[kCarry + L++] = '\n';
+        r++;
+      } else if (L == 0) {  // read longer than a chunk (or its tail): stage a piece on its own
+        const uint64_t take = std::min(remain, kStageBytes - 1);
+        memcpy(hs + kCarry, bases + off[r] + r_pos, take);
+        L = take;
+        r_pos += take;
+        piece_of = (long long)r;
+        if (r_pos == len) { hs[kCarry + L++] = '\n'; r++; r_pos = 0; }
+        break;
+      } else {
+        break;
+      }
+    }
+    hoff[nwhole] = kCarry + L;
+    const uint64_t total = kCarry + L;
+    memcpy(carry, hs + total - kCarry, kCarry);
+    // pad the tail so the 16-byte chunk loads of the kernel stay inside the copy
+    memset(hs + total, '\n', 64);
+    HIP_TRY(hipMemcpyAsync(g->d_stage[b], hs, total + 64, hipMemcpyHostToDevice, g->stream));
+    if (nwhole)
+      HIP_TRY(hipMemcpyAsync(g->d_stage[b] + off_region, hoff, (nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
+    StreamLaunch SL{g->d_stage[b], total, kCarry - (uint64_t)g->k, total - (uint64_t)g->k,
+                    piece_of >= 0 ? d_flags + piece_of : nullptr};
+    rc = launch_insert_stream(g, SL, colour);
+    if (rc != MCX_OK) return rc;
+    if (nwhole) {
+      hipLaunchKernelGGL(k_read_flags, dim3((unsigned)((nwhole + 255) / 256)), dim3(256), 0, g->stream,
+                         (const uint8_t *)g->d_stage[b], (const uint64_t *)(g->d_stage[b] + off_region), nwhole,
+                         g->k, d_flags + r0);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(g->ev[b], g->stream));
+  }
+  hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, g->stream, (const unsigned char *)d_flags, nreads, g->d_ctr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFreeAsync(d_flags, g->stream));
+  return MCX_OK;
+}
+
+// -Q / -H: contigs are cut on the device by the reference's own rules, written
+// out as a fresh separator stream and fed to the same front end.
+static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
+                        const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp)
+{
+  const uint64_t base0 = off[0], nb = off[nreads] - off[0];
+  uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_out = nullptr;
+  uint64_t *d_off = nullptr, *d_sizes = nullptr, *d_ooff = nullptr;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  std::vector<uint64_t> rel(nreads + 1);
+  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
+  HIP_TRY(hipMalloc((void **)&d_bases, nb + 16));
+  if (quals && fq > 0) HIP_TRY(hipMalloc((void **)&d_quals, nb + 16));
+  HIP_TRY(hipMalloc((void **)&d_off, (nreads + 1) * 8));
+  HIP_TRY(hipMalloc((void **)&d_sizes, (nreads + 1) * 8));
+  HIP_TRY(hipMalloc((void **)&d_ooff, (nreads + 1) * 8));
+  HIP_TRY(hipMemcpyAsync(d_bases, bases + base0, nb, hipMemcpyHostToDevice, g->stream));
+  if (d_quals) HIP_TRY(hipMemcpyAsync(d_quals, quals + base0, nb, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(hipMemcpyAsync(d_off, rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(hipMemsetAsync(d_sizes, 0, (nreads + 1) * 8, g->stream));
+  const unsigned blocks = (unsigned)((nreads + 127) / 128);
+  hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
+                     (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, 0, d_sizes, (const uint64_t *)nullptr, (uint8_t *)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
+  HIP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  HIP_TRY(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
+  uint64_t out_bytes = 0;
+  HIP_TRY(hipMemcpyAsync(&out_bytes, d_ooff + nreads, 8, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  int rc = MCX_OK;
+  if (out_bytes) {
+    HIP_TRY(hipMalloc((void **)&d_out, out_bytes + 64));
+    HIP_TRY(hipMemsetAsync(d_out + out_bytes, '\n', 64, g->stream));
+    hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
+                       (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, 1, d_sizes, (const uint64_t *)d_ooff, d_out);
+    HIP_TRY(hipGetLastError());
+    StreamLaunch SL{d_out, out_bytes, 0, out_bytes, nullptr};
+    rc = launch_insert_stream(g, SL, colour);
+  }
+  hipLaunchKernelGGL(k_count_sizes, dim3(256), dim3(256), 0, g->stream, (const uint64_t *)d_sizes, nreads, g->d_ctr);
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  (void)hipFree(d_bases); (void)hipFree(d_quals); (void)hipFree(d_off); (void)hipFree(d_sizes);
+  (void)hipFree(d_ooff); (void)hipFree(d_tmp); (void)hipFree(d_out);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// sync / stats
+// ---------------------------------------------------------------------------
+static int fetch_counters(mcx_graph *g)
+{
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipMemcpyAsync(g->h_ctr, g->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  if (g->h_ctr->full) return fail(MCX_ERR_FULL, "Hash table is full");
+  if (g->h_ctr->bin_over) return fail(MCX_ERR_FULL, "partition bin overflow");
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_sync(mcx_graph *g)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  return fetch_counters(g);
+}
+
+extern "C" int mcx_graph_nkmers(mcx_graph *g, uint64_t *n)
+{
+  if (!g || !n) return fail(MCX_ERR_ARG, "null argument");
+  int rc = fetch_counters(g);
+  *n = g->h_ctr->novel;
+  return rc;
+}
+
+extern "C" int mcx_graph_device_stats(mcx_graph *g, mcx_load_stats *out)
+{
+  if (!g || !out) return fail(MCX_ERR_ARG, "null argument");
+  int rc = fetch_counters(g);
+  memset(out, 0, sizeof(*out));
+  const Counters &c = *g->h_ctr;
+  out->num_good_reads = c.good_reads;
+  out->num_bad_reads = c.bad_reads;
+  out->contigs_parsed = c.contigs;
+  out->num_kmers_loaded = c.kmers;
+  out->num_kmers_novel = c.novel;
+  // sum of contig lengths = k-mers + (k-1) per contig (build_graph.c:173-176)
+  out->total_bases_loaded = c.kmers + (uint64_t)(g->k - 1) * c.contigs;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// export
+// ---------------------------------------------------------------------------
+template <int W>
+static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
+{
+  int rc = fetch_counters(g);
+  if (rc != MCX_OK) return rc;
+  const uint64_t n = g->h_ctr->novel;
+  if (n == 0) return MCX_OK;
+  hipStream_t st = g->stream;
+  uint64_t *d_k0 = nullptr, *d_k1 = nullptr, *d_slot = nullptr, *d_idx = nullptr, *d_idx2 = nullptr, *d_ks = nullptr, *d_ks2 = nullptr;
+  unsigned long long *d_cursor = nullptr;
+  void *d_tmp = nullptr;
+  uint8_t *d_rec = nullptr, *h_rec = nullptr;
+  size_t tmp_bytes = 0;
+  auto cleanup = [&]() {
+    (void)hipFree(d_k0); (void)hipFree(d_k1); (void)hipFree(d_slot); (void)hipFree(d_idx); (void)hipFree(d_idx2);
+    (void)hipFree(d_ks); (void)hipFree(d_ks2); (void)hipFree(d_cursor); (void)hipFree(d_tmp); (void)hipFree(d_rec);
+    if (h_rec) (void)hipHostFree(h_rec);
+  };
+#define EXP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      cleanup();                                                                          \
+      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    }                                                                                     \
+  } while (0)
+  EXP_TRY(hipMalloc((void **)&d_k0, n * 8));
+  if (W == 2) EXP_TRY(hipMalloc((void **)&d_k1, n * 8));
+  EXP_TRY(hipMalloc((void **)&d_slot, n * 8));
+  EXP_TRY(hipMalloc((void **)&d_cursor, 8));
+  EXP_TRY(hipMemsetAsync(d_cursor, 0, 8, st));
+  hipLaunchKernelGGL((k_compact<W>), dim3(g->grid), dim3(kThreads), 0, st, g->t, d_k0, d_k1, d_slot, d_cursor, n);
+  EXP_TRY(hipGetLastError());
+  unsigned long long found = 0;
+  EXP_TRY(hipMemcpyAsync(&found, d_cursor, 8, hipMemcpyDeviceToHost, st));
+  EXP_TRY(hipStreamSynchronize(st));
+  if (found != n) { cleanup(); return fail(MCX_ERR_HIP, "table scan found %llu nodes, counter says %llu", found, (unsigned long long)n); }
+
+  // permutation of the compacted entries: by key (sorted) or by slot (table order)
+  EXP_TRY(hipMalloc((void **)&d_idx, n * 8));
+  EXP_TRY(hipMalloc((void **)&d_idx2, n * 8));
+  EXP_TRY(hipMalloc((void **)&d_ks, n * 8));
+  EXP_TRY(hipMalloc((void **)&d_ks2, n * 8));
+  const unsigned gb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, n);
+  const uint64_t *first_key = sorted ? (W == 2 ? d_k1 : d_k0) : d_slot;
+  EXP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, first_key, d_ks, d_idx, d_idx2, n, 0, 64, st));
+  EXP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, first_key, d_ks, d_idx, d_idx2, n, 0, 64, st));
+  uint64_t *perm = d_idx2;
+  if (sorted && W == 2) {  // LSD: stable second pass on the most significant word
+    hipLaunchKernelGGL(k_gather_u64, dim3(gb), dim3(256), 0, st, (const uint64_t *)d_k0, (const uint64_t *)d_idx2, d_ks2, n);
+    EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, d_idx2, d_idx, n, 0, 64, st));
+    perm = d_idx;
+  }
+
+  const uint32_t recsz = 8u * W + 5u * (uint32_t)g->ncols;
+  const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz);
+  EXP_TRY(hipMalloc((void **)&d_rec, chunk * recsz));
+  EXP_TRY(hipHostMalloc((void **)&h_rec, chunk * recsz, hipHostMallocDefault));
+  for (uint64_t first = 0; first < n; first += chunk) {
+    const uint64_t cnt = std::min(chunk, n - first);
+    hipLaunchKernelGGL((k_emit_records<W>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g->t,
+                       (const uint64_t *)d_slot, (const uint64_t *)perm, first, cnt, (uint32_t)g->ncols, d_rec);
+    EXP_TRY(hipGetLastError());
+    EXP_TRY(hipMemcpyAsync(h_rec, d_rec, cnt * recsz, hipMemcpyDeviceToHost, st));
+    EXP_TRY(hipStreamSynchronize(st));
+    if (sink(ctx, h_rec, cnt * recsz) != 0) { cleanup(); return fail(MCX_ERR_SINK, "export sink failed"); }
+  }
+#undef EXP_TRY
+  cleanup();
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_export(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
+{
+  if (!g || !sink) return fail(MCX_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(g->device));
+  return g->W == 1 ? export_t<1>(g, sorted, sink, ctx) : export_t<2>(g, sorted, sink, ctx);
+}
+
+// ---------------------------------------------------------------------------
+// host-side primitives (rows A-C), same templates the kernels use
+// ---------------------------------------------------------------------------
+extern "C" void mcx_kmer_from_str(const char *seq, int k, uint64_t *out)
+{
+  const int W = words_for_k(k);
+  uint64_t hi = 0, lo = 0;  // 128-bit shift register, lo = least significant
+  for (int i = 0; i < k; i++) {
+    hi = (hi << 2) | (lo >> 62);
+    lo = (lo << 2) | base_code((unsigned char)seq[i]);
+  }
+  if (W == 1) out[0] = lo;
+  else { out[0] = hi; out[1] = lo; }
+}
+
+extern "C" void mcx_kmer_canonical(const uint64_t *in, int k, uint64_t *key_out, int *orient_out)
+{
+  uint32_t o = 0;
+  if (words_for_k(k) == 1) {
+    Kmer<1> fw{{in[0]}};
+    Kmer<1> key = canonical<1>(fw, revcomp<1>(fw, k), o);
+    key_out[0] = key.w[0];
+  } else {
+    Kmer<2> fw{{in[0], in[1]}};
+    Kmer<2> key = canonical<2>(fw, revcomp<2>(fw, k), o);
+    key_out[0] = key.w[0]; key_out[1] = key.w[1];
+  }
+  if (orient_out) *orient_out = (int)o;
+}
+
+extern "C" uint32_t mcx_kmer_hash(const uint64_t *key, int k, uint32_t initval)
+{
+  if (words_for_k(k) == 1) { Kmer<1> x{{key[0]}}; return kmer_hash<1>(x, initval, nullptr); }
+  Kmer<2> x{{key[0], key[1]}};
+  return kmer_hash<2>(x, initval, nullptr);
+}

@@ -1,0 +1,644 @@
+// mcx_kernels.h -- gfx950 kernels of the McCortex `build` hot path (included by mcx_api.hip).
+//
+// One pass over a byte stream of reads in HBM does what the reference does per
+// read on the CPU (src/tools/build_graph.c:122-189): split into ACGT contigs,
+// roll 2-bit k-mers, canonicalise, Lookup3-hash, find-or-insert into an
+// open-addressed table in HBM, coverage +1, edge OR.
+//
+// Integer / atomic work only: no MFMA.  Bound by random HBM sector accesses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mcx_kmer.h"
+
+namespace mcx {
+
+// ---------------------------------------------------------------------------
+// Table layout in HBM
+// ---------------------------------------------------------------------------
+// Array of records, S = W + ncols 64-bit words each:
+//   word 0      : key word 0 | kFlag            (0 = empty slot)
+//   word 1..W-1 : remaining key words
+//   word W+c    : colour c value = coverage << 8 | edge byte
+// Coverage is a 56-bit count (never wraps) clamped to UINT32_MAX on export,
+// which is the reference's saturating +1 (src/graph/db_node.c:139-144); the
+// edge byte is only ever OR-ed (src/graph/db_node.h:273-274).  Key, coverage
+// and edges of a node share one 64-byte sector, so an occurrence costs one
+// random sector instead of the reference's three arrays.
+constexpr int kBucket = 4;  // slots per hash bucket (64 B when S == 2)
+
+struct TableView {
+  uint64_t *rec;
+  uint64_t nslots;    // multiple of kBucket
+  uint32_t nbuckets;  // nslots / kBucket
+  uint32_t S;         // words per record
+  uint32_t max_probe;
+};
+
+struct Counters {  // device-resident, 64-bit each
+  unsigned long long novel;     // nodes created (== hash_table num_kmers)
+  unsigned long long kmers;     // k-mer occurrences processed
+  unsigned long long contigs;   // contigs started
+  unsigned long long full;      // != 0: an insert ran out of probes
+  unsigned long long bin_over;  // != 0: a partition bin overflowed
+  unsigned long long good_reads, bad_reads;
+  unsigned long long pad;
+};
+
+#define MCX_RLX __ATOMIC_RELAXED
+#define MCX_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+// ---------------------------------------------------------------------------
+// find-or-insert + coverage/edge update for one k-mer occurrence
+// ---------------------------------------------------------------------------
+// Lock-free replacement of hash_table_find_or_insert_mt (hash_table.c:250-281)
+// + db_graph_update_node_mt (db_graph.c:101-105) + this occurrence's share of
+// db_graph_add_edge_mt (db_graph.c:152-166).
+//
+// Visibility argument (per-XCD L2s are not coherent for plain accesses): slot
+// state only moves empty -> key, never back.  A stale plain load can therefore
+// only claim "empty" for a slot that is taken, and then the agent-scope CAS
+// (performed at the coherence point) returns the real occupant.  Value words
+// are only touched by agent-scope atomics; the plain read of the value is a
+// hint used to skip the edge OR when the bits are already there (bits never
+// clear, so a stale hint can only cause a redundant OR).
+template <int W>
+__device__ __forceinline__ void update_value(uint64_t *val, uint64_t hint, uint32_t e)
+{
+  __hip_atomic_fetch_add(val, 256ULL, MCX_RLX, MCX_AGENT);
+  if (e & ~(uint32_t)hint & 0xffu) __hip_atomic_fetch_or(val, (uint64_t)e, MCX_RLX, MCX_AGENT);
+}
+
+template <int W, bool ONECOL>
+__device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &key, uint64_t slot,
+                                             uint64_t cur, uint64_t hint, uint32_t e, uint32_t col,
+                                             uint32_t &novel, uint32_t &full)
+{
+  const uint64_t want = key.w[0] | kFlag;
+  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : t.S;
+  uint32_t probes = 0;
+  bool fresh = true;  // `cur`/`hint` were preloaded for this slot
+  for (;;) {
+    uint64_t *r = t.rec + slot * S;
+    if (!fresh) {
+      if (W == 1 && ONECOL) {
+        const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(r);
+        cur = kv.x; hint = kv.y;
+      } else {
+        cur = r[0]; hint = 0;
+      }
+    }
+    fresh = false;
+    if (cur == 0) {
+      uint64_t expected = 0;
+      const uint64_t desired = (W == 1) ? want : (want | kPending);
+      if (__hip_atomic_compare_exchange_strong(r, &expected, desired, MCX_RLX, MCX_RLX, MCX_AGENT)) {
+        if (W == 2) {
+          // publish the low word write-through, drain, then clear kPending
+          __hip_atomic_store(r + 1, key.w[W - 1], MCX_RLX, MCX_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(r, want, MCX_RLX, MCX_AGENT);
+        }
+        novel++;
+        update_value<W>(r + W + col, 0, e);
+        return;
+      }
+      cur = expected;  // somebody else took the slot: look at what is there now
+      hint = 0;
+    }
+    if ((cur & ~kPending) == want) {
+      if (W == 2) {
+        if (cur & kPending) {  // owner has not published word 1 yet: re-read at agent scope
+          cur = __hip_atomic_load(r, MCX_RLX, MCX_AGENT);
+          fresh = true; hint = 0;
+          if (++probes > t.max_probe * 64u) { full = 1; return; }
+          continue;
+        }
+        const uint64_t w1 = __hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT);
+        if (w1 == key.w[W - 1]) { update_value<W>(r + W + col, r[W + col], e); return; }
+      } else {
+        if (!ONECOL) hint = r[W + col];
+        update_value<W>(r + W + col, hint, e);
+        return;
+      }
+    }
+    if (++probes > t.max_probe) { full = 1; return; }
+    slot++;
+    if (slot == t.nslots) slot = 0;
+  }
+}
+
+__device__ __forceinline__ uint64_t bucket_slot(const TableView &t, uint32_t h)
+{
+  return (((uint64_t)h * t.nbuckets) >> 32) * kBucket;
+}
+
+// Sink of the fused kernel: insert straight into the local table.
+template <int W, bool ONECOL> struct InsertSink {
+  TableView t;
+  uint32_t col;
+};
+
+// ---------------------------------------------------------------------------
+// Stream front end
+// ---------------------------------------------------------------------------
+constexpr int kThreads = 256;
+constexpr int kPosPerLane = 16;
+constexpr int kTile = kThreads * kPosPerLane;  // k-mer start positions per tile
+constexpr int kChunks = 272;                   // 16-byte chunks staged per tile: 1 halo + 256 + 15
+constexpr int kBatch = 4;                      // probes in flight per lane
+
+struct StreamArgs {
+  const uint8_t *stream;
+  uint64_t nbytes;          // bytes of context available (outside = separator)
+  uint64_t pos_lo, pos_hi;  // k-mer start positions owned by this launch
+  uint64_t tile0, ntiles;   // tiles [tile0, ntiles) cover [pos_lo, pos_hi)
+  int k;
+  Counters *ctr;
+  unsigned char *flag;      // optional: set to 1 if any contig starts in this launch
+};
+
+// 64 code bits (32 bases) starting at region base index q
+__device__ __forceinline__ uint64_t code_win64(const uint32_t *s_code, uint32_t q)
+{
+  const uint32_t j = q >> 4, sh = (q & 15u) * 2u;
+  const uint64_t hi = ((uint64_t)s_code[j] << 32) | s_code[j + 1];
+  const uint64_t lo = s_code[j + 2];
+  return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+}
+// 64 invalid-flag bits (64 bases) starting at region base index q
+__device__ __forceinline__ uint64_t inv_win64(const uint32_t *s_inv, uint32_t q)
+{
+  const uint32_t j = q >> 5, sh = q & 31u;
+  const uint64_t hi = ((uint64_t)s_inv[j] << 32) | s_inv[j + 1];
+  const uint64_t lo = s_inv[j + 2];
+  return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+}
+
+// Stage one 16-byte chunk: 16 bases -> 32 code bits (first base on top) and
+// 16 invalid flags (first base = bit 15).
+__device__ __forceinline__ void encode_chunk(const uint8_t *stream, uint64_t nbytes, int64_t g,
+                                             uint32_t &code, uint32_t &inv)
+{
+  uint32_t w[4];
+  if (g >= 0 && (uint64_t)g + 16 <= nbytes) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(stream + g);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  } else {
+    w[0] = w[1] = w[2] = w[3] = 0;  // byte 0 is not ACGT: out-of-range == separator
+    if (g + 16 > 0 && g < (int64_t)nbytes)
+      for (int i = 0; i < 16; i++) {
+        const int64_t p = g + i;
+        if (p >= 0 && (uint64_t)p < nbytes) w[i >> 2] |= (uint32_t)stream[p] << (8 * (i & 3));
+      }
+  }
+  code = 0; inv = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t x = w[i];
+    // 2-bit codes of 4 bytes gathered with one multiply (byte 0 most significant)
+    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    code = (code << 8) | ((t * 0x40100401u) >> 24);
+    // exact per-byte "is non-zero" of (folded byte ^ letter): 0x80 where it differs
+    const uint32_t u = x & 0xDFDFDFDFu;
+#define MCX_NZ(v) ((((v) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | (v))
+    const uint32_t bad = MCX_NZ(u ^ 0x41414141u) & MCX_NZ(u ^ 0x43434343u) &
+                         MCX_NZ(u ^ 0x47474747u) & MCX_NZ(u ^ 0x54545454u) & 0x80808080u;
+#undef MCX_NZ
+    inv = (inv << 4) | ((((bad >> 7) * 0x08040201u) >> 24) & 0xFu);
+  }
+}
+
+// One k-mer occurrence produced by the front end
+template <int W> struct Occ {
+  Kmer<W> key;
+  uint32_t h, h2, e;
+};
+
+template <int W, bool ONECOL>
+__device__ __forceinline__ void flush_batch(const InsertSink<W, ONECOL> &sink, const Occ<W> (&occ)[kBatch],
+                                            const bool (&ov)[kBatch], uint32_t &novel, uint32_t &full)
+{
+  uint64_t slot[kBatch], cur[kBatch], hint[kBatch];
+  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : sink.t.S;
+#pragma unroll
+  for (int i = 0; i < kBatch; i++) {  // issue all first probes before looking at any
+    cur[i] = 0; hint[i] = 0; slot[i] = 0;
+    if (ov[i]) {
+      slot[i] = bucket_slot(sink.t, occ[i].h);
+      const uint64_t *r = sink.t.rec + slot[i] * S;
+      if (W == 1 && ONECOL) {
+        const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(r);
+        cur[i] = kv.x; hint[i] = kv.y;
+      } else {
+        cur[i] = r[0];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kBatch; i++)
+    if (ov[i]) probe_insert<W, ONECOL>(sink.t, occ[i].key, slot[i], cur[i], hint[i], occ[i].e, sink.col, novel, full);
+}
+
+// Partition sink (sharded build): tuples are appended to per-owner bins.
+template <int W> struct PartitionSink {
+  uint64_t *keys;   // [nparts][bin_cap][W]
+  uint8_t *edges;   // [nparts][bin_cap]
+  unsigned long long *counts;  // [nparts]
+  uint64_t bin_cap;
+  uint32_t nparts;
+};
+
+constexpr int kMaxParts = 64;
+
+__device__ __forceinline__ uint32_t owner_of(uint32_t h2, uint32_t nparts)
+{
+  return (uint32_t)(((uint64_t)h2 * nparts) >> 32);
+}
+
+// The shared front end.  MODE 0: insert, MODE 1: partition.
+template <int W, bool ONECOL, int MODE>
+__global__ __launch_bounds__(kThreads) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink,
+                                                     PartitionSink<W> psink)
+{
+  __shared__ uint32_t s_code[kChunks + 4];
+  __shared__ uint32_t s_inv[kChunks / 2 + 4];
+  __shared__ unsigned long long s_base[kMaxParts];
+  __shared__ uint32_t s_cnt[kMaxParts];
+
+  const int tid = threadIdx.x;
+  const int k = a.k;
+  uint32_t n_kmers = 0, n_contigs = 0, n_novel = 0, full = 0;
+
+  const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
+  const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);  // bit position of base 0 in w[0]
+
+  for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();
+    const int64_t region0 = (int64_t)(tile * kTile) - 16;
+    for (int c = tid; c < kChunks; c += kThreads) {
+      uint32_t code, inv;
+      encode_chunk(a.stream, a.nbytes, region0 + 16 * (int64_t)c, code, inv);
+      s_code[c] = code;
+      reinterpret_cast<uint16_t *>(s_inv)[c ^ 1] = (uint16_t)inv;
+    }
+    if (MODE == 1 && tid < kMaxParts) s_cnt[tid] = 0;
+    if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
+    __syncthreads();
+
+    const uint32_t pl = 16u * (uint32_t)(tid + 1);  // region index of this lane's first position
+    const uint64_t Vh = inv_win64(s_inv, pl);
+    const uint64_t Vl = (W == 2) ? inv_win64(s_inv, pl + 64) : 0;
+    const uint32_t prev_chunk_inv = (s_inv[(pl - 1) >> 5] >> (31 - ((pl - 1) & 31))) & 1u;
+
+    // positions of this lane owned by the launch: j in [j_lo, j_hi)
+    const uint64_t P0 = tile * kTile + 16ull * (uint64_t)tid;
+    const int j_lo = a.pos_lo > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_lo - P0) : 0;
+    const int j_hi = a.pos_hi > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_hi - P0) : 0;
+
+    // any valid k-mer among this lane's 16 positions?
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kPosPerLane; j++) {
+      const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
+      any |= ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
+    }
+
+    Occ<W> occ[kBatch];
+    bool ov[kBatch];
+    // (all indices into occ/ov are compile-time constants after unrolling: no scratch)
+    if (MODE == 0) {
+      if (any) {
+        Kmer<W> fw, rc;
+        if (W == 1) {
+          fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
+        } else {
+          const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
+          const int s = 128 - 2 * k;
+          fw.w[0] = hi >> s;
+          fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
+        }
+        rc = revcomp<W>(fw, k);
+        const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
+        uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
+#pragma unroll
+        for (int j = 0; j < kPosPerLane; j++) {
+          const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
+          const bool valid = ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
+          const bool next_ok = ((Th >> (63 - k)) & 1ULL) == 0;
+          const bool prev_ok = (j == 0) ? (prev_chunk_inv == 0) : (((Vh >> (64 - j)) & 1ULL) == 0);
+          const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
+          ov[j % kBatch] = valid;
+          if (valid) {
+            uint32_t o;
+            Occ<W> &x = occ[j % kBatch];
+            x.key = canonical<W>(fw, rc, o);
+            uint32_t e = 0;
+            if (next_ok) e |= 1u << (nuc_next + 4u * o);
+            if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
+            x.e = e;
+            x.h = kmer_hash<W>(x.key, 0, &x.h2);
+            n_kmers++;
+            n_contigs += prev_ok ? 0u : 1u;
+          }
+          if (j % kBatch == kBatch - 1) flush_batch<W, ONECOL>(isink, occ, ov, n_novel, full);
+          // roll to position j+1
+          prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
+          if (W == 1) {
+            fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
+            rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
+          } else {
+            fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
+            fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
+            rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
+            rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
+          }
+        }
+      }
+    } else {
+      // ---- partition mode: sweep 1 counts tuples per owner in LDS, one global
+      // atomic per owner per tile reserves space, sweep 2 recomputes and writes.
+      for (int sweep = 0; sweep < 2; sweep++) {
+        if (any) {
+          Kmer<W> fw, rc;
+          if (W == 1) {
+            fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
+          } else {
+            const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
+            const int s = 128 - 2 * k;
+            fw.w[0] = hi >> s;
+            fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
+          }
+          rc = revcomp<W>(fw, k);
+          const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
+          uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
+#pragma unroll 1
+          for (int j = 0; j < kPosPerLane; j++) {
+            const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
+            const bool valid = ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
+            const bool next_ok = ((Th >> (63 - k)) & 1ULL) == 0;
+            const bool prev_ok = (j == 0) ? (prev_chunk_inv == 0) : (((Vh >> (64 - j)) & 1ULL) == 0);
+            const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
+            if (valid) {
+              uint32_t o, h2;
+              const Kmer<W> key = canonical<W>(fw, rc, o);
+              kmer_hash<W>(key, 0, &h2);
+              const uint32_t dst = owner_of(h2, psink.nparts);
+              if (sweep == 0) {
+                atomicAdd(&s_cnt[dst], 1u);
+                n_kmers++;
+                n_contigs += prev_ok ? 0u : 1u;
+              } else {
+                uint32_t e = 0;
+                if (next_ok) e |= 1u << (nuc_next + 4u * o);
+                if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
+                const uint32_t off = atomicAdd(&s_cnt[dst], 1u);
+                const unsigned long long pos = s_base[dst] + off;
+                if (pos < psink.bin_cap) {
+                  uint64_t *kd = psink.keys + ((uint64_t)dst * psink.bin_cap + pos) * W;
+                  kd[0] = key.w[0];
+                  if (W == 2) kd[W - 1] = key.w[W - 1];
+                  psink.edges[(uint64_t)dst * psink.bin_cap + pos] = (uint8_t)e;
+                } else {
+                  full = 2;
+                }
+              }
+            }
+            prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
+            if (W == 1) {
+              fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
+              rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
+            } else {
+              fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
+              fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
+              rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
+              rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
+            }
+          }
+        }
+        if (sweep == 0) {
+          __syncthreads();
+          if (tid < (int)psink.nparts) {
+            const uint32_t c = s_cnt[tid];
+            s_base[tid] = c ? atomicAdd(&psink.counts[tid], (unsigned long long)c) : 0ULL;
+            s_cnt[tid] = 0;
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+
+  // block-level reduction of the statistics: one atomic per counter per wave
+  // (hipcc folds the per-lane atomicAdd into a wave reduction)
+  if (n_kmers) atomicAdd(&a.ctr->kmers, (unsigned long long)n_kmers);
+  if (n_contigs) atomicAdd(&a.ctr->contigs, (unsigned long long)n_contigs);
+  if (n_novel) atomicAdd(&a.ctr->novel, (unsigned long long)n_novel);
+  if (full == 1) a.ctr->full = 1;
+  if (full == 2) a.ctr->bin_over = 1;
+  if (a.flag && n_contigs) *a.flag = 1;
+}
+
+// ---------------------------------------------------------------------------
+// Tuple insert (owner side of the sharded build)
+// ---------------------------------------------------------------------------
+template <int W, bool ONECOL>
+__global__ __launch_bounds__(kThreads) void k_insert_tuples(InsertSink<W, ONECOL> sink, const uint64_t *keys,
+                                                            const uint8_t *edges, uint64_t n, Counters *ctr)
+{
+  uint32_t n_novel = 0, full = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i0 < n; i0 += stride * kBatch) {
+    Occ<W> occ[kBatch];
+    bool ov[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {
+      const uint64_t i = i0 + (uint64_t)b * stride;
+      ov[b] = i < n;
+      if (i < n) {
+        Occ<W> &x = occ[b];
+        x.key.w[0] = keys[i * W];
+        if (W == 2) x.key.w[W - 1] = keys[i * W + 1];
+        x.e = edges[i];
+        x.h = kmer_hash<W>(x.key, 0, &x.h2);
+      }
+    }
+    flush_batch<W, ONECOL>(sink, occ, ov, n_novel, full);
+  }
+  if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
+  if (full) ctr->full = 1;
+}
+
+// ---------------------------------------------------------------------------
+// Per-read statistics (good/bad reads: build_graph.c:186-188)
+// ---------------------------------------------------------------------------
+// One lane per read; a read is good iff it holds an ACGT run of >= k bases.
+// stream_off[i] is the start of read i in the separator-delimited stream and
+// stream_off[i+1]-1 its separator.
+__global__ void k_read_flags(const uint8_t *stream, const uint64_t *stream_off, uint64_t nreads, int k,
+                             unsigned char *flags)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  const uint64_t b = stream_off[i], e = stream_off[i + 1] - 1;
+  int run = 0;
+  bool ok = false;
+  for (uint64_t p = b; p < e && !ok; p++) {
+    run = base_valid(stream[p]) ? run + 1 : 0;
+    ok = run >= k;
+  }
+  flags[i] = ok ? 1 : 0;
+}
+
+__global__ void k_count_flags(const unsigned char *flags, uint64_t n, Counters *ctr)
+{
+  unsigned long long good = 0, bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (flags[i]) good++; else bad++;
+  }
+  if (good) atomicAdd(&ctr->good_reads, good);
+  if (bad) atomicAdd(&ctr->bad_reads, bad);
+}
+
+// -Q/-H path: a read is good iff it produced at least one contig byte
+__global__ void k_count_sizes(const uint64_t *sizes, uint64_t n, Counters *ctr)
+{
+  unsigned long long good = 0, bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (sizes[i]) good++; else bad++;
+  }
+  if (good) atomicAdd(&ctr->good_reads, good);
+  if (bad) atomicAdd(&ctr->bad_reads, bad);
+}
+
+// ---------------------------------------------------------------------------
+// Quality / homopolymer contig splitting (seq_reader.c:61-172), -Q / -H only
+// ---------------------------------------------------------------------------
+// One lane per read walks the read exactly as load_read does
+// (build_graph.c:154-189) and emits its contigs, '\n'-separated, into a new
+// stream that the ordinary front end then consumes.  pass 0 sizes, pass 1 writes.
+__device__ inline uint64_t qh_contig_start(const uint8_t *seq, uint64_t len, const uint8_t *qual,
+                                           uint64_t offset, uint64_t k, uint32_t qcut, uint32_t hcut)
+{
+  uint64_t pos = offset, kend;
+  while ((kend = pos + k) <= len) {
+    uint64_t i = kend;
+    while (i > pos && base_valid(seq[i - 1])) i--;
+    if (i > pos) { pos = i; continue; }
+    if (qual && qcut > 0) {
+      i = kend;
+      while (i > pos && (int)(int8_t)qual[i - 1] > (int)qcut) i--;
+      if (i > pos) { pos = i; continue; }
+    }
+    if (hcut > 0) {
+      uint64_t run = 1;
+      for (i = kend - 1; i > pos; i--) {
+        if (seq[i - 1] == seq[i]) { run++; if (run == hcut) break; }
+        else run = 1;
+      }
+      if (i > pos) { pos = i; continue; }
+    }
+    return pos;
+  }
+  return len;
+}
+
+__device__ inline uint64_t qh_contig_end(const uint8_t *seq, uint64_t len, const uint8_t *qual,
+                                         uint64_t cstart, uint64_t k, uint32_t qcut, uint32_t hcut,
+                                         uint64_t *search)
+{
+  uint64_t end = cstart + k, hp = 1;
+  if (hcut > 0) while (hp < end && seq[end - 1 - hp] == seq[end - 1]) hp++;
+  for (; end < len; end++) {
+    if (!base_valid(seq[end]) || (qual && (int)(int8_t)qual[end] < (int)qcut)) break;
+    if (hcut > 0) {
+      if (seq[end] == seq[end - 1]) { hp++; if (hp >= hcut) break; }
+      else hp = 1;
+    }
+  }
+  *search = (hcut > 0 && hp >= hcut) ? end - hcut + 1 : end;
+  return end;
+}
+
+__global__ void k_qh_contigs(const uint8_t *bases, const uint8_t *quals, const uint64_t *off, uint64_t nreads,
+                             int k, uint32_t qcut, uint32_t hcut, int pass, uint64_t *out_sizes,
+                             const uint64_t *out_off, uint8_t *out_stream)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  const uint8_t *seq = bases + off[r];
+  const uint8_t *qual = (quals && qcut > 0) ? quals + off[r] : nullptr;
+  const uint64_t len = off[r + 1] - off[r];
+  uint64_t cs, ce, search = 0, w = pass ? out_off[r] : 0;
+  while ((cs = qh_contig_start(seq, len, qual, search, (uint64_t)k, qcut, hcut)) < len) {
+    ce = qh_contig_end(seq, len, qual, cs, (uint64_t)k, qcut, hcut, &search);
+    if (pass) {
+      for (uint64_t i = cs; i < ce; i++) out_stream[w + (i - cs)] = seq[i];
+      out_stream[w + (ce - cs)] = '\n';
+    }
+    w += ce - cs + 1;
+  }
+  if (!pass) out_sizes[r] = w;
+}
+
+// ---------------------------------------------------------------------------
+// Export: compact occupied slots
+// ---------------------------------------------------------------------------
+// Pass over the table; every occupied slot appends (key words, slot index).
+template <int W>
+__global__ __launch_bounds__(kThreads) void k_compact(TableView t, uint64_t *key0, uint64_t *key1, uint64_t *slot_out,
+                                                      unsigned long long *cursor, uint64_t cap_out)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+  for (uint64_t s = (uint64_t)blockIdx.x * kThreads + threadIdx.x; s < t.nslots; s += stride) {
+    const uint64_t w0 = t.rec[s * t.S];
+    if (w0 & kFlag) {
+      const unsigned long long pos = atomicAdd(cursor, 1ULL);
+      if (pos < cap_out) {
+        key0[pos] = w0 & kKeyMask;  // hash_table_fetch masks the top two bits (hash_table.h:41-46)
+        if (W == 2) key1[pos] = t.rec[s * t.S + 1];
+        slot_out[pos] = s;
+      }
+    }
+  }
+}
+
+__global__ void k_gather_u64(const uint64_t *src, const uint64_t *idx, uint64_t *dst, uint64_t n)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_iota(uint64_t *dst, uint64_t n)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = i;
+}
+
+// Final gather in sorted order: record i comes from compact index perm[i].
+// Writes .ctx body records (W*8 key bytes, ncols u32 covg, ncols u8 edges;
+// graph_writer.c:116-127) for records [first, first+count).
+template <int W>
+__global__ void k_emit_records(TableView t, const uint64_t *slot_of, const uint64_t *perm, uint64_t first,
+                               uint64_t count, uint32_t ncols, uint8_t *out)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t s = slot_of[perm ? perm[first + i] : first + i];
+  const uint64_t *r = t.rec + s * t.S;
+  const uint32_t recsz = 8u * W + 5u * ncols;
+  uint8_t *o = out + i * recsz;
+  uint64_t kw[2];
+  kw[0] = r[0] & kKeyMask;
+  if (W == 2) kw[1] = r[1];
+  for (int w = 0; w < W; w++)
+    for (int b = 0; b < 8; b++) o[w * 8 + b] = (uint8_t)(kw[w] >> (8 * b));
+  for (uint32_t c = 0; c < ncols; c++) {
+    const uint64_t v = r[W + c];
+    const uint64_t cv = v >> 8;
+    const uint32_t covg = cv > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)cv;  // COVG_MAX saturation
+    for (int b = 0; b < 4; b++) o[8 * W + 4 * c + b] = (uint8_t)(covg >> (8 * b));
+    o[8 * W + 4 * ncols + c] = (uint8_t)(v & 0xff);
+  }
+}
+
+}  // namespace mcx

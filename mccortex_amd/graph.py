@@ -1,0 +1,218 @@
+"""ctypes mirror of include/mcx_gpu.h (one Python method per C entry point)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+MCX_OK, MCX_ERR_ARG, MCX_ERR_NODEVICE, MCX_ERR_NOMEM, MCX_ERR_FULL, MCX_ERR_HIP, MCX_ERR_SINK = 0, -1, -2, -3, -4, -5, -6
+
+_LIB = None
+
+SYMBOLS = [
+    "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_graph_create", "mcx_graph_destroy",
+    "mcx_graph_reset", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
+    "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
+    "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
+    "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash",
+]
+
+
+class McxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mcx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class LoadStats(C.Structure):
+    """mcx_load_stats (subset of the reference's SeqLoadingStats)."""
+    _fields_ = [(n, C.c_uint64) for n in (
+        "num_se_reads", "num_good_reads", "num_bad_reads", "total_bases_read",
+        "total_bases_loaded", "contigs_parsed", "num_kmers_loaded", "num_kmers_novel")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def lib():
+    """Load libmcxgpu.so; raises if the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build())" % path)
+    L = C.CDLL(path)
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    L.mcx_last_error.restype = C.c_char_p
+    L.mcx_version.restype = C.c_char_p
+    L.mcx_device_count.restype = C.c_int
+    L.mcx_graph_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint64, C.c_int]
+    L.mcx_graph_destroy.argtypes = [vp]
+    L.mcx_graph_destroy.restype = None
+    L.mcx_graph_reset.argtypes = [vp]
+    L.mcx_graph_capacity.argtypes = [vp, u64p, u64p]
+    L.mcx_graph_add_reads.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint64, C.c_uint8, C.c_uint8,
+                                      C.POINTER(LoadStats)]
+    L.mcx_graph_add_stream_dev.argtypes = [vp, C.c_int, vp, C.c_uint64]
+    L.mcx_graph_partition_stream_dev.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp, vp, vp]
+    L.mcx_graph_insert_tuples_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
+    L.mcx_key_owner.restype = C.c_uint32
+    L.mcx_key_owner.argtypes = [u64p, C.c_int, C.c_int]
+    L.mcx_graph_sync.argtypes = [vp]
+    L.mcx_graph_nkmers.argtypes = [vp, u64p]
+    L.mcx_graph_device_stats.argtypes = [vp, C.POINTER(LoadStats)]
+    L.mcx_graph_stream.restype = vp
+    L.mcx_graph_stream.argtypes = [vp]
+    L.mcx_graph_export.argtypes = [vp, C.c_int, SINK_FN, vp]
+    L.mcx_kmer_from_str.restype = None
+    L.mcx_kmer_from_str.argtypes = [C.c_char_p, C.c_int, u64p]
+    L.mcx_kmer_canonical.restype = None
+    L.mcx_kmer_canonical.argtypes = [u64p, C.c_int, u64p, C.POINTER(C.c_int)]
+    L.mcx_kmer_hash.restype = C.c_uint32
+    L.mcx_kmer_hash.argtypes = [u64p, C.c_int, C.c_uint32]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != MCX_OK:
+        raise McxError(rc, lib().mcx_last_error().decode())
+
+
+def device_count():
+    return lib().mcx_device_count()
+
+
+def _words(k):
+    return (2 * k + 63) // 64
+
+
+def kmer_from_str(s, k):
+    out = (C.c_uint64 * 2)()
+    lib().mcx_kmer_from_str(s.encode() if isinstance(s, str) else s, k, out)
+    return [int(out[i]) for i in range(_words(k))]
+
+
+def kmer_canonical(words, k):
+    a = (C.c_uint64 * 2)(*words)
+    out = (C.c_uint64 * 2)()
+    o = C.c_int()
+    lib().mcx_kmer_canonical(a, k, out, C.byref(o))
+    return [int(out[i]) for i in range(_words(k))], int(o.value)
+
+
+def kmer_hash(words, k, initval=0):
+    a = (C.c_uint64 * 2)(*words)
+    return int(lib().mcx_kmer_hash(a, k, initval))
+
+
+def key_owner(words, k, nparts):
+    a = (C.c_uint64 * 2)(*words)
+    return int(lib().mcx_key_owner(a, k, nparts))
+
+
+def stream_from_reads(reads):
+    """Host helper: reads -> the separator-delimited byte stream the device entry takes."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    return np.frombuffer(b"".join(b + b"\n" for b in bs), dtype=np.uint8).copy()
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    if hasattr(x, "data_ptr"):  # torch tensor (device or host)
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+class Graph:
+    """One coloured de Bruijn graph resident in the HBM of one GPU."""
+
+    def __init__(self, kmer_size, ncols=1, capacity=1 << 20, device=0):
+        self.L = lib()
+        self.k, self.ncols, self.W = kmer_size, ncols, _words(kmer_size)
+        h = C.c_void_p()
+        _check(self.L.mcx_graph_create(C.byref(h), kmer_size, ncols, capacity, device))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mcx_graph_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(self.L.mcx_graph_reset(self.h))
+
+    def capacity(self):
+        s, b = C.c_uint64(), C.c_uint64()
+        _check(self.L.mcx_graph_capacity(self.h, C.byref(s), C.byref(b)))
+        return int(s.value), int(b.value)
+
+    def add_reads(self, colour, bases, offsets, quals=None, fq_cutoff=0, hp_cutoff=0, stats=None):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        st = stats if stats is not None else LoadStats()
+        _check(self.L.mcx_graph_add_reads(self.h, colour, _ptr(bases), _ptr(quals), _ptr(offsets),
+                                          len(offsets) - 1, fq_cutoff, hp_cutoff, C.byref(st)))
+        return st
+
+    def add_stream_dev(self, colour, d_stream, nbytes):
+        _check(self.L.mcx_graph_add_stream_dev(self.h, colour, _ptr(d_stream), nbytes))
+
+    def partition_stream_dev(self, d_stream, nbytes, nparts, bin_capacity, d_keys, d_edges, d_counts):
+        _check(self.L.mcx_graph_partition_stream_dev(self.h, _ptr(d_stream), nbytes, nparts, bin_capacity,
+                                                     _ptr(d_keys), _ptr(d_edges), _ptr(d_counts)))
+
+    def insert_tuples_dev(self, colour, d_keys, d_edges, n):
+        _check(self.L.mcx_graph_insert_tuples_dev(self.h, colour, _ptr(d_keys), _ptr(d_edges), n))
+
+    def sync(self):
+        _check(self.L.mcx_graph_sync(self.h))
+
+    @property
+    def nkmers(self):
+        n = C.c_uint64()
+        _check(self.L.mcx_graph_nkmers(self.h, C.byref(n)))
+        return int(n.value)
+
+    def device_stats(self):
+        st = LoadStats()
+        _check(self.L.mcx_graph_device_stats(self.h, C.byref(st)))
+        return st
+
+    @property
+    def stream(self):
+        return self.L.mcx_graph_stream(self.h)
+
+    def export(self, sorted_=True):
+        """Records in .ctx body layout as one bytes object."""
+        parts = []
+
+        def sink(_ctx, ptr, n):
+            parts.append(C.string_at(ptr, n))
+            return 0
+
+        cb = SINK_FN(sink)
+        _check(self.L.mcx_graph_export(self.h, 1 if sorted_ else 0, cb, None))
+        return b"".join(parts)
+
+    def records(self, sorted_=True):
+        """(keys[n,W] u64, covg[n,ncols] u32, edges[n,ncols] u8)."""
+        body = self.export(sorted_)
+        rs = 8 * self.W + 5 * self.ncols
+        rec = np.frombuffer(body, dtype=np.uint8).reshape(-1, rs)
+        keys = rec[:, :8 * self.W].copy().view(np.uint64).reshape(-1, self.W)
+        cov = rec[:, 8 * self.W:8 * self.W + 4 * self.ncols].copy().view(np.uint32).reshape(-1, self.ncols)
+        edg = rec[:, 8 * self.W + 4 * self.ncols:].copy()
+        return keys, cov, edg

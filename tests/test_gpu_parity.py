@@ -1,0 +1,184 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(orc, k, ncols, jobs, cap=1 << 20, **kw):
+    """jobs: list of (colour, bases, offs[, quals]) 'files' in order."""
+    og = orc.Graph(k, ncols, cap)
+    stats = []
+    for job in jobs:
+        col, bases, offs = job[:3]
+        quals = job[3] if len(job) > 3 else None
+        st = og.add_reads(col, bases, offs, quals=quals, **kw)
+        og.update_stats(col, st)
+        stats.append(st)
+    return og, stats
+
+
+def _gpu(mcx, k, ncols, jobs, cap=1 << 20, **kw):
+    g = mcx.Graph(k, ncols, cap)
+    hdr = mcx.CtxHeader(k, ncols)
+    stats = []
+    prev = g.device_stats()
+    for job in jobs:
+        col, bases, offs = job[:3]
+        quals = job[3] if len(job) > 3 else None
+        st = g.add_reads(col, bases, offs, quals=quals, **kw)
+        cur = g.device_stats()
+        for f in ("num_good_reads", "num_bad_reads", "total_bases_loaded", "contigs_parsed",
+                  "num_kmers_loaded", "num_kmers_novel"):
+            setattr(st, f, getattr(cur, f) - getattr(prev, f))
+        prev = cur
+        hdr.update_stats(col, st.total_bases_loaded, st.contigs_parsed)
+        stats.append(st)
+    return g, hdr, stats
+
+
+def _compare(mcx, orc, k, ncols, jobs, cap=1 << 20, names=None, **kw):
+    og, ost = _oracle(orc, k, ncols, jobs, cap, **kw)
+    g, hdr, gst = _gpu(mcx, k, ncols, jobs, cap, **kw)
+    if names:
+        for c, n in enumerate(names):
+            og.set_sample(c, n)
+            hdr.names[c] = n
+    for a, b in zip(gst, ost):
+        assert a.as_dict() == b.as_dict()
+    assert g.nkmers == og.nkmers
+    want = og.ctx_bytes(True)
+    got = mcx.ctx_header_bytes(hdr) + g.export(True)
+    assert len(got) == len(want)
+    assert got == want
+    # unsorted export holds the same record set
+    body = g.export(False)
+    rs = 8 * g.W + 5 * ncols
+    a = np.frombuffer(body, np.uint8).reshape(-1, rs)
+    b = np.frombuffer(want[og.header_size():], np.uint8).reshape(-1, rs)
+    assert sorted(map(bytes, a)) == sorted(map(bytes, b))
+    g.close()
+    return og
+
+
+@pytest.mark.parametrize("k", [31, 21, 3, 63, 39, 33])
+def test_random_reads_match_oracle(mcx, orc, k):
+    bases, offs = synth.reads(3000, 100, genome_len=20000, seed=k, n_frac=0.05, lower_frac=0.1)
+    _compare(mcx, orc, k, 1, [(0, bases, offs)])
+
+
+def test_ragged_and_empty_reads(mcx, orc):
+    bases, offs = synth.reads(5000, 40, genome_len=5000, seed=3, n_frac=0.2, var_len=True)
+    _compare(mcx, orc, 31, 1, [(0, bases, offs)])
+    _compare(mcx, orc, 63, 1, [(0, bases, offs)])
+
+
+def test_no_reads_and_all_short(mcx, orc):
+    e = np.zeros(0, np.uint8)
+    _compare(mcx, orc, 31, 1, [(0, e, np.zeros(1, np.uint64))])
+    bases, offs = orc.pack_reads(["ACGT", "", "ACGTACGTAC", "NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN"])
+    _compare(mcx, orc, 31, 1, [(0, bases, offs)])
+
+
+def test_reference_build_kat(mcx, orc):
+    # the reads the reference's own unit test loads (src/tests/build_graph_tests.c:41-121),
+    # minus the pairs its PCR-duplicate filter drops; expected coverages 3/3 (:119-120)
+    reads = ["CTACGATGTATGCTTAGCTGTTCCG", "TAGAACGTTCCCTACACGTCCTATG", "CTACGATGTATGCTTAGCTAATGAT",
+             "TAGAACGTTCCCTACACGTTGTTTG", "ACGTGTAGGGAACGTTCTACTTCTACCGGAGGAT",
+             "AGCTAAGCATACATCGTAGTACAATGCACCCTCC"]
+    bases, offs = orc.pack_reads(reads)
+    og = _compare(mcx, orc, 19, 1, [(0, bases, offs)], cap=1024)
+    assert og.lookup("CTACGATGTATGCTTAGCT")[0][0] == 3
+    assert og.lookup("TAGAACGTTCCCTACACGT")[0][0] == 3
+
+
+def test_multi_colour_and_files(mcx, orc):
+    g = synth.genome(30000, 5)
+    jobs = []
+    for c in range(3):
+        for f in range(2):
+            b, o = synth.reads(1500, 120, seed=10 * c + f, g=g, lower_frac=0.05)
+            jobs.append((c, b, o))
+    _compare(mcx, orc, 31, 3, jobs, names=["alice", "bob", "carol"])
+    _compare(mcx, orc, 51, 3, jobs, names=["alice", "bob", "carol"])
+
+
+def test_hot_keys_contention(mcx, orc):
+    # homopolymer and short-period reads: thousands of occurrences of a handful of keys
+    reads = ["A" * 150] * 3000 + ["ACACACACACACACACACACACACACACACACACACACACACACACACAC" * 3] * 2000 + ["T" * 200] * 500
+    bases, offs = orc.pack_reads(reads)
+    _compare(mcx, orc, 31, 1, [(0, bases, offs)])
+    _compare(mcx, orc, 63, 1, [(0, bases, offs)])
+
+
+def test_quality_and_homopolymer_cutoffs(mcx, orc):
+    bases, offs = synth.reads(2000, 120, genome_len=20000, seed=11, n_frac=0.05)
+    rng = np.random.default_rng(5)
+    quals = rng.integers(33, 74, len(bases)).astype(np.uint8)
+    # plant homopolymer runs
+    for p in rng.integers(0, len(bases) - 20, 300):
+        bases[p:p + int(rng.integers(3, 15))] = ord("ACGT"[int(rng.integers(0, 4))])
+    for fq, hp in [(33 + 10, 0), (0, 5), (33 + 5, 7), (33 + 20, 3)]:
+        _compare(mcx, orc, 21, 1, [(0, bases, offs, quals)], fq_cutoff=fq, hp_cutoff=hp)
+        _compare(mcx, orc, 41, 1, [(0, bases, offs, quals)], fq_cutoff=fq, hp_cutoff=hp)
+
+
+def test_table_full_is_reported(mcx):
+    bases, offs = synth.reads(4000, 100, genome_len=200000, seed=2)
+    g = mcx.Graph(31, 1, 1024)
+    g.add_reads(0, bases, offs)
+    with pytest.raises(mcx.McxError) as ei:
+        g.sync()
+    assert ei.value.code == mcx.MCX_ERR_FULL and "Hash table is full" in str(ei.value)
+    g.close()
+
+
+def test_device_stream_and_sharded_path(mcx, orc):
+    import torch
+    k = 31
+    for k in (31, 55):
+        bases, offs = synth.reads(20000, 150, genome_len=100000, seed=k)
+        og, _ = _oracle(orc, k, 1, [(0, bases, offs)])
+        want = og.ctx_bytes(True)[og.header_size():]
+        stream = torch.from_numpy(synth.to_stream(bases, offs)).cuda()
+        # (a) fused device-stream entry
+        g = mcx.Graph(k, 1, 1 << 21)
+        g.add_stream_dev(0, stream, stream.numel())
+        g.sync()
+        assert g.export(True) == want
+        # (b) partition into 4 owner bins, then insert each bin into its own shard graph
+        W = g.W
+        nparts, cap = 4, 1 << 20
+        keys = torch.zeros((nparts, cap, W), dtype=torch.int64, device="cuda")
+        edges = torch.zeros((nparts, cap), dtype=torch.uint8, device="cuda")
+        counts = torch.zeros(nparts, dtype=torch.int64, device="cuda")
+        g.partition_stream_dev(stream, stream.numel(), nparts, cap, keys, edges, counts)
+        g.sync()
+        torch.cuda.synchronize()
+        cnt = counts.cpu().numpy()
+        assert cnt.sum() == g.device_stats().num_kmers_loaded // 2  # counted by both launches
+        bodies = []
+        for p in range(nparts):
+            sg = mcx.Graph(k, 1, 1 << 20)
+            sg.insert_tuples_dev(0, keys[p], edges[p], int(cnt[p]))
+            sg.sync()
+            kk, cc, ee = sg.records(True)
+            for row in kk[:50]:
+                assert mcx.key_owner([int(x) for x in row], k, nparts) == p
+            bodies.append(sg.export(True))
+            sg.close()
+        rs = 8 * W + 5
+        allrec = np.concatenate([np.frombuffer(b, np.uint8).reshape(-1, rs) for b in bodies])
+        wantrec = np.frombuffer(want, np.uint8).reshape(-1, rs)
+        assert sorted(map(bytes, allrec)) == sorted(map(bytes, wantrec))
+        g.close()
+
+
+def test_config1_100k_x_100bp(mcx, orc):
+    # BASELINE.json configs[0]: 100k x 100bp, k=31, 1 colour, bit-identical sorted .ctx
+    g = synth.genome(1_000_000, 42)
+    bases, offs = synth.reads(100_000, 100, seed=42, g=g)
+    og = _compare(mcx, orc, 31, 1, [(0, bases, offs)], cap=4 << 20, names=["sample0"])
+    assert og.nkmers > 1_000_000
