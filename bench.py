@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s inserted by the `build` hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): k=31, 1 colour, synthetic 150 bp reads drawn from a
+200 Mbp random genome (50% reverse strand, 0.1% substitutions, 1% of reads with an N), table of
+2^30 slots.  One step = one batch of 5,000,000 reads (600M k-mer occurrences) that is already
+resident in HBM as a '\\n'-separated byte stream; the default 10 steps are the 50M x 150bp set.
+
+N>1 (one process per GPU, torchrun): weak scaling -- every rank k-merises its own 5M-read batch
+per step (genome scaled to N x 200 Mbp so every shard sees the same load), bins the tuples by
+owner hash, exchanges them with one RCCL all-to-all and inserts what it owns.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K = 31
+READ_LEN = 150
+BATCH_READS = 5_000_000
+GENOME_PER_GPU = 200_000_000
+TABLE_SLOTS = 1 << 30
+ALG_BYTES_PER_KMER = 21.25   # 1.25 input + 8 key + 8 covg RMW + ~4 edge RMW
+ALG_BYTES_PER_NOVEL = 8.0    # key write when the node is new
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def make_genome(n, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    return lut[torch.randint(0, 4, (n,), generator=g, device=device)]
+
+
+def make_batch(genome, nreads, seed, device):
+    """-> uint8 [nreads*(READ_LEN+1)] stream, every read followed by '\\n'."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty((nreads, READ_LEN + 1), dtype=torch.uint8, device=device)
+    ar = torch.arange(READ_LEN, device=device)
+    sub = 500_000
+    for lo in range(0, nreads, sub):
+        n = min(sub, nreads - lo)
+        starts = torch.randint(0, genome.numel() - READ_LEN, (n, 1), generator=g, device=device)
+        r = genome[starts + ar]
+        err = torch.rand((n, READ_LEN), generator=g, device=device) < 0.001
+        r = torch.where(err, acgt[torch.randint(0, 4, (n, READ_LEN), generator=g, device=device)], r)
+        rc = torch.rand((n, 1), generator=g, device=device) < 0.5
+        r = torch.where(rc, comp[r.flip(1).long()], r)
+        hasn = torch.rand((n,), generator=g, device=device) < 0.01
+        npos = torch.randint(0, READ_LEN, (n,), generator=g, device=device)
+        rows = torch.nonzero(hasn).squeeze(1)
+        r[rows, npos[rows]] = ord("N")
+        out[lo:lo + n, :READ_LEN] = r
+    out[:, READ_LEN] = ord("\n")
+    return out.reshape(-1)
+
+
+def cpu_baseline(stream_dev, rank):
+    """Time the CPU oracle (port of the reference algorithm, pthreads) on a bounded sample."""
+    from oracle import orc
+    ncores = os.cpu_count() or 1
+    nthreads = 1
+
+    def run(nreads):
+        s = stream_dev[:nreads * (READ_LEN + 1)].reshape(nreads, READ_LEN + 1)[:, :READ_LEN].contiguous().cpu().numpy()
+        bases = s.reshape(-1)
+        offs = (np.arange(nreads + 1, dtype=np.uint64) * READ_LEN)
+        g = orc.Graph(K, 1, max(1 << 20, nreads * 130))
+        t0 = time.perf_counter()
+        st = g.add_reads(0, bases, offs, nthreads=nthreads)
+        dt = time.perf_counter() - t0
+        return st.num_kmers_loaded, dt
+
+    # the reference's bucket-locked table scales badly (its own benchmark shows negative
+    # scaling): scan thread counts on a small sample and time the best one
+    n0 = 50_000
+    scan = {}
+    for nt in [t for t in (1, 4, 8, 16, 32, 64, 128) if t <= ncores]:
+        nthreads = nt
+        km, dt = run(n0)
+        scan[nt] = km / dt
+    nthreads = max(scan, key=scan.get)
+    n1 = int(min(BATCH_READS, max(n0, 12.0 * scan[nthreads] / 120)))
+    km, dt = run(n1)
+    return {"value": km / dt, "unit": "k-mers/s", "cores": nthreads, "kind": "port",
+            "sample": "first %d reads of step 0 (%d k-mer occurrences, %.1f s), oracle/mcx_oracle.c "
+                      "bucketed-table build, best of thread counts %s" % (n1, km, dt, sorted(scan)),
+            "host_cpus": ncores, "thread_scan_kmers_per_s": {str(k): round(v) for k, v in scan.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-reads", type=int, default=BATCH_READS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    import mccortex_amd as mcx
+
+    B = args.batch_reads
+    nsteps, nwarm = args.steps, args.warmup
+    genome = make_genome(GENOME_PER_GPU * world, device, seed=42)
+    batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device) for i in range(nsteps + nwarm)]
+    del genome
+    torch.cuda.synchronize()
+
+    graph = mcx.Graph(K, 1, TABLE_SLOTS, device=local_rank)
+    ext = torch.cuda.ExternalStream(graph.stream, device=device)
+    W = graph.W
+
+    if world > 1:
+        bin_cap = int(B * (READ_LEN - K + 1) / world * 1.10) + 65536
+        send_keys = torch.empty((world, bin_cap, W), dtype=torch.int64, device=device)
+        send_edges = torch.empty((world, bin_cap), dtype=torch.uint8, device=device)
+        recv_keys = torch.empty((world * bin_cap, W), dtype=torch.int64, device=device)
+        recv_edges = torch.empty((world * bin_cap,), dtype=torch.uint8, device=device)
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+
+    def step(i):
+        s = batches[i]
+        if world == 1:
+            graph.add_stream_dev(0, s, s.numel())
+            return
+        counts.zero_()
+        torch.cuda.current_stream().synchronize()
+        graph.partition_stream_dev(s, s.numel(), world, bin_cap, send_keys, send_edges, counts)
+        graph.sync()
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts)
+        sc, rc_ = counts.tolist(), recv_counts.tolist()
+        ro = np.concatenate([[0], np.cumsum(rc_)]).astype(np.int64)
+        dist.all_to_all([recv_keys[ro[p]:ro[p + 1]] for p in range(world)],
+                        [send_keys[p, :sc[p]] for p in range(world)])
+        dist.all_to_all([recv_edges[ro[p]:ro[p + 1]] for p in range(world)],
+                        [send_edges[p, :sc[p]] for p in range(world)])
+        torch.cuda.current_stream().synchronize()
+        graph.insert_tuples_dev(0, recv_keys, recv_edges, int(ro[-1]))
+
+    def fence():
+        torch.cuda.synchronize()
+        graph.sync()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(nwarm):
+        step(nsteps + i)
+    fence()
+    graph.reset()
+    fence()
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(ext)
+    for i in range(nsteps):
+        step(i)
+        ev[i + 1].record(ext)
+    fence()
+    dt = time.perf_counter() - t0
+
+    st = graph.device_stats()
+    kmers_local = st.num_kmers_loaded
+    tot = torch.tensor([float(kmers_local), dt], dtype=torch.float64, device=device)
+    if world > 1:
+        k_all = tot[:1].clone()
+        dist.all_reduce(k_all, op=dist.ReduceOp.SUM)
+        t_all = tot[1:].clone()
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        kmers_total, dt = float(k_all.item()), float(t_all.item())
+    else:
+        kmers_total = float(kmers_local)
+
+    if rank == 0:
+        value = kmers_total / dt
+        out = {
+            "metric": "k-mers/s inserted (build), k=31, 50M x 150bp synthetic reads",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": nsteps, "warmup": nwarm,
+            "ms_per_step": 1e3 * dt / nsteps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
+                                   "table 2^30 slots per GPU" % (B, READ_LEN, GENOME_PER_GPU * world // 1_000_000),
+                       "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
+                       "table_slots_per_gpu": TABLE_SLOTS, "sharding": "none" if world == 1 else "hash-prefix x%d, all-to-all" % world,
+                       "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel)},
+        }
+        if world == 1:
+            kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(nsteps)]
+            avg_ms = sum(kern_ms) / len(kern_ms)
+            alg_bytes = (ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel) / nsteps
+            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_stream<1,true,0>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "avg_kernel_ms": avg_ms, "alg_bytes_per_launch": alg_bytes}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(batches[0], rank)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,7 +146,13 @@ constexpr int kThreads = 256;
 constexpr int kPosPerLane = 16;
 constexpr int kTile = kThreads * kPosPerLane;  // k-mer start positions per tile
 constexpr int kChunks = 272;                   // 16-byte chunks staged per tile: 1 halo + 256 + 15
-constexpr int kBatch = 4;                      // probes in flight per lane
+#ifndef MCX_BATCH
+#define MCX_BATCH 4
+#endif
+#ifndef MCX_MIN_WAVES
+#define MCX_MIN_WAVES 1
+#endif
+constexpr int kBatch = MCX_BATCH;              // probes in flight per lane (must divide 16)
 
 struct StreamArgs {
   const uint8_t *stream;
@@ -258,7 +264,7 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t h2, uint32_t nparts)
 
 // The shared front end.  MODE 0: insert, MODE 1: partition.
 template <int W, bool ONECOL, int MODE>
-__global__ __launch_bounds__(kThreads) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink,
+__global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink,
                                                      PartitionSink<W> psink)
 {
   __shared__ uint32_t s_code[kChunks + 4];

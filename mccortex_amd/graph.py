@@ -43,7 +43,14 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  Importing torch first makes the loader bind this library to the runtime
+    # torch uses, so torch tensors' device pointers are valid in our kernels.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = os.environ.get("MCX_LIB", _build.LIB)  # MCX_LIB: tuning variants built by tools/
     if not os.path.exists(path):
         raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build())" % path)
     L = C.CDLL(path)
