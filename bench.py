@@ -39,7 +39,7 @@ def make_genome(n, device, seed):
     return lut[torch.randint(0, 4, (n,), generator=g, device=device)]
 
 
-def make_batch(genome, nreads, seed, device):
+def make_batch(genome, nreads, seed, device, err_rate=0.001):
     """-> uint8 [nreads*(READ_LEN+1)] stream, every read followed by '\\n'."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -54,7 +54,7 @@ def make_batch(genome, nreads, seed, device):
         n = min(sub, nreads - lo)
         starts = torch.randint(0, genome.numel() - READ_LEN, (n, 1), generator=g, device=device)
         r = genome[starts + ar]
-        err = torch.rand((n, READ_LEN), generator=g, device=device) < 0.001
+        err = torch.rand((n, READ_LEN), generator=g, device=device) < err_rate
         r = torch.where(err, acgt[torch.randint(0, 4, (n, READ_LEN), generator=g, device=device)], r)
         rc = torch.rand((n, 1), generator=g, device=device) < 0.5
         r = torch.where(rc, comp[r.flip(1).long()], r)
@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-reads", type=int, default=BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table-slots", type=int, default=TABLE_SLOTS, help="experiments only")
+    ap.add_argument("--genome", type=int, default=GENOME_PER_GPU, help="experiments only")
+    ap.add_argument("--err", type=float, default=0.001, help="experiments only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,12 +134,13 @@ def main():
 
     B = args.batch_reads
     nsteps, nwarm = args.steps, args.warmup
-    genome = make_genome(GENOME_PER_GPU * world, device, seed=42)
-    batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device) for i in range(nsteps + nwarm)]
+    genome = make_genome(args.genome * world, device, seed=42)
+    batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device, err_rate=args.err)
+               for i in range(nsteps + nwarm)]
     del genome
     torch.cuda.synchronize()
 
-    graph = mcx.Graph(K, 1, TABLE_SLOTS, device=local_rank)
+    graph = mcx.Graph(K, 1, args.table_slots, device=local_rank)
     ext = torch.cuda.ExternalStream(graph.stream, device=device)
     W = graph.W
 
@@ -210,9 +214,9 @@ def main():
             "ms_per_step": 1e3 * dt / nsteps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
-                                   "table 2^30 slots per GPU" % (B, READ_LEN, GENOME_PER_GPU * world // 1_000_000),
+                                   "table %d slots per GPU" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots),
                        "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
-                       "table_slots_per_gpu": TABLE_SLOTS, "sharding": "none" if world == 1 else "hash-prefix x%d, all-to-all" % world,
+                       "table_slots_per_gpu": args.table_slots, "sharding": "none" if world == 1 else "hash-prefix x%d, all-to-all" % world,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel)},
         }
         if world == 1:
