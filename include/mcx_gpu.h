@@ -52,6 +52,9 @@ typedef struct mcx_graph mcx_graph;
 const char *mcx_last_error(void);
 const char *mcx_version(void);
 int mcx_device_count(void);
+/* Free / total HBM of a device in bytes (the build command checks -m/-n against
+ * HBM where the reference checks host RAM, src/graph/cmd_mem.c:133-151). */
+int mcx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* Replaces db_graph_alloc (src/graph/db_graph.c:23) + hash_table_alloc
  * (src/graph/hash_table.c:16-52) for the build path.
@@ -82,8 +85,11 @@ int mcx_graph_capacity(const mcx_graph *g, uint64_t *slots, uint64_t *bytes);
  *   read_offsets   nreads+1 offsets into bases/quals
  *   fq_cutoff_abs  prefs.fq_cutoff + FASTQ offset, 0 = off (build_graph.c:203-206)
  *   hp_cutoff      homopolymer cutoff, 0 = off
- *   stats_accum    optional; read-level counters are added immediately, the
- *                  contig/k-mer counters after the batch has been processed
+ *   stats_accum    optional; num_se_reads and total_bases_read are added here.
+ *                  Contig / k-mer / good-read counters live on the device: read
+ *                  them with mcx_graph_device_stats() (the host takes the delta
+ *                  around each input file, as graph_info_update_stats needs
+ *                  per-file totals, src/tools/build_graph.c:294-298).
  * The call returns once the batch is staged; use mcx_graph_sync() to drain. */
 int mcx_graph_add_reads(mcx_graph *g, int colour,
                         const uint8_t *bases, const uint8_t *quals,

@@ -79,6 +79,19 @@ extern "C" int mcx_device_count(void)
   return n;
 }
 
+extern "C" int mcx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(MCX_ERR_NODEVICE, "no HIP device %d", device);
+  HIP_TRY(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return MCX_OK;
+}
+
 static int check_k(int k)
 {
   if (k < 3 || k > 63 || !(k & 1)) return fail(MCX_ERR_ARG, "kmer size must be odd and 3..63 (got %d)", k);

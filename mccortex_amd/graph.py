@@ -11,7 +11,7 @@ MCX_OK, MCX_ERR_ARG, MCX_ERR_NODEVICE, MCX_ERR_NOMEM, MCX_ERR_FULL, MCX_ERR_HIP,
 _LIB = None
 
 SYMBOLS = [
-    "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_graph_create", "mcx_graph_destroy",
+    "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",

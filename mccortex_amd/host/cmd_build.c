@@ -1,0 +1,372 @@
+/* cmd_build.c -- `mccortex<K> build`: the reference's command surface
+ * (src/commands/ctx_build.c:13-77 options, :133-242 parsing rules, :245-436 flow) driving the
+ * MI355X backend through include/mcx_gpu.h instead of build_graph() / graph_writer. */
+#define _GNU_SOURCE
+#include "host.h"
+
+#include <ctype.h>
+#include <errno.h>
+#include <getopt.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../../include/mcx_gpu.h"
+
+#define DEFAULT_NTHREADS 2
+#define DEFAULT_MEM (1UL << 29)
+#define IDEAL_OCCUPANCY 0.75f
+#define WARN_OCCUPANCY 0.9f
+#define BATCH_BASES (48u << 20)
+
+static const char build_usage[] =
+"usage: " CMD_NAME " build [options] <out.ctx>\n"
+"\n"
+"  Build a cortex graph.  \n"
+"\n"
+"  -h, --help               This help message\n"
+"  -q, --quiet              Silence status output normally printed to STDERR\n"
+"  -f, --force              Overwrite output files\n"
+"  -m, --memory <mem>       Memory to use\n"
+"  -n, --nkmers <kmers>     Number of hash table entries (e.g. 1G ~ 1 billion)\n"
+"  -t, --threads <T>        Number of threads to use [default: " MCX_STR(DEFAULT_NTHREADS) "]\n"
+"  -k, --kmer <kmer>        Kmer size must be odd (" MCX_STR(MAX_KMER_SIZE) " >= k >= " MCX_STR(MIN_KMER_SIZE) ")\n"
+"  -s, --sample <name>      Sample name (required before any seq args)\n"
+"  -1, --seq <in.fa>        Load sequence data\n"
+"  -2, --seq2 <in1:in2>     Load paired end sequence data\n"
+"  -i, --seqi <in.bam>      Load paired end sequence from a single file\n"
+"  -Q, --fq-cutoff <Q>      Filter quality scores [default: 0 (off)]\n"
+"  -O, --fq-offset <N>      FASTQ ASCII offset    [default: 0 (auto-detect)]\n"
+"  -H, --cut-hp <bp>        Breaks reads at homopolymers >= <bp> [default: off]\n"
+"  -p, --remove-pcr         Remove (or keep) PCR duplicate reads\n"
+"  -P, --keep-pcr           Don't do PCR duplicate removal [default]\n"
+"  -M, --matepair <orient>  Mate pair orientation: FF,FR,RF,RR [default: FR]\n"
+"                           (for --keep_pcr only)\n"
+"  -g, --graph <in.ctx>     Load samples from a graph file (.ctx)\n"
+"  -I, --intersect <i.ctx>  Only load kmers that appear in i.ctx. Multiple -I\n"
+"                           graphs will be merged, not intersected. Treated as\n"
+"                           single colour graphs.\n"
+"  -S, --sort               Output a graph file ordered by kmer\n"
+"  -D, --device <N>         GPU to build on [default: 0]\n"
+"\n"
+"  Note: Argument must come before input file\n"
+"  --sample <name> is required before sequence input can be loaded.\n"
+"  Consecutive sequence options are loaded into the same colour.\n"
+"  This build runs the graph construction on an MI355X: --remove-pcr, --graph and\n"
+"  --intersect and SAM/BAM/CRAM input are not available; -m/-n size the table in HBM.\n"
+"\n";
+
+static struct option longopts[] = {
+  {"help", no_argument, NULL, 'h'},       {"memory", required_argument, NULL, 'm'},
+  {"nkmers", required_argument, NULL, 'n'}, {"threads", required_argument, NULL, 't'},
+  {"force", no_argument, NULL, 'f'},      {"kmer", required_argument, NULL, 'k'},
+  {"sample", required_argument, NULL, 's'}, {"sort", no_argument, NULL, 'S'},
+  {"seq", required_argument, NULL, '1'},  {"seq2", required_argument, NULL, '2'},
+  {"seqi", required_argument, NULL, 'i'}, {"matepair", required_argument, NULL, 'M'},
+  {"fq-cutoff", required_argument, NULL, 'Q'}, {"fq-offset", required_argument, NULL, 'O'},
+  {"cut-hp", required_argument, NULL, 'H'}, {"remove-pcr", no_argument, NULL, 'p'},
+  {"keep-pcr", no_argument, NULL, 'P'},   {"graph", required_argument, NULL, 'g'},
+  {"intersect", required_argument, NULL, 'I'}, {"device", required_argument, NULL, 'D'},
+  {NULL, 0, NULL, 0}};
+
+typedef struct {
+  char *path;
+  int colour;
+  uint8_t fq_cutoff, fq_offset, hp_cutoff;
+  mcx_load_stats stats;
+  seq_fmt fmt;
+} build_task;
+
+static build_task *tasks = NULL;
+static size_t ntasks = 0, tasks_cap = 0;
+static char **sample_names = NULL;
+static size_t nsamples = 0;
+
+#define usage_die(...) print_usage(build_usage, __VA_ARGS__)
+
+static void optname(char c, char *out)
+{ /* "-k, --kmer" style, cmd_get_longopt_str (cmd.c:66-84) */
+  sprintf(out, "-%c, --Unknown", c);
+  for (int i = 0; longopts[i].name; i++)
+    if (longopts[i].val == c) sprintf(out, "-%c, --%s", c, longopts[i].name);
+}
+
+/* ctx_build.c:120-131 */
+static void check_sample_name(const char *s)
+{
+  if (strlen(s) < 1) die("Sample name is too short: '%s'", s);
+  if (!strcmp(s, "undefined")) die("Bad sample name: '%s'", s);
+  if (!strcmp(s, "noname")) die("Bad sample name: '%s'", s);
+  if (s[0] == '.') die("Sample name should start with a dot: '%s'", s);
+  if (strlen(s) > 255) die("Sample name too long: '%s'", s);
+  for (const char *p = s; *p; p++) {
+    if (isspace((unsigned char)*p)) die("Sample name should not contain whitespace: '%s'", s);
+    if (!isgraph((unsigned char)*p)) die("Bad character in sample name: '%s'", s);
+  }
+}
+
+static void add_task(const char *path, int colour, uint8_t fq_cutoff, uint8_t fq_offset, uint8_t hp)
+{ /* add_task: ctx_build.c:99-117 */
+  if (fq_offset >= 128) die("fq-offset too big: %i", (int)fq_offset);
+  if (fq_offset + fq_cutoff >= 128) die("fq-cutoff too big: %i", fq_offset + fq_cutoff);
+  if (ntasks == tasks_cap) { tasks_cap = tasks_cap ? tasks_cap * 2 : 16; tasks = realloc(tasks, tasks_cap * sizeof(*tasks)); }
+  build_task *t = &tasks[ntasks++];
+  memset(t, 0, sizeof(*t));
+  t->path = strdup(path); t->colour = colour;
+  t->fq_cutoff = fq_cutoff; t->fq_offset = fq_offset; t->hp_cutoff = hp;
+  if (strcmp(path, "-") != 0 && access(path, R_OK) != 0) die("Cannot open -1 file: %s", path);
+}
+
+static long file_size(const char *path)
+{
+  struct stat st;
+  if (!strcmp(path, "-") || stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return -1;
+  return (long)st.st_size;
+}
+
+static int write_sink(void *ctx, const void *recs, size_t n)
+{
+  return fwrite(recs, 1, n, (FILE *)ctx) == n ? 0 : 1;
+}
+
+static void mcx_check(int rc, const char *what)
+{
+  if (rc == MCX_ERR_FULL) die("Hash table is full");
+  if (rc != MCX_OK) die("%s: %s", what, mcx_last_error());
+}
+
+int ctx_build(int argc, char **argv)
+{
+  size_t nthreads = 0, kmer_size = 0, mem_to_use = DEFAULT_MEM, num_kmers = 0;
+  bool mem_set = false, nkmers_set = false, force = false, sort_kmers = false;
+  bool sample_named = false, pref_unused = false, remove_pcr = false;
+  uint8_t fq_offset = 0, fq_cutoff = 0, hp_cutoff = 0;
+  int intocolour = -1, device = 0, c;
+  char cmd[100];
+
+  /* '+': stop at the first non-option; single-dash long options accepted (cmd.c:87-102, ctx_build.c:149) */
+  optind = 1;
+  while ((c = getopt_long_only(argc, argv, "+hm:n:t:fk:s:S1:2:i:M:Q:O:H:pPg:I:D:", longopts, NULL)) != -1) {
+    optname((char)c, cmd);
+    unsigned u;
+    switch (c) {
+      case 'h': print_usage(build_usage, NULL);
+      case 't':
+        if (nthreads) usage_die("%s given twice", cmd);
+        if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int x >= 0: %s", cmd, optarg);
+        if (!u) usage_die("%s <N> must be > 0: %s", cmd, optarg);
+        nthreads = u; break;
+      case 'm':
+        if (mem_set) usage_die("-m, --memory <M> specifed more than once");
+        if (!mem_to_integer(optarg, &mem_to_use) || !mem_to_use) usage_die("Invalid memory argument: %s", optarg);
+        mem_set = true; break;
+      case 'n':
+        if (nkmers_set) usage_die("-n, --nkmers <N> specifed more than once");
+        if (!mem_to_integer(optarg, &num_kmers) || !num_kmers) usage_die("Invalid hash size: %s", optarg);
+        nkmers_set = true; break;
+      case 'f': if (force) usage_die("%s given twice", cmd); force = true; break;
+      case 'k': {
+        if (kmer_size) usage_die("%s given twice", cmd);
+        size_t k;
+        if (!parse_entire_size(optarg, &k)) usage_die("%s requires an int x >= 0: %s", cmd, optarg);
+        if (!k) usage_die("%s <N> must be > 0: %s", cmd, optarg);
+        if (k < MIN_KMER_SIZE || k > MAX_KMER_SIZE) die("Please recompile with correct kmer size (%zu)", k);
+        if (!(k & 1)) die("Invalid kmer-size (%zu): requires odd number %d <= k <= %d", k, MIN_KMER_SIZE, MAX_KMER_SIZE);
+        kmer_size = k; break;
+      }
+      case 's':
+        intocolour++;
+        check_sample_name(optarg);
+        sample_names = realloc(sample_names, (nsamples + 1) * sizeof(char *));
+        sample_names[nsamples++] = optarg;
+        sample_named = true; break;
+      case 'S': if (sort_kmers) usage_die("%s given twice", cmd); sort_kmers = true; break;
+      case '1': case '2': case 'i':
+        pref_unused = false;
+        if (!sample_named) usage_die("Please give sample name first [-s,--sample <name>]");
+        if (remove_pcr) die("--remove-pcr is not available in this build (order-dependent CPU filter, src/tools/build_graph.c:35-92)");
+        if (c == '2') { /* <in1>:<in2> (or a comma): loaded as two single-ended files (ctx_build.c:105-116) */
+          char *sep = strchr(optarg, ':');
+          if (!sep) sep = strchr(optarg, ',');
+          if (!sep || strchr(sep + 1, ':')) die("Expected -2 <in1>:<in2>");
+          *sep = '\0';
+          add_task(optarg, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+          add_task(sep + 1, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+        } else {
+          add_task(optarg, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+        }
+        break;
+      case 'M':
+        if (strcmp(optarg, "FF") && strcmp(optarg, "FR") && strcmp(optarg, "RF") && strcmp(optarg, "RR"))
+          die("-M,--matepair <orient> must be one of: FF,FR,RF,RR");
+        pref_unused = true; break;
+      case 'O': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int 0 <= x < 255: %s", cmd, optarg);
+        fq_offset = (uint8_t)u; pref_unused = true; break;
+      case 'Q': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int 0 <= x < 255: %s", cmd, optarg);
+        fq_cutoff = (uint8_t)u; pref_unused = true; break;
+      case 'H': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int 0 <= x < 255: %s", cmd, optarg);
+        hp_cutoff = (uint8_t)u; pref_unused = true; break;
+      case 'p': remove_pcr = true; pref_unused = true; break;
+      case 'P': remove_pcr = false; pref_unused = true; break;
+      case 'g': die("--graph is not available in this build (loads an existing .ctx; SURVEY.md 8f)");
+      case 'I': die("--intersect is not available in this build (SURVEY.md 8f)");
+      case 'D': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int x >= 0: %s", cmd, optarg);
+        device = (int)u; break;
+      case ':': case '?':
+        die("`" CMD_NAME " build -h` for help. Bad option: %s", argv[optind - 1]);
+      default: die("Bad option: %s", cmd);
+    }
+  }
+  if (!nthreads) nthreads = DEFAULT_NTHREADS;
+  if (optind + 1 > argc) usage_die("Expected exactly one graph file");
+  else if (optind + 1 < argc) usage_die("Expected only one graph file. What is this: '%s'", argv[optind]);
+  const char *out_path = argv[optind];
+  status("Saving graph to: %s", strcmp(out_path, "-") ? out_path : "STDOUT");
+  if (nsamples == 0) usage_die("No inputs given");
+  if (pref_unused) usage_die("Arguments not given BEFORE sequence file");
+  if (!kmer_size) die("kmer size not set with -k <K>");
+  const size_t ncols = (size_t)intocolour + (sample_named ? 1 : 0);
+
+  /* print inputs in sample/task order (ctx_build.c:270-279) and estimate k-mers from file
+   * sizes (asyncio_input_nkmers: bytes, halved for FASTQ, times 5; async_read_io.c:313-334) */
+  size_t max_kmers = 0;
+  bool size_unknown = false;
+  for (size_t s = 0, t = 0; s < nsamples || t < ntasks;) {
+    if (t == ntasks || (s < nsamples && (int)s <= tasks[t].colour)) { status("[sample] %zu: %s", s, sample_names[s]); s++; }
+    else {
+      build_task *bt = &tasks[t];
+      seq_in *probe = seq_in_open(bt->path);
+      if (!probe) die("Cannot open -1 file: %s", bt->path);
+      bt->fmt = strcmp(bt->path, "-") ? seq_in_format(probe) : SEQ_FMT_UNKNOWN;
+      if (strcmp(bt->path, "-")) seq_in_close(probe); /* stdin can only be opened once: leak the probe */
+      status("[task] %s; FASTQ offset: %s, threshold: %s; cut homopolymers: %s; colour: %i",
+             bt->path, bt->fq_offset ? "set" : "auto-detect", bt->fq_cutoff ? "on" : "off",
+             bt->hp_cutoff ? "on" : "off", bt->colour);
+      long fs = file_size(bt->path);
+      if (fs < 0) size_unknown = true;
+      else max_kmers += (size_t)(bt->fmt == SEQ_FMT_FASTQ ? fs / 2 : fs) * 5;
+      t++;
+    }
+  }
+  if (size_unknown) max_kmers = SIZE_MAX;
+
+  /* ---- decide on memory (ctx_build.c:305-322, cmd_mem.c:38-130) ---- */
+  const size_t W = (2 * kmer_size + 63) / 64;
+  size_t bits_per_kmer = W * 64 + (4 + 1) * 8 * ncols + (sort_kmers ? 64 : 0);
+  uint64_t kmers_in_hash = 0;
+  size_t graph_mem = 0;
+  char s1[64], s2[64];
+  status("[memory] %zu bits per kmer", bits_per_kmer);
+  if (nkmers_set) graph_mem = hash_table_mem(num_kmers, bits_per_kmer, &kmers_in_hash);
+  else graph_mem = hash_table_mem_limit(mem_to_use, bits_per_kmer, &kmers_in_hash);
+  if (max_kmers != SIZE_MAX && max_kmers > 0 && !nkmers_set) {
+    uint64_t k2; size_t m2 = hash_table_mem((uint64_t)((double)max_kmers / IDEAL_OCCUPANCY), bits_per_kmer, &k2);
+    if (m2 < graph_mem) { graph_mem = m2; kmers_in_hash = k2; }
+  }
+  if (kmers_in_hash < 1024) graph_mem = hash_table_mem(1024, bits_per_kmer, &kmers_in_hash);
+  if (mem_set && nkmers_set && num_kmers > kmers_in_hash)
+    die("-n <kmers> requires more memory than given with -m <mem> [%s > %s]",
+        bytes_to_str(graph_mem, 1, s1), bytes_to_str(mem_to_use, 1, s2));
+  if (mem_set && graph_mem > mem_to_use)
+    die("Not enough memory for requested graph: require at least %s [>%s]",
+        bytes_to_str(graph_mem, 1, s1), bytes_to_str(mem_to_use, 1, s2));
+  status("[memory] graph: %s", bytes_to_str(graph_mem, 1, s1));
+
+  if (mcx_device_count() < 1) die("No MI355X / HIP device found: %s has no CPU build path", CMD_NAME);
+  uint64_t hbm_free = 0, hbm_total = 0;
+  mcx_check(mcx_device_memory(device, &hbm_free, &hbm_total), "device query");
+  const uint64_t dev_bytes = kmers_in_hash * 8 * (W + ncols);
+  if (dev_bytes > hbm_free)
+    die("Requesting more memory than is available [ Reqeusted: %s HBM free: %s ]",
+        bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_free, 1, s2));
+  status("[memory] device %d: table %s of %s HBM\n", device, bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_total, 1, s2));
+
+  /* ---- output path (futil_create_output: file_util.c:164-186) ---- */
+  FILE *fout = stdout;
+  if (strcmp(out_path, "-") != 0) {
+    if (!force && access(out_path, F_OK) == 0) die("File already exists: %s", out_path);
+    fout = fopen(out_path, "wb");
+    if (!fout) die("Cannot open output file: %s [%s]", out_path, strerror(errno));
+  }
+  status("Writing %zu colour graph to %s\n", ncols, strcmp(out_path, "-") ? out_path : "STDOUT");
+
+  mcx_graph *g = NULL;
+  mcx_check(mcx_graph_create(&g, (int)kmer_size, (int)ncols, kmers_in_hash, device), "Cannot allocate graph");
+  uint64_t slots = 0, tbytes = 0;
+  mcx_graph_capacity(g, &slots, &tbytes);
+  status("[hasht] Allocated table in HBM with %s entries, using %s", ulong_to_str(slots, s1), bytes_to_str(tbytes, 1, s2));
+
+  col_info *cols = calloc(ncols, sizeof(col_info));
+  for (size_t i = 0; i < ncols; i++) col_info_init(&cols[i]);
+  for (size_t i = 0; i < nsamples; i++) strcpy(cols[i].name, sample_names[i]);
+
+  /* ---- load every input in task order (build_graph(): build_graph.c:257-300) ---- */
+  read_batch batch;
+  mcx_load_stats prev;
+  memset(&prev, 0, sizeof(prev));
+  for (size_t t = 0; t < ntasks; t++) {
+    build_task *bt = &tasks[t];
+    seq_in *in = seq_in_open(bt->path);
+    if (!in) die("Cannot open -1 file: %s", bt->path);
+    const bool use_q = bt->fq_cutoff > 0 && seq_in_format(in) == SEQ_FMT_FASTQ;
+    read_batch_init(&batch, use_q);
+    uint8_t fq_abs = 0;
+    size_t nread_total = 0;
+    while (seq_in_fill(in, &batch, BATCH_BASES) > 0 || batch.nreads) {
+      if (use_q && !fq_abs) { /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 */
+        int off = bt->fq_offset ? bt->fq_offset : seq_in_guess_fq_offset(in);
+        if (!off) off = 33;
+        fq_abs = (uint8_t)(bt->fq_cutoff + off);
+      }
+      mcx_check(mcx_graph_add_reads(g, bt->colour, batch.bases, use_q ? batch.quals : NULL, batch.offsets,
+                                    batch.nreads, fq_abs, bt->hp_cutoff, &bt->stats), "add reads");
+      nread_total += batch.nreads;
+      read_batch_clear(&batch);
+    }
+    read_batch_free(&batch);
+    seq_in_close(in);
+    /* per-file contig statistics = device counter delta around the file */
+    mcx_load_stats cur;
+    mcx_check(mcx_graph_device_stats(g, &cur), "device stats");
+    bt->stats.num_good_reads = cur.num_good_reads - prev.num_good_reads;
+    bt->stats.num_bad_reads = cur.num_bad_reads - prev.num_bad_reads;
+    bt->stats.total_bases_loaded = cur.total_bases_loaded - prev.total_bases_loaded;
+    bt->stats.contigs_parsed = cur.contigs_parsed - prev.contigs_parsed;
+    bt->stats.num_kmers_loaded = cur.num_kmers_loaded - prev.num_kmers_loaded;
+    bt->stats.num_kmers_novel = cur.num_kmers_novel - prev.num_kmers_novel;
+    prev = cur;
+    col_info_update(&cols[bt->colour], bt->stats.total_bases_loaded, bt->stats.contigs_parsed);
+    (void)nread_total;
+  }
+  mcx_check(mcx_graph_sync(g), "sync");
+
+  uint64_t nk = 0;
+  mcx_check(mcx_graph_nkmers(g, &nk), "nkmers");
+  status("[hash] occupancy: %s / %s (%.2f%%)", ulong_to_str(nk, s1), ulong_to_str(slots, s2), 100.0 * (double)nk / (double)slots);
+
+  /* per-file statistics (build_graph_task_print_stats: build_graph.c:352-386) */
+  for (size_t t = 0; t < ntasks; t++) {
+    const mcx_load_stats *st = &tasks[t].stats;
+    char a[64], b[64];
+    status("[task] input: %s colour: %i", tasks[t].path, tasks[t].colour);
+    status("  SE reads: %s  PE reads: 0", ulong_to_str(st->num_se_reads, a));
+    status("  good reads: %s  bad reads: %s", ulong_to_str(st->num_good_reads, a), ulong_to_str(st->num_bad_reads, b));
+    status("  bases read: %s  bases loaded: %s", ulong_to_str(st->total_bases_read, a), ulong_to_str(st->total_bases_loaded, b));
+    status("  num contigs: %s  num kmers: %s novel kmers: %s", ulong_to_str(st->contigs_parsed, a),
+           ulong_to_str(st->num_kmers_loaded, b), ulong_to_str(st->num_kmers_novel, s1));
+  }
+
+  status("Dumping graph...\n");
+  size_t hdr = ctx_write_header(fout, (uint32_t)kmer_size, (uint32_t)ncols, cols);
+  mcx_check(mcx_graph_export(g, sort_kmers ? 1 : 0, write_sink, fout), "export");
+  if (fflush(fout) != 0) die("Cannot write to file");
+  const size_t recsz = 8 * W + 5 * ncols;
+  status("Dumped %s kmers in %zu colour%s into: %s (format version: 6; %s)", ulong_to_str(nk, s1), ncols,
+         ncols == 1 ? "" : "s", strcmp(out_path, "-") ? out_path : "STDOUT", bytes_to_str(hdr + nk * recsz, 1, s2));
+  if (fout != stdout) fclose(fout);
+  mcx_graph_destroy(g);
+  for (size_t t = 0; t < ntasks; t++) free(tasks[t].path);
+  free(tasks); free(cols); free(sample_names);
+  return EXIT_SUCCESS;
+}

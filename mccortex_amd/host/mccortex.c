@@ -1,0 +1,54 @@
+/* mccortex.c -- `mccortex<K> <command>` dispatcher (src/main/mccortex.c:15-28,279-332).
+ * Only `build` is implemented: this repository replaces that one command's hot path. */
+#include "host.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+static const char usage[] =
+"usage: " CMD_NAME " <command> [options] <args>\n"
+"version: mccortex_amd (MI355X build backend) k=" MCX_STR(MIN_KMER_SIZE) ".." MCX_STR(MAX_KMER_SIZE) "\n"
+"\n"
+"Commands:   build       construct cortex graph from FASTA/FASTQ\n"
+"\n"
+"  Type a command with no arguments to see help.\n"
+"\n"
+"Common Options:\n"
+"  -h, --help            Help message\n"
+"  -q, --quiet           Silence status output normally printed to STDERR\n"
+"  -f, --force           Overwrite output files if they already exist\n"
+"  -m, --memory <M>      Memory e.g. 1GB [default: 1GB]\n"
+"  -n, --nkmers <H>      Hash entries [default: 4M, ~4 million]\n"
+"  -t, --threads <T>     Limit on proccessing threads [default: 2]\n"
+"\n";
+
+int main(int argc, char **argv)
+{
+  struct timeval t0, t1;
+  gettimeofday(&t0, NULL);
+  msg_out = stderr;
+  host_set_cmdline(argc, argv);
+  if (argc == 1) { fputs(usage, stderr); return EXIT_FAILURE; }
+  /* -q anywhere silences status output (mccortex.c:255-277) */
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "--")) break;
+    if (!strcmp(argv[i], "-q") || !strcmp(argv[i], "--quiet")) {
+      msg_out = NULL;
+      memmove(argv + i, argv + i + 1, (size_t)(argc - i) * sizeof(char *));
+      argc--; i--;
+    }
+  }
+  if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { fputs(usage, stderr); return EXIT_FAILURE; }
+  if (strcmp(argv[1], "build") != 0) {
+    fprintf(stderr, "%s: command '%s' is not part of this build (only `build` is)\n\n", CMD_NAME, argv[1]);
+    fputs(usage, stderr);
+    return EXIT_FAILURE;
+  }
+  int rc = ctx_build(argc - 1, argv + 1);
+  gettimeofday(&t1, NULL);
+  double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_usec - t0.tv_usec);
+  if (rc == 0) status("[time] %.2f seconds", secs);
+  status(rc == 0 ? "  Done." : "  Fail.");
+  return rc;
+}

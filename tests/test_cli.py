@@ -1,0 +1,161 @@
+"""`mccortex<K> build` host program: command-line contract (CPU) and end-to-end .ctx parity (GPU).
+The option rules follow src/commands/ctx_build.c:133-242; the end-to-end check is the reference's
+own integration pattern (tests/sort/Makefile:29-45): `build --sort` output compared byte for byte."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mccortex_amd", "bin")
+
+
+def run(maxk, *args, stdin=None):
+    exe = os.path.join(BIN, "mccortex%d" % maxk)
+    p = subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, input=stdin)
+    return p.returncode, p.stdout, p.stderr.decode(errors="replace")
+
+
+@pytest.fixture(scope="module")
+def built(mcx):
+    assert os.path.exists(os.path.join(BIN, "mccortex31")) and os.path.exists(os.path.join(BIN, "mccortex63"))
+    return True
+
+
+def test_usage_and_argument_errors(built, tmp_path):
+    fa = tmp_path / "a.fa"
+    fa.write_text(">r\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    rc, _, err = run(31)
+    assert rc == 1 and "usage: mccortex31 <command>" in err
+    rc, _, err = run(31, "view", "x.ctx")
+    assert rc == 1 and "not part of this build" in err
+    rc, _, err = run(31, "build", "-h")
+    assert rc == 1 and "usage: mccortex31 build [options] <out.ctx>" in err
+    cases = [
+        (["build", "-k", "30", "-s", "a", "--seq", str(fa), "o.ctx"], "Invalid kmer-size (30)"),
+        (["build", "-k", "33", "-s", "a", "--seq", str(fa), "o.ctx"], "Please recompile with correct kmer size (33)"),
+        (["build", "-k", "31", "--seq", str(fa), "o.ctx"], "Please give sample name first"),
+        (["build", "-k", "31", "-s", "a", "--seq", str(fa)], "Expected exactly one graph file"),
+        (["build", "-k", "31", "-s", "a", "--seq", str(fa), "o.ctx", "extra"], "Expected only one graph file"),
+        (["build", "-k", "31", "o.ctx"], "No inputs given"),
+        (["build", "-k", "31", "-s", "a", "--seq", str(fa), "-Q", "10", "o.ctx"], "Arguments not given BEFORE sequence file"),
+        (["build", "-s", "a", "--seq", str(fa), "o.ctx"], "kmer size not set"),
+        (["build", "-k", "31", "-k", "21", "-s", "a", "--seq", str(fa), "o.ctx"], "given twice"),
+        (["build", "-k", "31", "-s", "undefined", "--seq", str(fa), "o.ctx"], "Bad sample name"),
+        (["build", "-k", "31", "-s", "a b", "--seq", str(fa), "o.ctx"], "whitespace"),
+        (["build", "-k", "31", "-s", "a", "--seq", str(tmp_path / "missing.fa"), "o.ctx"], "Cannot open"),
+        (["build", "-k", "31", "-m", "12XB", "-s", "a", "--seq", str(fa), "o.ctx"], "Invalid memory argument"),
+        (["build", "-k", "31", "-s", "a", "-p", "--seq", str(fa), "o.ctx"], "--remove-pcr is not available"),
+        (["build", "-k", "31", "-s", "a", "--bogus", "o.ctx"], "Bad option"),
+    ]
+    for args, msg in cases:
+        rc, _, err = run(31, *args)
+        assert rc == 1, args
+        assert msg in err, (args, err)
+    # mccortex63 accepts 33..63 only (MIN_KMER_SIZE = MAXK-30, reference Makefile:48)
+    rc, _, err = run(63, "build", "-k", "31", "-s", "a", "--seq", str(fa), "o.ctx")
+    assert rc == 1 and "Please recompile" in err
+    # single-dash long options are accepted (getopt_long_only)
+    rc, _, err = run(31, "build", "-kmer", "30", "-sample", "a", "-seq", str(fa), "o.ctx")
+    assert rc == 1 and "Invalid kmer-size (30)" in err
+
+
+def _write_inputs(tmp_path, bases, offs, name, fmt, gz=False, qual=None, width=0):
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(len(offs) - 1)]
+    out = []
+    for i, r in enumerate(reads):
+        if fmt == "fa":
+            body = r if not width else b"\n".join(r[j:j + width] for j in range(0, max(len(r), 1), width))
+            out.append(b">read%d desc\n" % i + body + b"\n")
+        elif fmt == "fq":
+            q = bytes(qual[int(offs[i]):int(offs[i + 1])]) if qual is not None else b"I" * len(r)
+            out.append(b"@read%d\n" % i + r + b"\n+\n" + q + b"\n")
+        else:
+            if len(r):
+                out.append(r + b"\n")
+    data = b"".join(out)
+    p = tmp_path / (name + "." + fmt + (".gz" if gz else ""))
+    if gz:
+        with gzip.open(p, "wb") as f:
+            f.write(data)
+    else:
+        p.write_bytes(data)
+    return str(p)
+
+
+@pytest.mark.gpu
+def test_build_sort_matches_oracle_ctx(built, orc, tmp_path):
+    g = synth.genome(40000, 3)
+    b0, o0 = synth.reads(3000, 100, seed=1, g=g, n_frac=0.05, lower_frac=0.1)
+    b1, o1 = synth.reads(2000, 150, seed=2, g=g, n_frac=0.05)
+    b2, o2 = synth.reads(1500, 80, seed=3, g=g, var_len=True)
+    f0 = _write_inputs(tmp_path, b0, o0, "s0", "fa", width=60)
+    f1 = _write_inputs(tmp_path, b1, o1, "s1", "fq", gz=True)
+    f2 = _write_inputs(tmp_path, b2, o2, "s2", "txt")
+    for maxk, k in [(31, 31), (31, 17), (63, 51)]:
+        out = str(tmp_path / ("out%d.ctx" % k))
+        rc, _, err = run(maxk, "build", "-k", str(k), "-n", "1M", "--sort",
+                         "--sample", "alice", "--seq", f0, "--seq", f1, "--sample", "bob", "--seq2", f2 + ":" + f0, out)
+        assert rc == 0, err
+        og = orc.Graph(k, 2, 1 << 20)
+        og.set_sample(0, "alice"); og.set_sample(1, "bob")
+        # plain-format empty lines are skipped by the reader: drop empty reads for colour 1 file 1
+        keep = np.diff(o2.astype(np.int64)) > 0
+        o2k = np.concatenate([[0], np.cumsum(np.diff(o2.astype(np.int64))[keep])]).astype(np.uint64)
+        for col, bb, oo in [(0, b0, o0), (0, b1, o1), (1, b2, o2k), (1, b0, o0)]:
+            st = og.add_reads(col, bb, oo)
+            og.update_stats(col, st)
+        want = og.ctx_bytes(True)
+        got = open(out, "rb").read()
+        assert len(got) == len(want)
+        assert got == want
+        # refuses to overwrite without -f; unsorted output has the same record set
+        rc, _, err = run(maxk, "build", "-k", str(k), "-n", "1M", "-s", "alice", "--seq", f0, out)
+        assert rc == 1 and "already exists" in err
+        rc, _, err = run(maxk, "build", "-q", "-f", "-k", str(k), "-n", "1M", "-s", "alice", "--seq", f0, "--seq", f1,
+                         "-s", "bob", "--seq", f2, "--seq", f0, out)
+        assert rc == 0 and err == ""
+        got2 = open(out, "rb").read()
+        hs = og.header_size()
+        rs = 8 * og.W + 10
+        assert got2[:hs] == want[:hs]
+        a = np.frombuffer(got2[hs:], np.uint8).reshape(-1, rs)
+        b = np.frombuffer(want[hs:], np.uint8).reshape(-1, rs)
+        assert sorted(map(bytes, a)) == sorted(map(bytes, b))
+
+
+@pytest.mark.gpu
+def test_build_quality_cutoff_stdin_stdout(built, orc, tmp_path):
+    bases, offs = synth.reads(2000, 100, genome_len=20000, seed=8, n_frac=0.05)
+    rng = np.random.default_rng(1)
+    quals = rng.integers(33, 74, len(bases)).astype(np.uint8)
+    fq = _write_inputs(tmp_path, bases, offs, "q", "fq", qual=quals)
+    out = str(tmp_path / "q.ctx")
+    rc, _, err = run(31, "build", "-k", "21", "-n", "1M", "-S", "-s", "smp", "-Q", "10", "-O", "33", "-H", "6", "--seq", fq, out)
+    assert rc == 0, err
+    og = orc.Graph(21, 1, 1 << 20)
+    og.set_sample(0, "smp")
+    st = og.add_reads(0, bases, offs, quals=quals, fq_cutoff=43, hp_cutoff=6)
+    og.update_stats(0, st)
+    assert open(out, "rb").read() == og.ctx_bytes(True)
+    # stdin '-' as input, '-' (stdout) as output
+    fa = open(_write_inputs(tmp_path, bases, offs, "p", "fa"), "rb").read()
+    rc, stdout, err = run(31, "build", "-q", "-k", "21", "-n", "1M", "-S", "-s", "smp", "--seq", "-", "-", stdin=fa)
+    assert rc == 0, err
+    og2 = orc.Graph(21, 1, 1 << 20)
+    og2.set_sample(0, "smp")
+    st = og2.add_reads(0, bases, offs)
+    og2.update_stats(0, st)
+    assert stdout == og2.ctx_bytes(True)
+
+
+@pytest.mark.gpu
+def test_build_table_full_dies(built, tmp_path):
+    bases, offs = synth.reads(4000, 100, genome_len=300000, seed=4)
+    fa = _write_inputs(tmp_path, bases, offs, "big", "fa")
+    rc, _, err = run(31, "build", "-k", "31", "-n", "1024", "-s", "a", "--seq", fa, str(tmp_path / "o.ctx"))
+    assert rc == 1 and "Hash table is full" in err
