@@ -236,10 +236,13 @@ int ctx_build(int argc, char **argv)
     if (t == ntasks || (s < nsamples && (int)s <= tasks[t].colour)) { status("[sample] %zu: %s", s, sample_names[s]); s++; }
     else {
       build_task *bt = &tasks[t];
-      seq_in *probe = seq_in_open(bt->path);
-      if (!probe) die("Cannot open -1 file: %s", bt->path);
-      bt->fmt = strcmp(bt->path, "-") ? seq_in_format(probe) : SEQ_FMT_UNKNOWN;
-      if (strcmp(bt->path, "-")) seq_in_close(probe); /* stdin can only be opened once: leak the probe */
+      bt->fmt = SEQ_FMT_UNKNOWN;
+      if (strcmp(bt->path, "-")) { /* stdin can only be read once: no format probe */
+        seq_in *probe = seq_in_open(bt->path);
+        if (!probe) die("Cannot open -1 file: %s", bt->path);
+        bt->fmt = seq_in_format(probe);
+        seq_in_close(probe);
+      }
       status("[task] %s; FASTQ offset: %s, threshold: %s; cut homopolymers: %s; colour: %i",
              bt->path, bt->fq_offset ? "set" : "auto-detect", bt->fq_cutoff ? "on" : "off",
              bt->hp_cutoff ? "on" : "off", bt->colour);
