@@ -121,9 +121,13 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # MCX_BENCH_FORCE_SHARD=1: run the partition -> all-to-all -> insert path even at N=1
+    # (validation of the N>1 code on a 1-GPU box; never used for the reported N=1 number)
+    force_shard = os.environ.get("MCX_BENCH_FORCE_SHARD") == "1"
+    if world > 1 or force_shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import __graft_entry__
     if rank == 0:
@@ -131,6 +135,7 @@ def main():
     if world > 1:
         dist.barrier()
     import mccortex_amd as mcx
+    from mccortex_amd import shard
 
     B = args.batch_reads
     nsteps, nwarm = args.steps, args.warmup
@@ -144,33 +149,28 @@ def main():
     ext = torch.cuda.ExternalStream(graph.stream, device=device)
     W = graph.W
 
-    if world > 1:
+    sharded = world > 1 or force_shard
+    live = []
+    if sharded:
         bin_cap = int(B * (READ_LEN - K + 1) / world * 1.10) + 65536
         send_keys = torch.empty((world, bin_cap, W), dtype=torch.int64, device=device)
         send_edges = torch.empty((world, bin_cap), dtype=torch.uint8, device=device)
-        recv_keys = torch.empty((world * bin_cap, W), dtype=torch.int64, device=device)
-        recv_edges = torch.empty((world * bin_cap,), dtype=torch.uint8, device=device)
         counts = torch.zeros(world, dtype=torch.int64, device=device)
 
     def step(i):
         s = batches[i]
-        if world == 1:
+        if not sharded:
             graph.add_stream_dev(0, s, s.numel())
             return
         counts.zero_()
         torch.cuda.current_stream().synchronize()
         graph.partition_stream_dev(s, s.numel(), world, bin_cap, send_keys, send_edges, counts)
-        graph.sync()
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts)
-        sc, rc_ = counts.tolist(), recv_counts.tolist()
-        ro = np.concatenate([[0], np.cumsum(rc_)]).astype(np.int64)
-        dist.all_to_all([recv_keys[ro[p]:ro[p + 1]] for p in range(world)],
-                        [send_keys[p, :sc[p]] for p in range(world)])
-        dist.all_to_all([recv_edges[ro[p]:ro[p + 1]] for p in range(world)],
-                        [send_edges[p, :sc[p]] for p in range(world)])
+        graph.sync()      # also: the previous step's insert (same stream) has finished
+        live.clear()      # ... so its receive buffers may now be recycled by the allocator
+        rk, re_, rc_ = shard.exchange(send_keys, send_edges, counts)
         torch.cuda.current_stream().synchronize()
-        graph.insert_tuples_dev(0, recv_keys, recv_edges, int(ro[-1]))
+        graph.insert_tuples_dev(0, rk, re_, int(sum(rc_)))
+        live.append((rk, re_))
 
     def fence():
         torch.cuda.synchronize()
@@ -195,7 +195,7 @@ def main():
     dt = time.perf_counter() - t0
 
     st = graph.device_stats()
-    kmers_local = st.num_kmers_loaded
+    kmers_local = st.num_kmers_loaded  # k-mer occurrences this rank k-merised (== inserted job-wide)
     tot = torch.tensor([float(kmers_local), dt], dtype=torch.float64, device=device)
     if world > 1:
         k_all = tot[:1].clone()
@@ -216,10 +216,10 @@ def main():
             "config": {"workload": "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
                                    "table %d slots per GPU" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots),
                        "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
-                       "table_slots_per_gpu": args.table_slots, "sharding": "none" if world == 1 else "hash-prefix x%d, all-to-all" % world,
+                       "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else "hash-prefix x%d, all-to-all" % world,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel)},
         }
-        if world == 1:
+        if not sharded:
             kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(nsteps)]
             avg_ms = sum(kern_ms) / len(kern_ms)
             alg_bytes = (ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel) / nsteps
@@ -230,7 +230,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(batches[0], rank)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_shard:
         dist.barrier()
         dist.destroy_process_group()
 

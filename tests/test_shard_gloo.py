@@ -1,0 +1,76 @@
+"""World-size-2 gloo test of the sharded build's host logic (exchange + merge), on CPU.
+Tuples come from the oracle (allowed in tests); owners from the product's mcx_key_owner."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, k, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mccortex_amd as mcx
+    from mccortex_amd import shard
+    from oracle import orc
+    g = synth.genome(20000, 1)
+    bases, offs = synth.reads(1500, 100, seed=100 + rank, g=g, n_frac=0.05)
+    keys, edges = orc.tuples(k, bases, offs)
+    W = keys.shape[1]
+    owner = np.array([mcx.key_owner([int(x) for x in row], k, world) for row in keys], dtype=np.int64)
+    cap = len(keys)
+    sk = torch.zeros((world, cap, W), dtype=torch.int64)
+    se = torch.zeros((world, cap), dtype=torch.uint8)
+    cnt = torch.zeros(world, dtype=torch.int64)
+    for p in range(world):
+        m = owner == p
+        n = int(m.sum())
+        sk[p, :n] = torch.from_numpy(keys[m].view(np.int64))
+        se[p, :n] = torch.from_numpy(edges[m])
+        cnt[p] = n
+    rk, re, rc = shard.exchange(sk, se, cnt)
+    rkeys = rk.numpy().view(np.uint64)
+    # everything received is owned by this rank
+    assert all(mcx.key_owner([int(x) for x in row], k, world) == rank for row in rkeys[::97])
+    K, C, E = orc.graph_from_tuples(rkeys, re.numpy())
+    rs = 8 * W + 5
+    body = np.zeros((len(K), rs), dtype=np.uint8)
+    body[:, :8 * W] = K.view(np.uint8).reshape(len(K), 8 * W)
+    body[:, 8 * W:8 * W + 4] = C[:, :1].copy().view(np.uint8).reshape(len(K), 4)
+    body[:, 8 * W + 4] = E[:, 0]
+    np.save(os.path.join(tmpdir, "body%d.npy" % rank), body)
+    np.save(os.path.join(tmpdir, "in%d.npy" % rank), np.concatenate([bases, np.zeros(1, np.uint8)]))
+    np.save(os.path.join(tmpdir, "off%d.npy" % rank), offs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [31, 47])
+def test_two_rank_exchange_equals_single_graph(mcx, orc, tmp_path, k):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path)), nprocs=world, join=True)
+    from mccortex_amd import shard
+    W = (2 * k + 63) // 64
+    rs = 8 * W + 5
+    bodies = [np.load(tmp_path / ("body%d.npy" % r)).tobytes() for r in range(world)]
+    merged = shard.merge_sorted_bodies(bodies, rs, 8 * W)
+    og = orc.Graph(k, 1, 1 << 20)
+    for r in range(world):
+        b = np.load(tmp_path / ("in%d.npy" % r))[:-1]
+        o = np.load(tmp_path / ("off%d.npy" % r))
+        og.add_reads(0, b, o)
+    assert merged == og.ctx_bytes(True)[og.header_size():]
