@@ -255,6 +255,7 @@ struct orc_graph {
   uint64_t *total_sequence;
   char (*sample)[256];
   volatile int full;
+  int force_generic; /* tests: run the multi-word code even when W == 1 */
 };
 
 orc_graph *orc_graph_new(int k, int ncols, uint64_t capacity_kmers, uint32_t seed)
@@ -293,6 +294,7 @@ int orc_graph_set_sample(orc_graph *g, int col, const char *name)
   strcpy(g->sample[col], name);
   return 0;
 }
+void orc_graph_force_generic(orc_graph *g, int on) { g->force_generic = on; }
 uint64_t orc_graph_nkmers(const orc_graph *g) { return g->num_kmers; }
 uint64_t orc_graph_capacity(const orc_graph *g) { return g->capacity; }
 
@@ -377,9 +379,85 @@ static inline void add_edge(orc_graph *g, int colour, orc_node src, orc_node tgt
   __sync_fetch_and_or(&g->edges[tgt.hkey * (uint64_t)g->ncols + (uint64_t)colour], e_tgt);
 }
 
+/* ---- W == 1 fast path -------------------------------------------------------------
+ * Same algorithm with the key held in one uint64_t, as the reference's MAXK=31 build has it
+ * at compile time (NUM_BKMER_WORDS == 1): used for the timed CPU baseline so the port is not
+ * handicapped by the generic multi-word code above.  Results are identical (tests compare). */
+static inline uint32_t hash_w1(uint64_t key, uint32_t initval)
+{ /* kmer_hash.h:162-211 with BKMER_BYTES == 8 */
+  uint32_t a, b, c;
+  a = b = c = 0xdeadbeefu + 8u + initval;
+  a += (uint32_t)key; b += (uint32_t)(key >> 32);
+  LK3_FINAL(a, b, c);
+  return c;
+}
+
+static inline uint64_t find_or_insert_w1(orc_graph *g, uint64_t key, int *found)
+{ /* hash_table.c:250-281 */
+  const uint64_t want = key | ORC_FLAG;
+  int i;
+  for(i = 0; i < ORC_REHASH_LIMIT; i++) {
+    uint64_t h = hash_w1(key, g->seed + (uint32_t)i) & g->hash_mask;
+    bkt_lock(&g->locks[h]);
+    uint64_t *slot = g->table + h * g->bucket_size;
+    unsigned n = g->bsize[h], j;
+    for(j = 0; j < n; j++)
+      if(slot[j] == want) { *found = 1; bkt_unlock(&g->locks[h]); return h * g->bucket_size + j; }
+    if(n < g->bucket_size) {
+      slot[n] = want;
+      g->bsize[h] = (uint8_t)(n + 1);
+      __sync_add_and_fetch(&g->num_kmers, 1);
+      *found = 0;
+      bkt_unlock(&g->locks[h]);
+      return h * g->bucket_size + n;
+    }
+    bkt_unlock(&g->locks[h]);
+  }
+  return ORC_NOT_FOUND;
+}
+
+static inline orc_node node_w1(orc_graph *g, uint64_t bk, int colour, int *found)
+{ /* db_graph.c:126-135 + :101-105; binary_kmer.c:43-57 */
+  const int k = g->k;
+  unsigned first = (unsigned)(bk >> (2 * k - 2)) & 3u, last = (unsigned)bk & 3u;
+  uint64_t key = bk;
+  if(!(first < (~last & 3u))) {
+    orc_bkmer t; t.b[0] = bk;
+    uint64_t rc = orc_kmer_revcomp(t, k).b[0];
+    if(rc < bk) key = rc;
+  }
+  orc_node n;
+  n.hkey = find_or_insert_w1(g, key, found);
+  n.orient = key == bk ? 0 : 1;
+  if(n.hkey != ORC_NOT_FOUND) covg_inc(&g->covgs[n.hkey * (uint64_t)g->ncols + (uint64_t)colour]);
+  return n;
+}
+
+static size_t build_from_str_w1(orc_graph *g, int colour, const char *seq, size_t len)
+{ /* build_graph.c:122-150 */
+  const int k = g->k;
+  const uint64_t mask = UINT64_MAX >> (64 - 2 * k);
+  size_t i, nonnovel = 0;
+  int found = 0;
+  uint64_t bk = 0;
+  for(i = 0; i < (size_t)k; i++) bk = (bk << 2) | (uint64_t)orc_char_to_nuc((unsigned char)seq[i]);
+  orc_node prev = node_w1(g, bk, colour, &found), curr;
+  if(prev.hkey == ORC_NOT_FOUND) { g->full = 1; return 0; }
+  nonnovel += (size_t)found;
+  for(i = (size_t)k; i < len; i++, prev = curr) {
+    bk = ((bk << 2) | (uint64_t)orc_char_to_nuc((unsigned char)seq[i])) & mask;
+    curr = node_w1(g, bk, colour, &found);
+    if(curr.hkey == ORC_NOT_FOUND) { g->full = 1; return nonnovel; }
+    add_edge(g, colour, prev, curr);
+    nonnovel += (size_t)found;
+  }
+  return nonnovel;
+}
+
 /* build_graph.c:122-150 */
 static size_t build_from_str(orc_graph *g, int colour, const char *seq, size_t len)
 {
+  if(g->W == 1 && !g->force_generic) return build_from_str_w1(g, colour, seq, len);
   const int k = g->k;
   size_t i, nonnovel = 0;
   int found = 0;

@@ -53,6 +53,7 @@ size_t orc_contig_end(const char *seq, size_t seqlen, const char *qual, size_t q
 orc_graph *orc_graph_new(int k, int ncols, uint64_t capacity_kmers, uint32_t seed);
 void       orc_graph_free(orc_graph *g);
 int        orc_graph_set_sample(orc_graph *g, int col, const char *name);
+void       orc_graph_force_generic(orc_graph *g, int on); /* W==1: use the multi-word code path */
 uint64_t   orc_graph_nkmers(const orc_graph *g);
 uint64_t   orc_graph_capacity(const orc_graph *g);
 

@@ -69,6 +69,7 @@ def lib():
     L.orc_graph_new.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32]
     L.orc_graph_free.argtypes = [C.c_void_p]
     L.orc_graph_set_sample.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    L.orc_graph_force_generic.argtypes = [C.c_void_p, C.c_int]
     L.orc_graph_nkmers.restype = C.c_uint64
     L.orc_graph_nkmers.argtypes = [C.c_void_p]
     L.orc_graph_capacity.restype = C.c_uint64
@@ -134,6 +135,9 @@ class Graph:
         if getattr(self, "h", None):
             self.L.orc_graph_free(self.h)
             self.h = None
+
+    def force_generic(self, on=True):
+        self.L.orc_graph_force_generic(self.h, 1 if on else 0)
 
     def set_sample(self, col, name):
         assert self.L.orc_graph_set_sample(self.h, col, name.encode()) == 0

@@ -213,3 +213,17 @@ def test_quality_homopolymer_rules(orc):
     assert L.orc_contig_start(hp, len(hp), None, 0, 0, 5, 0, 4) == 0
     e = L.orc_contig_end(hp, len(hp), None, 0, 0, 5, 0, 4, C.byref(ss))
     assert e == 7 and ss.value == 4  # run A A A (A) would reach 4 at index 7
+
+
+def test_w1_fast_path_equals_generic_code(orc):
+    """The single-word fast path used for the timed CPU baseline gives the same graph as the
+    generic multi-word restatement."""
+    bases, offs = synth.reads(3000, 100, genome_len=15000, seed=12, n_frac=0.1, lower_frac=0.2)
+    for k in (5, 21, 31):
+        a = orc.Graph(k, 2, 1 << 18)
+        b = orc.Graph(k, 2, 1 << 18)
+        b.force_generic()
+        for g in (a, b):
+            g.add_reads(0, bases, offs)
+            g.add_reads(1, bases[:int(offs[1000])], offs[:1001], nthreads=4)
+        assert a.ctx_bytes(True) == b.ctx_bytes(True)
