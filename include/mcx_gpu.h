@@ -72,6 +72,18 @@ void mcx_graph_destroy(mcx_graph *g);
 /* Empty the table and zero the statistics (graph stays allocated). */
 int mcx_graph_reset(mcx_graph *g);
 
+/* Tuning knobs (no reference equivalent).  Keys:
+ *   "defer"        1 (default): k-mer occurrences are radix-partitioned by table region into
+ *                  HBM bins and applied one sub-table at a time from LDS when the bins fill
+ *                  up or the graph is read (sync / nkmers / stats / export); 0: every
+ *                  occurrence is inserted straight into the HBM table with device atomics.
+ *                  Both give the same graph.
+ *   "defer_tuples" occurrences buffered per flush (sizes the bin workspace in HBM)
+ *   "profile"      1: time every kernel launch with HIP events (see mcx_graph_profile) */
+int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value);
+/* "kernel calls total_ms" per line for the launches recorded since "profile" was set. */
+int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen);
+
 /* Slots actually allocated (>= capacity_kmers) and bytes of HBM held. */
 int mcx_graph_capacity(const mcx_graph *g, uint64_t *slots, uint64_t *bytes);
 

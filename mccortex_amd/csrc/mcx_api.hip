@@ -16,6 +16,7 @@
 
 #include "../../include/mcx_gpu.h"
 #include "mcx_kernels.h"
+#include "mcx_defer.h"
 
 using namespace mcx;
 
@@ -67,7 +68,25 @@ struct mcx_graph {
   uint64_t stage_alloc = 0;
   int cur = 0;
   int grid = 0;
+  // ---- deferred (partition -> LDS insert) path, mcx_defer.h ----
+  bool defer = true;
+  uint64_t defer_tuples = 0;    // tuples buffered per flush (0 = pick from the table size)
+  uint32_t nsub = 0;            // sub-tables
+  uint32_t b1 = 0, subs_per_bin = 0;
+  uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 bin / per L2 (sub-table) bin
+  uint64_t *l1_keys = nullptr, *l2_keys = nullptr;
+  uint8_t *l1_edges = nullptr, *l2_edges = nullptr;
+  unsigned long long *l1_cnt = nullptr, *l2_cnt = nullptr;
+  uint64_t pending = 0;         // upper bound of tuples sitting in the L1 bins
+  int pending_colour = 0;
+  // ---- optional per-kernel timing (mcx_graph_configure("profile", 1)) ----
+  bool profile = false;
+  struct Span { const char *name; hipEvent_t a, b; };
+  std::vector<Span> spans;
 };
+
+static int flush_deferred(mcx_graph *g);
+static void free_defer(mcx_graph *g);
 
 extern "C" const char *mcx_last_error(void) { return g_err; }
 extern "C" const char *mcx_version(void) { return "mccortex_amd 0.1 (gfx950)"; }
@@ -116,14 +135,14 @@ extern "C" int mcx_graph_create(mcx_graph **out, int kmer_size, int ncols, uint6
   g->W = words_for_k(kmer_size);
   g->ncols = ncols;
   g->device = device;
-  const uint64_t min_slots = 1024;
-  uint64_t slots = std::max(capacity_kmers, min_slots);
-  slots = (slots + 1023) / 1024 * 1024;
+  uint64_t slots = std::max<uint64_t>(capacity_kmers, 1024);
+  slots = (slots + kSubSlots - 1) / kSubSlots * kSubSlots;  // whole sub-tables
   if (slots / kBucket > 0xFFFFFFFFull) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }
   g->t.nslots = slots;
   g->t.nbuckets = (uint32_t)(slots / kBucket);
   g->t.S = (uint32_t)(g->W + ncols);
-  g->t.max_probe = (uint32_t)std::min<uint64_t>(slots, 8192);
+  g->t.max_probe = (uint32_t)kSubSlots;  // a probe sequence never leaves its sub-table
+  { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
   g->table_bytes = slots * g->t.S * 8;
 
   hipDeviceProp_t prop;
@@ -161,6 +180,8 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
     if (g->d_stage[i]) (void)hipFree(g->d_stage[i]);
     if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
   }
+  free_defer(g);
+  for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (g->t.rec) (void)hipFree(g->t.rec);
   if (g->d_ctr) (void)hipFree(g->d_ctr);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
@@ -174,6 +195,8 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
+  if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * 8, g->stream));
+  g->pending = 0;  // buffered tuples are discarded with the table
   return MCX_OK;
 }
 
@@ -196,40 +219,252 @@ struct StreamLaunch {
   unsigned char *flag;
 };
 
-template <int W, bool ONECOL, int MODE>
-static void launch_stream_t(mcx_graph *g, const StreamLaunch &L, int colour, const PartitionSink<W> &ps)
+#define DISPATCH_WC(g, F, ...)                                                        \
+  do {                                                                                \
+    if ((g)->W == 1) { if ((g)->ncols == 1) F<1, true>(__VA_ARGS__); else F<1, false>(__VA_ARGS__); } \
+    else { if ((g)->ncols == 1) F<2, true>(__VA_ARGS__); else F<2, false>(__VA_ARGS__); }            \
+  } while (0)
+
+// optional per-kernel timing with HIP events on the handle's stream
+struct SpanGuard {
+  mcx_graph *g; size_t idx; bool on;
+  SpanGuard(mcx_graph *g_, const char *name) : g(g_), idx(0), on(g_->profile) {
+    if (!on) return;
+    mcx_graph::Span sp{name, nullptr, nullptr};
+    (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b);
+    (void)hipEventRecord(sp.a, g->stream);
+    idx = g->spans.size();
+    g->spans.push_back(sp);
+  }
+  ~SpanGuard() { if (on) (void)hipEventRecord(g->spans[idx].b, g->stream); }
+};
+
+template <class K> static void allow_lds(K kernel, size_t bytes)
 {
-  StreamArgs a;
-  a.stream = L.stream;
-  a.nbytes = L.nbytes;
-  a.pos_lo = L.pos_lo;
-  a.pos_hi = L.pos_hi;
-  a.tile0 = L.pos_lo / kTile;
-  a.ntiles = (L.pos_hi + kTile - 1) / kTile;
-  a.k = g->k;
-  a.ctr = g->d_ctr;
-  a.flag = L.flag;
-  InsertSink<W, ONECOL> is;
-  is.t = g->t;
-  is.col = (uint32_t)colour;
-  const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
-  if (!nt) return;
-  const int grid = (int)std::min<uint64_t>(nt, (uint64_t)g->grid);
-  hipLaunchKernelGGL((k_stream<W, ONECOL, MODE>), dim3(grid), dim3(kThreads), 0, g->stream, a, is, ps);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-static int launch_insert_stream(mcx_graph *g, const StreamLaunch &L, int colour)
+static StreamArgs make_args(mcx_graph *g, const StreamLaunch &L)
 {
-  if (g->W == 1) {
-    PartitionSink<1> ps{};
-    if (g->ncols == 1) launch_stream_t<1, true, 0>(g, L, colour, ps);
-    else launch_stream_t<1, false, 0>(g, L, colour, ps);
-  } else {
-    PartitionSink<2> ps{};
-    if (g->ncols == 1) launch_stream_t<2, true, 0>(g, L, colour, ps);
-    else launch_stream_t<2, false, 0>(g, L, colour, ps);
+  StreamArgs a;
+  a.stream = L.stream; a.nbytes = L.nbytes; a.pos_lo = L.pos_lo; a.pos_hi = L.pos_hi;
+  a.tile0 = L.pos_lo / kTile;
+  a.ntiles = (L.pos_hi + kTile - 1) / kTile;
+  a.k = g->k; a.ctr = g->d_ctr; a.flag = L.flag;
+  return a;
+}
+
+template <int W, bool ONECOL> static void launch_direct_t(mcx_graph *g, const StreamLaunch &L, int colour)
+{
+  const StreamArgs a = make_args(g, L);
+  const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
+  if (!nt) return;
+  InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
+  SpanGuard sp(g, "k_stream");
+  hipLaunchKernelGGL((k_stream<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid)), dim3(kThreads), 0,
+                     g->stream, a, is);
+}
+
+template <int W, bool ONECOL>
+static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour, BinSpec bs, BinOut out)
+{
+  const StreamArgs a = make_args(g, L);
+  const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
+  if (!nt) return;
+  InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
+  static bool once = false;
+  if (!once) { allow_lds(k_stream_bin<W, ONECOL>, sizeof(BinLds<W>)); once = true; }
+  SpanGuard sp(g, "k_stream_bin");
+  hipLaunchKernelGGL((k_stream_bin<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid)), dim3(kThreads),
+                     sizeof(BinLds<W>), g->stream, a, bs, out, is);
+}
+
+template <int W, bool ONECOL>
+static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
+{
+  const uint64_t nchunks = (in.seg_cap + kTile - 1) / kTile * in.nseg;
+  if (!nchunks) return;
+  InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
+  static bool once = false;
+  if (!once) { allow_lds(k_tuples_bin<W, ONECOL>, sizeof(BinLds<W>)); once = true; }
+  SpanGuard sp(g, "k_tuples_bin");
+  hipLaunchKernelGGL((k_tuples_bin<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nchunks, (uint64_t)g->grid * 4)),
+                     dim3(kThreads), sizeof(BinLds<W>), g->stream, in, bs, out, is, g->d_ctr);
+}
+
+template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour)
+{
+  const size_t lds = kSubSlots * (W + 1) * 8;
+  static bool once = false;
+  if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
+  BinOut bins{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
+  SpanGuard sp(g, "k_lds_insert");
+  hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(g->nsub, (uint64_t)g->grid * 4)),
+                     dim3(kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
+}
+
+template <int W, bool ONECOL>
+static void launch_insert_tuples_t(mcx_graph *g, int colour, const uint64_t *keys, const uint8_t *edges, uint64_t n)
+{
+  const int grid = (int)std::min<uint64_t>((n + kThreads * kBatch - 1) / (kThreads * kBatch), (uint64_t)g->grid);
+  InsertSink<W, ONECOL> s{g->t, (uint32_t)colour};
+  SpanGuard sp(g, "k_insert_tuples");
+  hipLaunchKernelGGL((k_insert_tuples<W, ONECOL>), dim3(grid), dim3(kThreads), 0, g->stream, s, keys, edges, n, g->d_ctr);
+}
+
+// ---- deferred path bookkeeping -------------------------------------------------------------
+static void free_defer(mcx_graph *g)
+{
+  (void)hipFree(g->l1_keys); (void)hipFree(g->l1_edges); (void)hipFree(g->l1_cnt);
+  (void)hipFree(g->l2_keys); (void)hipFree(g->l2_edges); (void)hipFree(g->l2_cnt);
+  g->l1_keys = g->l2_keys = nullptr; g->l1_edges = g->l2_edges = nullptr; g->l1_cnt = g->l2_cnt = nullptr;
+  g->cap1 = g->cap2 = 0;
+}
+
+static int ensure_defer(mcx_graph *g)
+{
+  if (g->l1_keys) return MCX_OK;
+  g->nsub = (uint32_t)(g->t.nslots >> kSubShift);
+  g->b1 = std::min<uint32_t>(g->nsub, 512);
+  g->subs_per_bin = (g->nsub + g->b1 - 1) / g->b1;
+  if (g->subs_per_bin > (uint32_t)kMaxBins) { g->b1 = 1024; g->subs_per_bin = (g->nsub + 1023) / 1024; }
+  if (g->subs_per_bin > (uint32_t)kMaxBins) { g->defer = false; return MCX_OK; }  // > 2^33 slots: direct path
+  g->b1 = (g->nsub + g->subs_per_bin - 1) / g->subs_per_bin;
+  uint64_t tcap = g->defer_tuples;
+  if (!tcap) {
+    const char *e = getenv("MCX_DEFER_TUPLES");
+    tcap = e ? strtoull(e, nullptr, 10) : std::min<uint64_t>(std::max<uint64_t>(4 * g->t.nslots, 1ull << 20), 1ull << 31);
   }
+  g->defer_tuples = tcap;
+  g->cap1 = g->b1 == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->b1 * 1.04) + 8192;
+  g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
+  const uint64_t n1 = (uint64_t)g->b1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
+#define DEFER_TRY(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess) {                                                                               \
+      free_defer(g);                                                                                      \
+      return fail(MCX_ERR_NOMEM, "deferred-insert workspace (%.1f GB): %s", (double)(n1 + n2) * (8 * g->W + 1) / 1e9, hipGetErrorString(_e)); \
+    }                                                                                                     \
+  } while (0)
+  DEFER_TRY(hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W));
+  DEFER_TRY(hipMalloc((void **)&g->l1_edges, n1));
+  DEFER_TRY(hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * 8));
+  DEFER_TRY(hipMalloc((void **)&g->l2_keys, n2 * 8 * g->W));
+  DEFER_TRY(hipMalloc((void **)&g->l2_edges, n2));
+  DEFER_TRY(hipMalloc((void **)&g->l2_cnt, (size_t)g->nsub * 8));
+  DEFER_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * 8, g->stream));
+  DEFER_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
+#undef DEFER_TRY
+  return MCX_OK;
+}
+
+// Split every L1 bin by sub-table, then let one workgroup per sub-table apply its tuples in LDS.
+static int flush_deferred(mcx_graph *g)
+{
+  if (!g->pending) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  TupleIn in{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1, g->b1};
+  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, g->subs_per_bin};
+  BinOut out{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
+  DISPATCH_WC(g, launch_bin_tuples_t, g, in, g->pending_colour, bs, out);
   HIP_TRY(hipGetLastError());
+  DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * 8, g->stream));
+  HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
+  g->pending = 0;
+  return MCX_OK;
+}
+
+// make room for `ub` more tuples of `colour` in the L1 bins
+static int defer_reserve(mcx_graph *g, int colour, uint64_t ub)
+{
+  int rc = ensure_defer(g);
+  if (rc != MCX_OK || !g->defer) return rc;
+  if (g->pending && (colour != g->pending_colour || g->pending + ub > g->defer_tuples)) {
+    rc = flush_deferred(g);
+    if (rc != MCX_OK) return rc;
+  }
+  g->pending_colour = colour;
+  return MCX_OK;
+}
+
+static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
+{
+  if (g->defer) { int rc = ensure_defer(g); if (rc != MCX_OK) return rc; }
+  if (!g->defer) {
+    DISPATCH_WC(g, launch_direct_t, g, L, colour);
+    HIP_TRY(hipGetLastError());
+    return MCX_OK;
+  }
+  // pieces of at most defer_tuples start positions (an upper bound of the tuples they yield)
+  for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
+    const uint64_t hi = std::min(L.pos_hi, lo + g->defer_tuples);
+    int rc = defer_reserve(g, colour, hi - lo);
+    if (rc != MCX_OK) return rc;
+    StreamLaunch P = L;
+    P.pos_lo = lo; P.pos_hi = hi;
+    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1};
+    BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
+    DISPATCH_WC(g, launch_bin_stream_t, g, P, colour, bs, out);
+    HIP_TRY(hipGetLastError());
+    g->pending += hi - lo;
+    lo = hi;
+  }
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value)
+{
+  if (!g || !key) return fail(MCX_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(g->device));
+  if (!strcmp(key, "defer")) {
+    int rc = flush_deferred(g);
+    if (rc != MCX_OK) return rc;
+    g->defer = value != 0;
+    return MCX_OK;
+  }
+  if (!strcmp(key, "defer_tuples")) {
+    int rc = flush_deferred(g);
+    if (rc != MCX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    free_defer(g);
+    g->defer_tuples = value;
+    return MCX_OK;
+  }
+  if (!strcmp(key, "profile")) {
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    g->spans.clear();
+    g->profile = value != 0;
+    return MCX_OK;
+  }
+  return fail(MCX_ERR_ARG, "unknown configuration key '%s'", key);
+}
+
+// Text report "kernel calls total_ms" per line of the spans recorded since profiling was enabled.
+extern "C" int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen)
+{
+  if (!g || !buf || !buflen) return fail(MCX_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  struct Acc { const char *name; int calls; double ms; };
+  std::vector<Acc> acc;
+  for (auto &sp : g->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+    bool found = false;
+    for (auto &a : acc) if (!strcmp(a.name, sp.name)) { a.calls++; a.ms += ms; found = true; }
+    if (!found) acc.push_back({sp.name, 1, ms});
+  }
+  size_t o = 0;
+  buf[0] = '\0';
+  for (auto &a : acc) {
+    int n = snprintf(buf + o, buflen - o, "%s %d %.4f\n", a.name, a.calls, a.ms);
+    if (n < 0 || (size_t)n >= buflen - o) break;
+    o += (size_t)n;
+  }
   return MCX_OK;
 }
 
@@ -241,25 +476,22 @@ extern "C" int mcx_graph_add_stream_dev(mcx_graph *g, int colour, const void *d_
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  return launch_insert_stream(g, L, colour);
+  return submit_stream(g, L, colour);
 }
 
 extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, int nparts,
                                               uint64_t bin_capacity, void *d_keys, void *d_edges, void *d_counts)
 {
   if (!g) return fail(MCX_ERR_ARG, "null graph");
-  if (nparts < 1 || nparts > kMaxParts) return fail(MCX_ERR_ARG, "nparts must be 1..%d", kMaxParts);
+  if (nparts < 1 || nparts > kMaxBins) return fail(MCX_ERR_ARG, "nparts must be 1..%d", kMaxBins);
   if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  if (g->W == 1) {
-    PartitionSink<1> ps{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity, (uint32_t)nparts};
-    launch_stream_t<1, true, 1>(g, L, 0, ps);
-  } else {
-    PartitionSink<2> ps{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity, (uint32_t)nparts};
-    launch_stream_t<2, true, 1>(g, L, 0, ps);
-  }
+  BinSpec bs{BIN_OWNER, (uint32_t)nparts, 1, (uint32_t)nparts};
+  BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity};
+  if (g->W == 1) launch_bin_stream_t<1, true>(g, L, 0, bs, out);
+  else launch_bin_stream_t<2, true>(g, L, 0, bs, out);
   HIP_TRY(hipGetLastError());
   return MCX_OK;
 }
@@ -270,25 +502,24 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
   if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (!n) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
-  const int grid = (int)std::min<uint64_t>((n + kThreads * kBatch - 1) / (kThreads * kBatch), (uint64_t)g->grid);
-  if (g->W == 1) {
-    if (g->ncols == 1) {
-      InsertSink<1, true> s{g->t, (uint32_t)colour};
-      hipLaunchKernelGGL((k_insert_tuples<1, true>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
-    } else {
-      InsertSink<1, false> s{g->t, (uint32_t)colour};
-      hipLaunchKernelGGL((k_insert_tuples<1, false>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
-    }
-  } else {
-    if (g->ncols == 1) {
-      InsertSink<2, true> s{g->t, (uint32_t)colour};
-      hipLaunchKernelGGL((k_insert_tuples<2, true>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
-    } else {
-      InsertSink<2, false> s{g->t, (uint32_t)colour};
-      hipLaunchKernelGGL((k_insert_tuples<2, false>), dim3(grid), dim3(kThreads), 0, g->stream, s, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n, g->d_ctr);
-    }
+  if (g->defer) { int rc = ensure_defer(g); if (rc != MCX_OK) return rc; }
+  if (!g->defer) {
+    DISPATCH_WC(g, launch_insert_tuples_t, g, colour, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n);
+    HIP_TRY(hipGetLastError());
+    return MCX_OK;
   }
-  HIP_TRY(hipGetLastError());
+  for (uint64_t lo = 0; lo < n;) {
+    const uint64_t cnt = std::min(n - lo, g->defer_tuples);
+    int rc = defer_reserve(g, colour, cnt);
+    if (rc != MCX_OK) return rc;
+    TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1};
+    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1};
+    BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
+    DISPATCH_WC(g, launch_bin_tuples_t, g, in, colour, bs, out);
+    HIP_TRY(hipGetLastError());
+    g->pending += cnt;
+    lo += cnt;
+  }
   return MCX_OK;
 }
 
@@ -396,7 +627,7 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
       HIP_TRY(hipMemcpyAsync(g->d_stage[b] + off_region, hoff, (nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
     StreamLaunch SL{g->d_stage[b], total, kCarry - (uint64_t)g->k, total - (uint64_t)g->k,
                     piece_of >= 0 ? d_flags + piece_of : nullptr};
-    rc = launch_insert_stream(g, SL, colour);
+    rc = submit_stream(g, SL, colour);
     if (rc != MCX_OK) return rc;
     if (nwhole) {
       hipLaunchKernelGGL(k_read_flags, dim3((unsigned)((nwhole + 255) / 256)), dim3(256), 0, g->stream,
@@ -451,7 +682,7 @@ static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const ui
                        (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, 1, d_sizes, (const uint64_t *)d_ooff, d_out);
     HIP_TRY(hipGetLastError());
     StreamLaunch SL{d_out, out_bytes, 0, out_bytes, nullptr};
-    rc = launch_insert_stream(g, SL, colour);
+    rc = submit_stream(g, SL, colour);
   }
   hipLaunchKernelGGL(k_count_sizes, dim3(256), dim3(256), 0, g->stream, (const uint64_t *)d_sizes, nreads, g->d_ctr);
   HIP_TRY(hipStreamSynchronize(g->stream));
@@ -466,6 +697,7 @@ static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const ui
 static int fetch_counters(mcx_graph *g)
 {
   HIP_TRY(hipSetDevice(g->device));
+  { int rc = flush_deferred(g); if (rc != MCX_OK) return rc; }
   HIP_TRY(hipMemcpyAsync(g->h_ctr, g->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
   if (g->h_ctr->full) return fail(MCX_ERR_FULL, "Hash table is full");

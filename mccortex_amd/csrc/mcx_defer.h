@@ -1,0 +1,409 @@
+// mcx_defer.h -- partition-then-insert path of the build ("deferred" mode) and the
+// owner partition of the sharded build.  Included by mcx_api.hip after mcx_kernels.h.
+//
+// Why: on MI355X every device atomic costs one 64-byte line request and the chip retires
+// ~17 G of them per second on a 16 GiB table (23.7 G/s even when the table sits in the
+// Infinity Cache) -- profiles/r01_ubench_atomics*.log.  The fused kernel already runs at that
+// ceiling, so the only way past it is to stop issuing one HBM atomic per k-mer occurrence:
+//
+//   1. k_stream_bin      k-merise reads, radix-partition the per-occurrence tuples
+//                        (key words + edge byte) by table region into L1 bins      (streaming)
+//   2. k_tuples_bin      split every L1 bin by sub-table (4096 slots) into L2 bins  (streaming)
+//   3. k_lds_insert      one workgroup per sub-table: slice -> LDS, apply its tuples with
+//                        LDS atomics (find-or-insert, coverage +1, edge OR), slice -> HBM
+//
+// All HBM traffic is coalesced streaming; tuples that do not fit a bin (hot k-mers, skew)
+// fall back to the lock-free direct insert of mcx_kernels.h, so no input can overflow.
+// The same binning kernels with BIN_OWNER produce the per-GPU bins of the sharded build.
+#pragma once
+#include "mcx_kernels.h"
+
+namespace mcx {
+
+enum : int { BIN_OWNER = 0, BIN_GROUP = 1, BIN_SUBLOCAL = 2 };
+
+struct BinSpec {
+  int mode;
+  uint32_t nparts;  // BIN_OWNER: number of owners
+  uint32_t div;     // BIN_GROUP: sub-tables per L1 bin; BIN_SUBLOCAL: sub-tables per input segment
+  uint32_t nlocal;  // bins a block can meet (size of the LDS histogram), <= kMaxBins
+};
+
+struct BinOut {
+  uint64_t *keys;              // [nbins][cap][W]
+  uint8_t *edges;              // [nbins][cap]
+  unsigned long long *counts;  // [nbins] fill (may exceed cap: the excess went to the fallback)
+  uint64_t cap;
+};
+
+constexpr int kMaxBins = 2048;
+
+__device__ __forceinline__ uint32_t sub_of(const TableView &t, uint32_t h)
+{
+  return (uint32_t)(bucket_slot(t, h) >> kSubShift);
+}
+
+// LDS working set of one binning block
+template <int W> struct BinLds {
+  uint32_t cnt[kMaxBins];
+  uint32_t off[kMaxBins + 1];
+  unsigned long long base[kMaxBins];
+  uint64_t skey[kTile * W];
+  uint16_t sbin[kTile];
+  uint8_t se[kTile];
+};
+
+// bin index inside the block's histogram, and output bin, of a tuple
+__device__ __forceinline__ void bin_of(const BinSpec &bs, const TableView &t, uint32_t h, uint32_t h2,
+                                       uint32_t seg, uint32_t &local, uint32_t &outbin)
+{
+  if (bs.mode == BIN_OWNER) {
+    local = outbin = owner_of(h2, bs.nparts);
+  } else {
+    const uint32_t sub = sub_of(t, h);
+    if (bs.mode == BIN_GROUP) { local = outbin = sub / bs.div; }
+    else { local = sub - seg * bs.div; outbin = sub; }
+  }
+}
+
+// After the counting sweep: exclusive scan of the histogram (wave 0) and one global
+// reservation per non-empty bin.  Leaves cnt[] zeroed for the placement sweep.
+template <int W>
+__device__ __forceinline__ void bin_reserve(BinLds<W> &L, const BinSpec &bs, const BinOut &out, uint32_t seg)
+{
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid < 64) {
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < bs.nlocal; b0 += 64) {
+      const uint32_t b = b0 + tid;
+      const uint32_t c = b < bs.nlocal ? L.cnt[b] : 0;
+      uint32_t x = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (tid >= d) x += y;
+      }
+      if (b < bs.nlocal) L.off[b] = carry + x - c;
+      carry += __shfl(x, 63, 64);
+    }
+    if (tid == 0) L.off[bs.nlocal] = carry;
+  }
+  __syncthreads();
+  for (uint32_t b = tid; b < bs.nlocal; b += kThreads) {
+    const uint32_t c = L.cnt[b];
+    const uint32_t ob = bs.mode == BIN_SUBLOCAL ? seg * bs.div + b : b;
+    L.base[b] = c ? atomicAdd(&out.counts[ob], (unsigned long long)c) : 0ULL;
+    L.cnt[b] = 0;
+  }
+  __syncthreads();
+}
+
+// Placement sweep: drop a tuple at its sorted position in the LDS staging area
+template <int W>
+__device__ __forceinline__ void bin_place(BinLds<W> &L, uint32_t local, const Kmer<W> &key, uint32_t e)
+{
+  const uint32_t p = L.off[local] + atomicAdd(&L.cnt[local], 1u);
+  L.skey[p * W] = key.w[0];
+  if (W == 2) L.skey[p * W + 1] = key.w[W - 1];
+  L.sbin[p] = (uint16_t)local;
+  L.se[p] = (uint8_t)e;
+}
+
+// Linear write-out: consecutive lanes write consecutive tuples of a bin.  Tuples beyond a
+// bin's capacity take the direct insert (deferred modes) or raise bin_over (owner mode).
+template <int W, bool ONECOL>
+__device__ __forceinline__ void bin_writeout(BinLds<W> &L, const BinSpec &bs, const BinOut &out, uint32_t seg,
+                                             const InsertSink<W, ONECOL> &isink, uint32_t &novel, uint32_t &full)
+{
+  __syncthreads();
+  const uint32_t n = L.off[bs.nlocal];
+  for (uint32_t p = threadIdx.x; p < n; p += kThreads) {
+    const uint32_t b = L.sbin[p];
+    const uint64_t gpos = L.base[b] + (p - L.off[b]);
+    const uint32_t ob = bs.mode == BIN_SUBLOCAL ? seg * bs.div + b : b;
+    if (gpos < out.cap) {
+      uint64_t *kd = out.keys + ((uint64_t)ob * out.cap + gpos) * W;
+      kd[0] = L.skey[p * W];
+      if (W == 2) kd[1] = L.skey[p * W + 1];
+      out.edges[(uint64_t)ob * out.cap + gpos] = L.se[p];
+    } else if (bs.mode == BIN_OWNER) {
+      full = 2;
+    } else {
+      Kmer<W> key;
+      key.w[0] = L.skey[p * W];
+      if (W == 2) key.w[W - 1] = L.skey[p * W + 1];
+      const uint32_t h = kmer_hash<W>(key, 0, nullptr);
+      const uint64_t slot = bucket_slot(isink.t, h);
+      const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
+      const uint64_t cur = isink.t.rec[slot * S];
+      probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, L.se[p], isink.col, novel, full);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 1. reads -> bins
+// ---------------------------------------------------------------------------
+template <int W, bool ONECOL>
+__global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
+                                                         InsertSink<W, ONECOL> isink)
+{
+  __shared__ uint32_t s_code[kChunks + 4];
+  __shared__ uint32_t s_inv[kChunks / 2 + 4];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  BinLds<W> &L = *reinterpret_cast<BinLds<W> *>(dyn_lds);
+
+  const int tid = threadIdx.x;
+  const int k = a.k;
+  uint32_t n_kmers = 0, n_contigs = 0, n_novel = 0, full = 0;
+  const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
+  const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);
+
+  for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();
+    const int64_t region0 = (int64_t)(tile * kTile) - 16;
+    for (int c = tid; c < kChunks; c += kThreads) {
+      uint32_t code, inv;
+      encode_chunk(a.stream, a.nbytes, region0 + 16 * (int64_t)c, code, inv);
+      s_code[c] = code;
+      reinterpret_cast<uint16_t *>(s_inv)[c ^ 1] = (uint16_t)inv;
+    }
+    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
+    if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
+    __syncthreads();
+
+    const uint32_t pl = 16u * (uint32_t)(tid + 1);
+    const uint64_t Vh = inv_win64(s_inv, pl);
+    const uint64_t Vl = (W == 2) ? inv_win64(s_inv, pl + 64) : 0;
+    const uint32_t prev_chunk_inv = (s_inv[(pl - 1) >> 5] >> (31 - ((pl - 1) & 31))) & 1u;
+    const uint64_t P0 = tile * kTile + 16ull * (uint64_t)tid;
+    const int j_lo = a.pos_lo > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_lo - P0) : 0;
+    const int j_hi = a.pos_hi > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_hi - P0) : 0;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kPosPerLane; j++) {
+      const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
+      any |= ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
+    }
+
+    // sweep 0 counts tuples per bin, sweep 1 recomputes them (cheaper than keeping 16 tuples
+    // per lane alive) and places them sorted by bin in LDS
+    for (int sweep = 0; sweep < 2; sweep++) {
+      if (any) {
+        Kmer<W> fw, rc;
+        if (W == 1) {
+          fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
+        } else {
+          const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
+          const int s = 128 - 2 * k;
+          fw.w[0] = hi >> s;
+          fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
+        }
+        rc = revcomp<W>(fw, k);
+        const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
+        uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
+#pragma unroll 1
+        for (int j = 0; j < kPosPerLane; j++) {
+          const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
+          const bool valid = ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
+          const bool next_ok = ((Th >> (63 - k)) & 1ULL) == 0;
+          const bool prev_ok = (j == 0) ? (prev_chunk_inv == 0) : (((Vh >> (64 - j)) & 1ULL) == 0);
+          const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
+          if (valid) {
+            uint32_t o, h2, local, ob;
+            const Kmer<W> key = canonical<W>(fw, rc, o);
+            const uint32_t h = kmer_hash<W>(key, 0, &h2);
+            bin_of(bs, isink.t, h, h2, 0, local, ob);
+            if (sweep == 0) {
+              atomicAdd(&L.cnt[local], 1u);
+              n_kmers++;
+              n_contigs += prev_ok ? 0u : 1u;
+            } else {
+              uint32_t e = 0;
+              if (next_ok) e |= 1u << (nuc_next + 4u * o);
+              if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
+              bin_place<W>(L, local, key, e);
+            }
+          }
+          prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
+          if (W == 1) {
+            fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
+            rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
+          } else {
+            fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
+            fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
+            rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
+            rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
+          }
+        }
+      }
+      if (sweep == 0) bin_reserve<W>(L, bs, out, 0);
+    }
+    bin_writeout<W, ONECOL>(L, bs, out, 0, isink, n_novel, full);
+  }
+
+  if (n_kmers) atomicAdd(&a.ctr->kmers, (unsigned long long)n_kmers);
+  if (n_contigs) atomicAdd(&a.ctr->contigs, (unsigned long long)n_contigs);
+  if (n_novel) atomicAdd(&a.ctr->novel, (unsigned long long)n_novel);
+  if (full == 1) a.ctr->full = 1;
+  if (full == 2) a.ctr->bin_over = 1;
+  if (a.flag && n_contigs) *a.flag = 1;
+}
+
+// ---------------------------------------------------------------------------
+// 2. tuples -> bins (L2 split of the L1 bins; L1 binning of tuples received from other GPUs)
+// ---------------------------------------------------------------------------
+struct TupleIn {
+  const uint64_t *keys;              // [nseg][seg_cap][W]
+  const uint8_t *edges;              // [nseg][seg_cap]
+  const unsigned long long *counts;  // [nseg] or nullptr (every segment holds seg_cap tuples)
+  uint64_t seg_cap;
+  uint32_t nseg;
+};
+
+template <int W, bool ONECOL>
+__global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
+                                                         InsertSink<W, ONECOL> isink, Counters *ctr)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  BinLds<W> &L = *reinterpret_cast<BinLds<W> *>(dyn_lds);
+  const int tid = threadIdx.x;
+  uint32_t n_novel = 0, full = 0;
+  const uint64_t chunks_per_seg = (in.seg_cap + kTile - 1) / kTile;
+  const uint64_t nchunks = chunks_per_seg * in.nseg;
+  for (uint64_t v = blockIdx.x; v < nchunks; v += gridDim.x) {
+    const uint32_t seg = (uint32_t)(v / chunks_per_seg);
+    const uint64_t start = (v % chunks_per_seg) * kTile;
+    uint64_t cnt = in.counts ? (uint64_t)in.counts[seg] : in.seg_cap;
+    if (cnt > in.seg_cap) cnt = in.seg_cap;
+    if (start >= cnt) continue;  // uniform across the block
+    const uint32_t n = (uint32_t)min((uint64_t)kTile, cnt - start);
+    __syncthreads();
+    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
+    __syncthreads();
+    const uint64_t *kin = in.keys + ((uint64_t)seg * in.seg_cap + start) * W;
+    const uint8_t *ein = in.edges + (uint64_t)seg * in.seg_cap + start;
+    for (int sweep = 0; sweep < 2; sweep++) {
+      for (uint32_t i = tid; i < n; i += kThreads) {
+        Kmer<W> key;
+        key.w[0] = kin[(uint64_t)i * W];
+        if (W == 2) key.w[W - 1] = kin[(uint64_t)i * W + 1];
+        uint32_t h2, local, ob;
+        const uint32_t h = kmer_hash<W>(key, 0, &h2);
+        bin_of(bs, isink.t, h, h2, seg, local, ob);
+        if (local >= bs.nlocal) local = bs.nlocal - 1;  // cannot happen for well-formed bins
+        if (sweep == 0) atomicAdd(&L.cnt[local], 1u);
+        else bin_place<W>(L, local, key, ein[i]);
+      }
+      if (sweep == 0) bin_reserve<W>(L, bs, out, seg);
+    }
+    bin_writeout<W, ONECOL>(L, bs, out, seg, isink, n_novel, full);
+  }
+  if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
+  if (full == 1) ctr->full = 1;
+  if (full == 2) ctr->bin_over = 1;
+}
+
+// ---------------------------------------------------------------------------
+// 3. LDS insert: one workgroup owns one sub-table
+// ---------------------------------------------------------------------------
+// The slice is held in LDS as kSubSlots x (W key words + this colour's value word); other
+// colours' value words stay untouched in HBM.  find-or-insert / coverage / edges are the same
+// protocol as probe_insert, with LDS atomics.
+template <int W, bool ONECOL>
+__global__ __launch_bounds__(kThreads) void k_lds_insert(TableView t, uint32_t col, BinOut bins, uint32_t nsub,
+                                                         Counters *ctr)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
+  constexpr int R = W + 1;  // words per slot in LDS
+  const int tid = threadIdx.x;
+  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : t.S;
+  uint32_t n_novel = 0, full = 0;
+
+  for (uint32_t sub = blockIdx.x; sub < nsub; sub += gridDim.x) {
+    uint64_t n = bins.counts[sub];
+    if (n == 0) continue;  // uniform
+    if (n > bins.cap) n = bins.cap;
+    uint64_t *slice = t.rec + (uint64_t)sub * kSubSlots * S;
+    __syncthreads();
+    if (W == 1 && ONECOL) {  // record == LDS slot: straight 16-byte copies
+      const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(slice);
+      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
+      for (uint32_t i = tid; i < kSubSlots; i += kThreads) dst[i] = src[i];
+    } else {
+      for (uint32_t i = tid; i < kSubSlots; i += kThreads) {
+        const uint64_t *r = slice + (uint64_t)i * S;
+        lds[i * R] = r[0];
+        if (W == 2) lds[i * R + 1] = r[1];
+        lds[i * R + W] = r[W + col];
+      }
+    }
+    __syncthreads();
+
+    const uint64_t *kin = bins.keys + (uint64_t)sub * bins.cap * W;
+    const uint8_t *ein = bins.edges + (uint64_t)sub * bins.cap;
+    for (uint64_t i = tid; i < n; i += kThreads) {
+      Kmer<W> key;
+      key.w[0] = kin[i * W];
+      if (W == 2) key.w[W - 1] = kin[i * W + 1];
+      const uint32_t e = ein[i];
+      const uint32_t h = kmer_hash<W>(key, 0, nullptr);
+      uint32_t slot = (uint32_t)(bucket_slot(t, h) & (kSubSlots - 1));
+      const unsigned long long want = key.w[0] | kFlag;
+      uint32_t probes = 0;
+      for (;;) {
+        unsigned long long *r = lds + slot * R;
+        unsigned long long cur = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == 0) {
+          const unsigned long long desired = (W == 1) ? want : (want | kPending);
+          cur = atomicCAS(r, 0ULL, desired);
+          if (cur == 0) {
+            if (W == 2) {
+              __hip_atomic_store(r + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(r, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            n_novel++;
+            atomicAdd(r + W, 256ULL);
+            if (e) atomicOr(r + W, (unsigned long long)e);
+            break;
+          }
+        }
+        if ((cur & ~kPending) == want) {
+          bool match = true;
+          if (W == 2) {
+            if (cur & kPending) { if (++probes > (1u << 22)) { full = 1; break; } continue; }
+            match = __hip_atomic_load(r + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1];
+          }
+          if (match) {
+            atomicAdd(r + W, 256ULL);
+            if (e & ~(uint32_t)__hip_atomic_load(r + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+              atomicOr(r + W, (unsigned long long)e);
+            break;
+          }
+        }
+        if (++probes > kSubSlots) { full = 1; break; }
+        slot = (slot + 1) & (uint32_t)(kSubSlots - 1);
+      }
+    }
+    __syncthreads();
+
+    if (W == 1 && ONECOL) {
+      const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(lds);
+      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(slice);
+      for (uint32_t i = tid; i < kSubSlots; i += kThreads) dst[i] = src[i];
+    } else {
+      for (uint32_t i = tid; i < kSubSlots; i += kThreads) {
+        uint64_t *r = slice + (uint64_t)i * S;
+        r[0] = lds[i * R];
+        if (W == 2) r[1] = lds[i * R + 1];
+        r[W + col] = lds[i * R + W];
+      }
+    }
+  }
+  if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
+  if (full) ctr->full = 1;
+}
+
+}  // namespace mcx

@@ -26,10 +26,15 @@ namespace mcx {
 // and edges of a node share one 64-byte sector, so an occurrence costs one
 // random sector instead of the reference's three arrays.
 constexpr int kBucket = 4;  // slots per hash bucket (64 B when S == 2)
+// The table is an array of independent sub-tables of kSubSlots slots: a key's probe sequence
+// starts at its hash bucket and wraps inside its sub-table, so one sub-table (64 KiB at S == 2)
+// can be staged in LDS and owned by a single workgroup (mcx_defer.h).
+constexpr int kSubShift = 12;
+constexpr uint64_t kSubSlots = 1ull << kSubShift;
 
 struct TableView {
   uint64_t *rec;
-  uint64_t nslots;    // multiple of kBucket
+  uint64_t nslots;    // multiple of kSubSlots
   uint32_t nbuckets;  // nslots / kBucket
   uint32_t S;         // words per record
   uint32_t max_probe;
@@ -124,7 +129,7 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
     }
     if (++probes > t.max_probe) { full = 1; return; }
     slot++;
-    if (slot == t.nslots) slot = 0;
+    if ((slot & (kSubSlots - 1)) == 0) slot -= kSubSlots;  // wrap inside the sub-table
   }
 }
 
@@ -246,31 +251,18 @@ __device__ __forceinline__ void flush_batch(const InsertSink<W, ONECOL> &sink, c
     if (ov[i]) probe_insert<W, ONECOL>(sink.t, occ[i].key, slot[i], cur[i], hint[i], occ[i].e, sink.col, novel, full);
 }
 
-// Partition sink (sharded build): tuples are appended to per-owner bins.
-template <int W> struct PartitionSink {
-  uint64_t *keys;   // [nparts][bin_cap][W]
-  uint8_t *edges;   // [nparts][bin_cap]
-  unsigned long long *counts;  // [nparts]
-  uint64_t bin_cap;
-  uint32_t nparts;
-};
-
-constexpr int kMaxParts = 64;
-
 __device__ __forceinline__ uint32_t owner_of(uint32_t h2, uint32_t nparts)
 {
   return (uint32_t)(((uint64_t)h2 * nparts) >> 32);
 }
 
-// The shared front end.  MODE 0: insert, MODE 1: partition.
-template <int W, bool ONECOL, int MODE>
-__global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink,
-                                                     PartitionSink<W> psink)
+// Fused build kernel: k-merise a stream tile by tile and insert straight into the table
+// (direct path; the deferred path of mcx_defer.h shares the front end helpers).
+template <int W, bool ONECOL>
+__global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink)
 {
   __shared__ uint32_t s_code[kChunks + 4];
   __shared__ uint32_t s_inv[kChunks / 2 + 4];
-  __shared__ unsigned long long s_base[kMaxParts];
-  __shared__ uint32_t s_cnt[kMaxParts];
 
   const int tid = threadIdx.x;
   const int k = a.k;
@@ -288,7 +280,6 @@ __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a
       s_code[c] = code;
       reinterpret_cast<uint16_t *>(s_inv)[c ^ 1] = (uint16_t)inv;
     }
-    if (MODE == 1 && tid < kMaxParts) s_cnt[tid] = 0;
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     __syncthreads();
 
@@ -313,7 +304,7 @@ __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a
     Occ<W> occ[kBatch];
     bool ov[kBatch];
     // (all indices into occ/ov are compile-time constants after unrolling: no scratch)
-    if (MODE == 0) {
+    {
       if (any) {
         Kmer<W> fw, rc;
         if (W == 1) {
@@ -361,77 +352,6 @@ __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a
           }
         }
       }
-    } else {
-      // ---- partition mode: sweep 1 counts tuples per owner in LDS, one global
-      // atomic per owner per tile reserves space, sweep 2 recomputes and writes.
-      for (int sweep = 0; sweep < 2; sweep++) {
-        if (any) {
-          Kmer<W> fw, rc;
-          if (W == 1) {
-            fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
-          } else {
-            const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
-            const int s = 128 - 2 * k;
-            fw.w[0] = hi >> s;
-            fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
-          }
-          rc = revcomp<W>(fw, k);
-          const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
-          uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
-#pragma unroll 1
-          for (int j = 0; j < kPosPerLane; j++) {
-            const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
-            const bool valid = ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
-            const bool next_ok = ((Th >> (63 - k)) & 1ULL) == 0;
-            const bool prev_ok = (j == 0) ? (prev_chunk_inv == 0) : (((Vh >> (64 - j)) & 1ULL) == 0);
-            const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
-            if (valid) {
-              uint32_t o, h2;
-              const Kmer<W> key = canonical<W>(fw, rc, o);
-              kmer_hash<W>(key, 0, &h2);
-              const uint32_t dst = owner_of(h2, psink.nparts);
-              if (sweep == 0) {
-                atomicAdd(&s_cnt[dst], 1u);
-                n_kmers++;
-                n_contigs += prev_ok ? 0u : 1u;
-              } else {
-                uint32_t e = 0;
-                if (next_ok) e |= 1u << (nuc_next + 4u * o);
-                if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
-                const uint32_t off = atomicAdd(&s_cnt[dst], 1u);
-                const unsigned long long pos = s_base[dst] + off;
-                if (pos < psink.bin_cap) {
-                  uint64_t *kd = psink.keys + ((uint64_t)dst * psink.bin_cap + pos) * W;
-                  kd[0] = key.w[0];
-                  if (W == 2) kd[W - 1] = key.w[W - 1];
-                  psink.edges[(uint64_t)dst * psink.bin_cap + pos] = (uint8_t)e;
-                } else {
-                  full = 2;
-                }
-              }
-            }
-            prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
-            if (W == 1) {
-              fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
-              rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
-            } else {
-              fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
-              fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
-              rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
-              rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
-            }
-          }
-        }
-        if (sweep == 0) {
-          __syncthreads();
-          if (tid < (int)psink.nparts) {
-            const uint32_t c = s_cnt[tid];
-            s_base[tid] = c ? atomicAdd(&psink.counts[tid], (unsigned long long)c) : 0ULL;
-            s_cnt[tid] = 0;
-          }
-          __syncthreads();
-        }
-      }
     }
   }
 
@@ -441,7 +361,6 @@ __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a
   if (n_contigs) atomicAdd(&a.ctr->contigs, (unsigned long long)n_contigs);
   if (n_novel) atomicAdd(&a.ctr->novel, (unsigned long long)n_novel);
   if (full == 1) a.ctr->full = 1;
-  if (full == 2) a.ctr->bin_over = 1;
   if (a.flag && n_contigs) *a.flag = 1;
 }
 

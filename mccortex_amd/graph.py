@@ -12,7 +12,7 @@ _LIB = None
 
 SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create", "mcx_graph_destroy",
-    "mcx_graph_reset", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
+    "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
     "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash",
@@ -63,6 +63,8 @@ def lib():
     L.mcx_graph_destroy.restype = None
     L.mcx_graph_reset.argtypes = [vp]
     L.mcx_graph_capacity.argtypes = [vp, u64p, u64p]
+    L.mcx_graph_configure.argtypes = [vp, C.c_char_p, C.c_uint64]
+    L.mcx_graph_profile.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.mcx_graph_add_reads.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint64, C.c_uint8, C.c_uint8,
                                       C.POINTER(LoadStats)]
     L.mcx_graph_add_stream_dev.argtypes = [vp, C.c_int, vp, C.c_uint64]
@@ -158,6 +160,19 @@ class Graph:
 
     def reset(self):
         _check(self.L.mcx_graph_reset(self.h))
+
+    def configure(self, key, value):
+        _check(self.L.mcx_graph_configure(self.h, key.encode(), int(value)))
+
+    def profile(self):
+        """{kernel: (calls, total_ms)} for launches recorded since configure('profile', 1)."""
+        buf = C.create_string_buffer(4096)
+        _check(self.L.mcx_graph_profile(self.h, buf, 4096))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.split()
+            out[name] = (int(calls), float(ms))
+        return out
 
     def capacity(self):
         s, b = C.c_uint64(), C.c_uint64()

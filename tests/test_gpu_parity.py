@@ -182,3 +182,44 @@ def test_config1_100k_x_100bp(mcx, orc):
     bases, offs = synth.reads(100_000, 100, seed=42, g=g)
     og = _compare(mcx, orc, 31, 1, [(0, bases, offs)], cap=4 << 20, names=["sample0"])
     assert og.nkmers > 1_000_000
+
+
+@pytest.mark.parametrize("k,ncols", [(31, 1), (31, 3), (63, 1), (45, 2)])
+def test_direct_and_deferred_paths_agree(mcx, orc, k, ncols):
+    """The two insert strategies (HBM atomics vs partition + LDS insert) build the same graph,
+    including multiple flushes, bin overflow -> direct-insert fallback (tiny bins, hot keys) and
+    colour switches."""
+    g0 = synth.genome(30000, 9)
+    jobs = []
+    for c in range(ncols):
+        b, o = synth.reads(4000, 120, seed=50 + c, g=g0, n_frac=0.05, lower_frac=0.05)
+        jobs.append((c, b, o))
+    hb, ho = orc.pack_reads(["A" * 150] * 800 + ["ACGT" * 40] * 500)
+    jobs.append((0, hb, ho))
+    og, _ = _oracle(orc, k, ncols, jobs)
+    want = og.ctx_bytes(True)[og.header_size():]
+    for cfg in [{"defer": 0}, {"defer": 1}, {"defer": 1, "defer_tuples": 20000}, {"defer": 1, "defer_tuples": 300000}]:
+        g = mcx.Graph(k, ncols, 1 << 20)
+        for key, v in cfg.items():
+            g.configure(key, v)
+        for col, b, o in jobs:
+            g.add_reads(col, b, o)
+        assert g.nkmers == og.nkmers, cfg
+        assert g.export(True) == want, cfg
+        st = g.device_stats()
+        assert st.num_kmers_novel == og.nkmers
+        g.close()
+
+
+def test_deferred_large_table_many_subtables(mcx, orc):
+    """Enough slots for several L1 bins (nsub > 512) so both partition levels are exercised."""
+    bases, offs = synth.reads(60000, 150, genome_len=400000, seed=21)
+    og, _ = _oracle(orc, 31, 1, [(0, bases, offs)], cap=1 << 22)
+    want = og.ctx_bytes(True)[og.header_size():]
+    g = mcx.Graph(31, 1, 3 << 20)  # 768 sub-tables -> 2 L1 bins of 384... plus ragged tail
+    g.configure("profile", 1)
+    g.add_reads(0, bases, offs)
+    assert g.export(True) == want
+    prof = g.profile()
+    assert "k_stream_bin" in prof and "k_tuples_bin" in prof and "k_lds_insert" in prof
+    g.close()
