@@ -273,10 +273,17 @@ static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour,
   if (!nt) return;
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
   static bool once = false;
-  if (!once) { allow_lds(k_stream_bin<W, ONECOL>, sizeof(BinLds<W>)); once = true; }
+  if (!once) {
+    allow_lds(k_stream_bin<W, ONECOL, 512>, sizeof(BinLds<W, 512>));
+    allow_lds(k_stream_bin<W, ONECOL, kMaxBins>, sizeof(BinLds<W, kMaxBins>));
+    once = true;
+  }
   SpanGuard sp(g, "k_stream_bin");
-  hipLaunchKernelGGL((k_stream_bin<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid)), dim3(kThreads),
-                     sizeof(BinLds<W>), g->stream, a, bs, out, is);
+  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
+  if (bs.nlocal <= 512)
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512>), grid, dim3(kThreads), sizeof(BinLds<W, 512>), g->stream, a, bs, out, is);
+  else
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins>), g->stream, a, bs, out, is);
 }
 
 template <int W, bool ONECOL>
@@ -286,10 +293,17 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   if (!nchunks) return;
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
   static bool once = false;
-  if (!once) { allow_lds(k_tuples_bin<W, ONECOL>, sizeof(BinLds<W>)); once = true; }
+  if (!once) {
+    allow_lds(k_tuples_bin<W, ONECOL, 512>, sizeof(BinLds<W, 512>));
+    allow_lds(k_tuples_bin<W, ONECOL, kMaxBins>, sizeof(BinLds<W, kMaxBins>));
+    once = true;
+  }
   SpanGuard sp(g, "k_tuples_bin");
-  hipLaunchKernelGGL((k_tuples_bin<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nchunks, (uint64_t)g->grid * 4)),
-                     dim3(kThreads), sizeof(BinLds<W>), g->stream, in, bs, out, is, g->d_ctr);
+  const dim3 grid((unsigned)std::min<uint64_t>(nchunks, (uint64_t)g->grid * 4));
+  if (bs.nlocal <= 512)
+    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512>), grid, dim3(kThreads), sizeof(BinLds<W, 512>), g->stream, in, bs, out, is, g->d_ctr);
+  else
+    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, kMaxBins>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins>), g->stream, in, bs, out, is, g->d_ctr);
 }
 
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour)
@@ -300,7 +314,7 @@ template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int 
   BinOut bins{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
   SpanGuard sp(g, "k_lds_insert");
   hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(g->nsub, (uint64_t)g->grid * 4)),
-                     dim3(kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
+                     dim3(kLdsThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
 }
 
 template <int W, bool ONECOL>
@@ -338,6 +352,7 @@ static int ensure_defer(mcx_graph *g)
   g->defer_tuples = tcap;
   g->cap1 = g->b1 == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->b1 * 1.04) + 8192;
   g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
+  if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "defer_tuples too large for this table");
   const uint64_t n1 = (uint64_t)g->b1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
 #define DEFER_TRY(expr)                                                                                   \
   do {                                                                                                    \
@@ -484,6 +499,7 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
 {
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (nparts < 1 || nparts > kMaxBins) return fail(MCX_ERR_ARG, "nparts must be 1..%d", kMaxBins);
+  if (bin_capacity >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "bin capacity must be below 2^32 tuples");
   if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));

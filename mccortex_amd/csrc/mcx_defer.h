@@ -43,12 +43,12 @@ __device__ __forceinline__ uint32_t sub_of(const TableView &t, uint32_t h)
   return (uint32_t)(bucket_slot(t, h) >> kSubShift);
 }
 
-// LDS working set of one binning block
-template <int W> struct BinLds {
-  uint32_t cnt[kMaxBins];
-  uint32_t off[kMaxBins + 1];
-  unsigned long long base[kMaxBins];
+// LDS working set of one binning block (NB = histogram capacity: 512 keeps three blocks per CU)
+template <int W, int NB> struct BinLds {
   uint64_t skey[kTile * W];
+  uint32_t cnt[NB];
+  uint32_t off[NB + 4];
+  uint32_t base[NB];  // bin capacities are < 2^32 tuples (checked by the host)
   uint16_t sbin[kTile];
   uint8_t se[kTile];
 };
@@ -68,8 +68,8 @@ __device__ __forceinline__ void bin_of(const BinSpec &bs, const TableView &t, ui
 
 // After the counting sweep: exclusive scan of the histogram (wave 0) and one global
 // reservation per non-empty bin.  Leaves cnt[] zeroed for the placement sweep.
-template <int W>
-__device__ __forceinline__ void bin_reserve(BinLds<W> &L, const BinSpec &bs, const BinOut &out, uint32_t seg)
+template <int W, int NB>
+__device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs, const BinOut &out, uint32_t seg)
 {
   const int tid = threadIdx.x;
   __syncthreads();
@@ -93,15 +93,16 @@ __device__ __forceinline__ void bin_reserve(BinLds<W> &L, const BinSpec &bs, con
   for (uint32_t b = tid; b < bs.nlocal; b += kThreads) {
     const uint32_t c = L.cnt[b];
     const uint32_t ob = bs.mode == BIN_SUBLOCAL ? seg * bs.div + b : b;
-    L.base[b] = c ? atomicAdd(&out.counts[ob], (unsigned long long)c) : 0ULL;
+    unsigned long long g0 = c ? atomicAdd(&out.counts[ob], (unsigned long long)c) : 0ULL;
+    L.base[b] = g0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g0;  // saturated == beyond any capacity
     L.cnt[b] = 0;
   }
   __syncthreads();
 }
 
 // Placement sweep: drop a tuple at its sorted position in the LDS staging area
-template <int W>
-__device__ __forceinline__ void bin_place(BinLds<W> &L, uint32_t local, const Kmer<W> &key, uint32_t e)
+template <int W, int NB>
+__device__ __forceinline__ void bin_place(BinLds<W, NB> &L, uint32_t local, const Kmer<W> &key, uint32_t e)
 {
   const uint32_t p = L.off[local] + atomicAdd(&L.cnt[local], 1u);
   L.skey[p * W] = key.w[0];
@@ -112,15 +113,15 @@ __device__ __forceinline__ void bin_place(BinLds<W> &L, uint32_t local, const Km
 
 // Linear write-out: consecutive lanes write consecutive tuples of a bin.  Tuples beyond a
 // bin's capacity take the direct insert (deferred modes) or raise bin_over (owner mode).
-template <int W, bool ONECOL>
-__device__ __forceinline__ void bin_writeout(BinLds<W> &L, const BinSpec &bs, const BinOut &out, uint32_t seg,
+template <int W, bool ONECOL, int NB>
+__device__ __forceinline__ void bin_writeout(BinLds<W, NB> &L, const BinSpec &bs, const BinOut &out, uint32_t seg,
                                              const InsertSink<W, ONECOL> &isink, uint32_t &novel, uint32_t &full)
 {
   __syncthreads();
   const uint32_t n = L.off[bs.nlocal];
   for (uint32_t p = threadIdx.x; p < n; p += kThreads) {
     const uint32_t b = L.sbin[p];
-    const uint64_t gpos = L.base[b] + (p - L.off[b]);
+    const uint64_t gpos = (uint64_t)L.base[b] + (p - L.off[b]);
     const uint32_t ob = bs.mode == BIN_SUBLOCAL ? seg * bs.div + b : b;
     if (gpos < out.cap) {
       uint64_t *kd = out.keys + ((uint64_t)ob * out.cap + gpos) * W;
@@ -145,14 +146,14 @@ __device__ __forceinline__ void bin_writeout(BinLds<W> &L, const BinSpec &bs, co
 // ---------------------------------------------------------------------------
 // 1. reads -> bins
 // ---------------------------------------------------------------------------
-template <int W, bool ONECOL>
+template <int W, bool ONECOL, int NB>
 __global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
                                                          InsertSink<W, ONECOL> isink)
 {
   __shared__ uint32_t s_code[kChunks + 4];
   __shared__ uint32_t s_inv[kChunks / 2 + 4];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  BinLds<W> &L = *reinterpret_cast<BinLds<W> *>(dyn_lds);
+  BinLds<W, NB> &L = *reinterpret_cast<BinLds<W, NB> *>(dyn_lds);
 
   const int tid = threadIdx.x;
   const int k = a.k;
@@ -187,60 +188,64 @@ __global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec b
       any |= ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
     }
 
-    // sweep 0 counts tuples per bin, sweep 1 recomputes them (cheaper than keeping 16 tuples
-    // per lane alive) and places them sorted by bin in LDS
-    for (int sweep = 0; sweep < 2; sweep++) {
-      if (any) {
-        Kmer<W> fw, rc;
-        if (W == 1) {
-          fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
-        } else {
-          const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
-          const int s = 128 - 2 * k;
-          fw.w[0] = hi >> s;
-          fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
+    // One pass over the lane's 16 positions: the tuples stay in registers (static indices
+    // after unrolling) while the block histograms, reserves and then places them.
+    Kmer<W> tk[kPosPerLane];
+    uint32_t tle[kPosPerLane];  // local bin << 8 | edge byte
+    uint32_t vmask = 0;
+    if (any) {
+      Kmer<W> fw, rc;
+      if (W == 1) {
+        fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
+      } else {
+        const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
+        const int s = 128 - 2 * k;
+        fw.w[0] = hi >> s;
+        fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
+      }
+      rc = revcomp<W>(fw, k);
+      const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
+      uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
+#pragma unroll
+      for (int j = 0; j < kPosPerLane; j++) {
+        const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
+        const bool valid = ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
+        const bool next_ok = ((Th >> (63 - k)) & 1ULL) == 0;
+        const bool prev_ok = (j == 0) ? (prev_chunk_inv == 0) : (((Vh >> (64 - j)) & 1ULL) == 0);
+        const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
+        tle[j] = 0;
+        tk[j] = fw;
+        if (valid) {
+          uint32_t o, h2, local, ob;
+          tk[j] = canonical<W>(fw, rc, o);
+          const uint32_t h = kmer_hash<W>(tk[j], 0, &h2);
+          bin_of(bs, isink.t, h, h2, 0, local, ob);
+          uint32_t e = 0;
+          if (next_ok) e |= 1u << (nuc_next + 4u * o);
+          if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
+          tle[j] = (local << 8) | e;
+          vmask |= 1u << j;
+          atomicAdd(&L.cnt[local], 1u);
+          n_kmers++;
+          n_contigs += prev_ok ? 0u : 1u;
         }
-        rc = revcomp<W>(fw, k);
-        const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
-        uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
-#pragma unroll 1
-        for (int j = 0; j < kPosPerLane; j++) {
-          const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
-          const bool valid = ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
-          const bool next_ok = ((Th >> (63 - k)) & 1ULL) == 0;
-          const bool prev_ok = (j == 0) ? (prev_chunk_inv == 0) : (((Vh >> (64 - j)) & 1ULL) == 0);
-          const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
-          if (valid) {
-            uint32_t o, h2, local, ob;
-            const Kmer<W> key = canonical<W>(fw, rc, o);
-            const uint32_t h = kmer_hash<W>(key, 0, &h2);
-            bin_of(bs, isink.t, h, h2, 0, local, ob);
-            if (sweep == 0) {
-              atomicAdd(&L.cnt[local], 1u);
-              n_kmers++;
-              n_contigs += prev_ok ? 0u : 1u;
-            } else {
-              uint32_t e = 0;
-              if (next_ok) e |= 1u << (nuc_next + 4u * o);
-              if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
-              bin_place<W>(L, local, key, e);
-            }
-          }
-          prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
-          if (W == 1) {
-            fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
-            rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
-          } else {
-            fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
-            fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
-            rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
-            rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
-          }
+        prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
+        if (W == 1) {
+          fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
+          rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
+        } else {
+          fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
+          fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
+          rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
+          rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
         }
       }
-      if (sweep == 0) bin_reserve<W>(L, bs, out, 0);
     }
-    bin_writeout<W, ONECOL>(L, bs, out, 0, isink, n_novel, full);
+    bin_reserve<W, NB>(L, bs, out, 0);
+#pragma unroll
+    for (int j = 0; j < kPosPerLane; j++)
+      if (vmask & (1u << j)) bin_place<W, NB>(L, tle[j] >> 8, tk[j], tle[j] & 0xffu);
+    bin_writeout<W, ONECOL, NB>(L, bs, out, 0, isink, n_novel, full);
   }
 
   if (n_kmers) atomicAdd(&a.ctr->kmers, (unsigned long long)n_kmers);
@@ -262,12 +267,12 @@ struct TupleIn {
   uint32_t nseg;
 };
 
-template <int W, bool ONECOL>
+template <int W, bool ONECOL, int NB>
 __global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
                                                          InsertSink<W, ONECOL> isink, Counters *ctr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  BinLds<W> &L = *reinterpret_cast<BinLds<W> *>(dyn_lds);
+  BinLds<W, NB> &L = *reinterpret_cast<BinLds<W, NB> *>(dyn_lds);
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
   const uint64_t chunks_per_seg = (in.seg_cap + kTile - 1) / kTile;
@@ -284,21 +289,38 @@ __global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs,
     __syncthreads();
     const uint64_t *kin = in.keys + ((uint64_t)seg * in.seg_cap + start) * W;
     const uint8_t *ein = in.edges + (uint64_t)seg * in.seg_cap + start;
-    for (int sweep = 0; sweep < 2; sweep++) {
-      for (uint32_t i = tid; i < n; i += kThreads) {
-        Kmer<W> key;
-        key.w[0] = kin[(uint64_t)i * W];
-        if (W == 2) key.w[W - 1] = kin[(uint64_t)i * W + 1];
-        uint32_t h2, local, ob;
-        const uint32_t h = kmer_hash<W>(key, 0, &h2);
-        bin_of(bs, isink.t, h, h2, seg, local, ob);
-        if (local >= bs.nlocal) local = bs.nlocal - 1;  // cannot happen for well-formed bins
-        if (sweep == 0) atomicAdd(&L.cnt[local], 1u);
-        else bin_place<W>(L, local, key, ein[i]);
+    // each lane keeps its kTile/kThreads tuples in registers: all loads are issued up front
+    // (memory-level parallelism) and the placement sweep does not re-read HBM
+    constexpr int PER = kTile / kThreads;
+    Kmer<W> key[PER];
+    uint32_t ev[PER], loc[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const uint32_t i = (uint32_t)q * kThreads + tid;
+      key[q].w[0] = 0; if (W == 2) key[q].w[W - 1] = 0;
+      ev[q] = 0;
+      if (i < n) {
+        key[q].w[0] = kin[(uint64_t)i * W];
+        if (W == 2) key[q].w[W - 1] = kin[(uint64_t)i * W + 1];
+        ev[q] = ein[i];
       }
-      if (sweep == 0) bin_reserve<W>(L, bs, out, seg);
     }
-    bin_writeout<W, ONECOL>(L, bs, out, seg, isink, n_novel, full);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const uint32_t i = (uint32_t)q * kThreads + tid;
+      uint32_t h2, ob;
+      const uint32_t h = kmer_hash<W>(key[q], 0, &h2);
+      bin_of(bs, isink.t, h, h2, seg, loc[q], ob);
+      if (loc[q] >= bs.nlocal) loc[q] = bs.nlocal - 1;  // cannot happen for well-formed bins
+      if (i < n) atomicAdd(&L.cnt[loc[q]], 1u);
+    }
+    bin_reserve<W, NB>(L, bs, out, seg);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const uint32_t i = (uint32_t)q * kThreads + tid;
+      if (i < n) bin_place<W, NB>(L, loc[q], key[q], ev[q]);
+    }
+    bin_writeout<W, ONECOL, NB>(L, bs, out, seg, isink, n_novel, full);
   }
   if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
   if (full == 1) ctr->full = 1;
@@ -311,9 +333,57 @@ __global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs,
 // The slice is held in LDS as kSubSlots x (W key words + this colour's value word); other
 // colours' value words stay untouched in HBM.  find-or-insert / coverage / edges are the same
 // protocol as probe_insert, with LDS atomics.
+constexpr int kLdsThreads = 512;
+constexpr int kLdsBatch = 4;
+
+// find-or-insert one tuple in the LDS-resident sub-table
+template <int W>
+__device__ __forceinline__ void lds_apply(unsigned long long *lds, const TableView &t, const Kmer<W> &key, uint32_t e,
+                                          uint32_t &n_novel, uint32_t &full)
+{
+  constexpr int R = W + 1;
+  const uint32_t h = kmer_hash<W>(key, 0, nullptr);
+  uint32_t slot = (uint32_t)(bucket_slot(t, h) & (kSubSlots - 1));
+  const unsigned long long want = key.w[0] | kFlag;
+  uint32_t probes = 0;
+  for (;;) {
+    unsigned long long *r = lds + slot * R;
+    unsigned long long cur = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cur == 0) {
+      const unsigned long long desired = (W == 1) ? want : (want | kPending);
+      cur = atomicCAS(r, 0ULL, desired);
+      if (cur == 0) {
+        if (W == 2) {
+          __hip_atomic_store(r + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(r, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        n_novel++;
+        atomicAdd(r + W, 256ULL);
+        if (e) atomicOr(r + W, (unsigned long long)e);
+        return;
+      }
+    }
+    if ((cur & ~kPending) == want) {
+      bool match = true;
+      if (W == 2) {
+        if (cur & kPending) { if (++probes > (1u << 22)) { full = 1; return; } continue; }
+        match = __hip_atomic_load(r + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1];
+      }
+      if (match) {
+        atomicAdd(r + W, 256ULL);
+        if (e & ~(uint32_t)__hip_atomic_load(r + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+          atomicOr(r + W, (unsigned long long)e);
+        return;
+      }
+    }
+    if (++probes > kSubSlots) { full = 1; return; }
+    slot = (slot + 1) & (uint32_t)(kSubSlots - 1);
+  }
+}
+
 template <int W, bool ONECOL>
-__global__ __launch_bounds__(kThreads) void k_lds_insert(TableView t, uint32_t col, BinOut bins, uint32_t nsub,
-                                                         Counters *ctr)
+__global__ __launch_bounds__(kLdsThreads) void k_lds_insert(TableView t, uint32_t col, BinOut bins, uint32_t nsub,
+                                                            Counters *ctr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
@@ -328,12 +398,18 @@ __global__ __launch_bounds__(kThreads) void k_lds_insert(TableView t, uint32_t c
     if (n > bins.cap) n = bins.cap;
     uint64_t *slice = t.rec + (uint64_t)sub * kSubSlots * S;
     __syncthreads();
-    if (W == 1 && ONECOL) {  // record == LDS slot: straight 16-byte copies
+    constexpr int PER = (int)(kSubSlots / kLdsThreads);
+    if (W == 1 && ONECOL) {  // record == LDS slot: straight 16-byte copies, all loads in flight
       const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(slice);
       ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
-      for (uint32_t i = tid; i < kSubSlots; i += kThreads) dst[i] = src[i];
+      ulonglong2 v[PER];
+#pragma unroll
+      for (int q = 0; q < PER; q++) v[q] = src[q * kLdsThreads + tid];
+#pragma unroll
+      for (int q = 0; q < PER; q++) dst[q * kLdsThreads + tid] = v[q];
     } else {
-      for (uint32_t i = tid; i < kSubSlots; i += kThreads) {
+#pragma unroll 4
+      for (uint32_t i = tid; i < kSubSlots; i += kLdsThreads) {
         const uint64_t *r = slice + (uint64_t)i * S;
         lds[i * R] = r[0];
         if (W == 2) lds[i * R + 1] = r[1];
@@ -344,57 +420,32 @@ __global__ __launch_bounds__(kThreads) void k_lds_insert(TableView t, uint32_t c
 
     const uint64_t *kin = bins.keys + (uint64_t)sub * bins.cap * W;
     const uint8_t *ein = bins.edges + (uint64_t)sub * bins.cap;
-    for (uint64_t i = tid; i < n; i += kThreads) {
-      Kmer<W> key;
-      key.w[0] = kin[i * W];
-      if (W == 2) key.w[W - 1] = kin[i * W + 1];
-      const uint32_t e = ein[i];
-      const uint32_t h = kmer_hash<W>(key, 0, nullptr);
-      uint32_t slot = (uint32_t)(bucket_slot(t, h) & (kSubSlots - 1));
-      const unsigned long long want = key.w[0] | kFlag;
-      uint32_t probes = 0;
-      for (;;) {
-        unsigned long long *r = lds + slot * R;
-        unsigned long long cur = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (cur == 0) {
-          const unsigned long long desired = (W == 1) ? want : (want | kPending);
-          cur = atomicCAS(r, 0ULL, desired);
-          if (cur == 0) {
-            if (W == 2) {
-              __hip_atomic_store(r + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_store(r, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            n_novel++;
-            atomicAdd(r + W, 256ULL);
-            if (e) atomicOr(r + W, (unsigned long long)e);
-            break;
-          }
+    for (uint64_t i0 = tid; i0 < n; i0 += (uint64_t)kLdsThreads * kLdsBatch) {
+      Kmer<W> key[kLdsBatch];
+      uint32_t e[kLdsBatch];
+#pragma unroll
+      for (int q = 0; q < kLdsBatch; q++) {
+        const uint64_t i = i0 + (uint64_t)q * kLdsThreads;
+        if (i < n) {
+          key[q].w[0] = kin[i * W];
+          if (W == 2) key[q].w[W - 1] = kin[i * W + 1];
+          e[q] = ein[i];
         }
-        if ((cur & ~kPending) == want) {
-          bool match = true;
-          if (W == 2) {
-            if (cur & kPending) { if (++probes > (1u << 22)) { full = 1; break; } continue; }
-            match = __hip_atomic_load(r + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1];
-          }
-          if (match) {
-            atomicAdd(r + W, 256ULL);
-            if (e & ~(uint32_t)__hip_atomic_load(r + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-              atomicOr(r + W, (unsigned long long)e);
-            break;
-          }
-        }
-        if (++probes > kSubSlots) { full = 1; break; }
-        slot = (slot + 1) & (uint32_t)(kSubSlots - 1);
       }
+#pragma unroll
+      for (int q = 0; q < kLdsBatch; q++)
+        if (i0 + (uint64_t)q * kLdsThreads < n) lds_apply<W>(lds, t, key[q], e[q], n_novel, full);
     }
     __syncthreads();
 
     if (W == 1 && ONECOL) {
       const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(lds);
       ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(slice);
-      for (uint32_t i = tid; i < kSubSlots; i += kThreads) dst[i] = src[i];
+#pragma unroll
+      for (int q = 0; q < PER; q++) dst[q * kLdsThreads + tid] = src[q * kLdsThreads + tid];
     } else {
-      for (uint32_t i = tid; i < kSubSlots; i += kThreads) {
+#pragma unroll 4
+      for (uint32_t i = tid; i < kSubSlots; i += kLdsThreads) {
         uint64_t *r = slice + (uint64_t)i * S;
         r[0] = lds[i * R];
         if (W == 2) r[1] = lds[i * R + 1];
