@@ -73,7 +73,8 @@ struct mcx_graph {
   uint64_t defer_tuples = 0;    // tuples buffered per flush (0 = pick from the table size)
   uint32_t nsub = 0;            // sub-tables
   uint32_t b1 = 0, subs_per_bin = 0;
-  uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 bin / per L2 (sub-table) bin
+  uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 (replica, bin) segment / per L2 (sub-table) bin
+  uint32_t rep1 = 8;            // replicas of every L1 bin (one per XCD)
   uint64_t *l1_keys = nullptr, *l2_keys = nullptr;
   uint8_t *l1_edges = nullptr, *l2_edges = nullptr;
   unsigned long long *l1_cnt = nullptr, *l2_cnt = nullptr;
@@ -195,7 +196,7 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
-  if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * 8, g->stream));
+  if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   g->pending = 0;  // buffered tuples are discarded with the table
   return MCX_OK;
 }
@@ -350,10 +351,10 @@ static int ensure_defer(mcx_graph *g)
     tcap = e ? strtoull(e, nullptr, 10) : std::min<uint64_t>(std::max<uint64_t>(4 * g->t.nslots, 1ull << 20), 1ull << 31);
   }
   g->defer_tuples = tcap;
-  g->cap1 = g->b1 == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->b1 * 1.04) + 8192;
+  g->cap1 = (uint64_t)((double)tcap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + 8192;
   g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
   if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "defer_tuples too large for this table");
-  const uint64_t n1 = (uint64_t)g->b1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
+  const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
 #define DEFER_TRY(expr)                                                                                   \
   do {                                                                                                    \
     hipError_t _e = (expr);                                                                               \
@@ -364,11 +365,11 @@ static int ensure_defer(mcx_graph *g)
   } while (0)
   DEFER_TRY(hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W));
   DEFER_TRY(hipMalloc((void **)&g->l1_edges, n1));
-  DEFER_TRY(hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * 8));
+  DEFER_TRY(hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * g->rep1 * 8));
   DEFER_TRY(hipMalloc((void **)&g->l2_keys, n2 * 8 * g->W));
   DEFER_TRY(hipMalloc((void **)&g->l2_edges, n2));
   DEFER_TRY(hipMalloc((void **)&g->l2_cnt, (size_t)g->nsub * 8));
-  DEFER_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * 8, g->stream));
+  DEFER_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   DEFER_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
 #undef DEFER_TRY
   return MCX_OK;
@@ -379,14 +380,14 @@ static int flush_deferred(mcx_graph *g)
 {
   if (!g->pending) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
-  TupleIn in{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1, g->b1};
-  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, g->subs_per_bin};
+  TupleIn in{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1, g->b1 * g->rep1};
+  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, g->subs_per_bin, 1, g->nsub, g->b1};
   BinOut out{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
   DISPATCH_WC(g, launch_bin_tuples_t, g, in, g->pending_colour, bs, out);
   HIP_TRY(hipGetLastError());
   DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * 8, g->stream));
+  HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
   g->pending = 0;
   return MCX_OK;
@@ -420,7 +421,7 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     if (rc != MCX_OK) return rc;
     StreamLaunch P = L;
     P.pos_lo = lo; P.pos_hi = hi;
-    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1};
+    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1};
     BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
     DISPATCH_WC(g, launch_bin_stream_t, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
@@ -504,7 +505,7 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  BinSpec bs{BIN_OWNER, (uint32_t)nparts, 1, (uint32_t)nparts};
+  BinSpec bs{BIN_OWNER, (uint32_t)nparts, 1, (uint32_t)nparts, 1, (uint32_t)nparts, 1};
   BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity};
   if (g->W == 1) launch_bin_stream_t<1, true>(g, L, 0, bs, out);
   else launch_bin_stream_t<2, true>(g, L, 0, bs, out);
@@ -529,7 +530,7 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
     int rc = defer_reserve(g, colour, cnt);
     if (rc != MCX_OK) return rc;
     TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1};
-    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1};
+    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1};
     BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
     DISPATCH_WC(g, launch_bin_tuples_t, g, in, colour, bs, out);
     HIP_TRY(hipGetLastError());

@@ -27,13 +27,22 @@ struct BinSpec {
   uint32_t nparts;  // BIN_OWNER: number of owners
   uint32_t div;     // BIN_GROUP: sub-tables per L1 bin; BIN_SUBLOCAL: sub-tables per input segment
   uint32_t nlocal;  // bins a block can meet (size of the LDS histogram), <= kMaxBins
+  // Output replication (replica-major): every output bin exists `rep` times (own counter, own
+  // storage) and a block appends to replica blockIdx % rep.  All blocks reserving from the same
+  // 64 counter lines once per tile serialise on those lines (~12 ns per same-line atomic:
+  // 1.7 of 5 ms per 600 M tuples, profiles/r01b); 8 replicas in separate lines remove that, and
+  // since block b is observed to run on XCD b % 8 each replica's write fronts stay in one L2,
+  // which merges the 8-tuple runs into full-line write-backs (speed only, never correctness).
+  uint32_t rep;
+  uint32_t nout;     // output bins per replica
+  uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s belongs to L1 bin s % seg_mod
 };
 
 struct BinOut {
-  uint64_t *keys;              // [nbins][cap][W]
-  uint8_t *edges;              // [nbins][cap]
-  unsigned long long *counts;  // [nbins] fill (may exceed cap: the excess went to the fallback)
-  uint64_t cap;
+  uint64_t *keys;              // [rep][nbins][cap][W]
+  uint8_t *edges;              // [rep][nbins][cap]
+  unsigned long long *counts;  // [rep][nbins] fill (may exceed cap: the excess went to the fallback)
+  uint64_t cap;                // tuples per (replica, bin) segment
 };
 
 constexpr int kMaxBins = 2048;
@@ -62,7 +71,7 @@ __device__ __forceinline__ void bin_of(const BinSpec &bs, const TableView &t, ui
   } else {
     const uint32_t sub = sub_of(t, h);
     if (bs.mode == BIN_GROUP) { local = outbin = sub / bs.div; }
-    else { local = sub - seg * bs.div; outbin = sub; }
+    else { local = sub - (seg % bs.seg_mod) * bs.div; outbin = sub; }
   }
 }
 
@@ -92,7 +101,7 @@ __device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs,
   __syncthreads();
   for (uint32_t b = tid; b < bs.nlocal; b += kThreads) {
     const uint32_t c = L.cnt[b];
-    const uint32_t ob = bs.mode == BIN_SUBLOCAL ? seg * bs.div + b : b;
+    const uint32_t ob = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div + b : b) + (blockIdx.x % bs.rep) * bs.nout;
     unsigned long long g0 = c ? atomicAdd(&out.counts[ob], (unsigned long long)c) : 0ULL;
     L.base[b] = g0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g0;  // saturated == beyond any capacity
     L.cnt[b] = 0;
@@ -122,7 +131,7 @@ __device__ __forceinline__ void bin_writeout(BinLds<W, NB> &L, const BinSpec &bs
   for (uint32_t p = threadIdx.x; p < n; p += kThreads) {
     const uint32_t b = L.sbin[p];
     const uint64_t gpos = (uint64_t)L.base[b] + (p - L.off[b]);
-    const uint32_t ob = bs.mode == BIN_SUBLOCAL ? seg * bs.div + b : b;
+    const uint32_t ob = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div + b : b) + (blockIdx.x % bs.rep) * bs.nout;
     if (gpos < out.cap) {
       uint64_t *kd = out.keys + ((uint64_t)ob * out.cap + gpos) * W;
       kd[0] = L.skey[p * W];
@@ -241,11 +250,38 @@ __global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec b
         }
       }
     }
+#ifdef MCX_L1_SCATTER
+    // experiment: no LDS staging -- reserve per bin, then every lane stores its tuples itself
+    __syncthreads();
+    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) {
+      const uint32_t c = L.cnt[b];
+      unsigned long long g0 = c ? atomicAdd(&out.counts[b + (blockIdx.x % bs.rep) * bs.nout], (unsigned long long)c) : 0ULL;
+      L.base[b] = g0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g0;
+      L.cnt[b] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPosPerLane; j++)
+      if (vmask & (1u << j)) {
+        const uint32_t local = tle[j] >> 8;
+        const uint64_t gpos = (uint64_t)L.base[local] + atomicAdd(&L.cnt[local], 1u);
+        if (gpos < out.cap) {
+          const uint64_t sg = local + (uint64_t)(blockIdx.x % bs.rep) * bs.nout;
+          uint64_t *kd = out.keys + (sg * out.cap + gpos) * W;
+          kd[0] = tk[j].w[0];
+          if (W == 2) kd[1] = tk[j].w[W - 1];
+          out.edges[sg * out.cap + gpos] = (uint8_t)(tle[j] & 0xffu);
+        } else {
+          full = 2;
+        }
+      }
+#else
     bin_reserve<W, NB>(L, bs, out, 0);
 #pragma unroll
     for (int j = 0; j < kPosPerLane; j++)
       if (vmask & (1u << j)) bin_place<W, NB>(L, tle[j] >> 8, tk[j], tle[j] & 0xffu);
     bin_writeout<W, ONECOL, NB>(L, bs, out, 0, isink, n_novel, full);
+#endif
   }
 
   if (n_kmers) atomicAdd(&a.ctr->kmers, (unsigned long long)n_kmers);
@@ -276,10 +312,24 @@ __global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs,
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
   const uint64_t chunks_per_seg = (in.seg_cap + kTile - 1) / kTile;
-  const uint64_t nchunks = chunks_per_seg * in.nseg;
-  for (uint64_t v = blockIdx.x; v < nchunks; v += gridDim.x) {
-    const uint32_t seg = (uint32_t)(v / chunks_per_seg);
-    const uint64_t start = (v % chunks_per_seg) * kTile;
+  // Work order.  Blocks that run at the same time must not all split the same L1 bin: they
+  // would reserve from the same 64 counter lines (~12 ns per same-line atomic).  So chunks are
+  // taken segment-interleaved, and -- XCD-aware -- block x only takes L1 bins b with
+  // b % 8 == x % 8: with the observed block -> XCD round-robin every sub-table bin is then
+  // written from one XCD, whose L2 merges the 8-tuple runs into full lines (speed only).
+  const bool xcd = bs.mode == BIN_SUBLOCAL && gridDim.x % 8 == 0 && bs.seg_mod % 8 == 0 && in.nseg % bs.seg_mod == 0;
+  const uint32_t group = xcd ? blockIdx.x % 8 : 0;
+  const uint32_t nseg_g = xcd ? in.nseg / 8 : in.nseg;  // segments this block may take
+  const uint64_t nchunks = chunks_per_seg * nseg_g;
+  const uint64_t v0 = xcd ? blockIdx.x / 8 : blockIdx.x, vstep = xcd ? gridDim.x / 8 : gridDim.x;
+  for (uint64_t v = v0; v < nchunks; v += vstep) {
+    const uint32_t sl = (uint32_t)(v % nseg_g);  // segment-interleaved
+    uint32_t seg = sl;
+    if (xcd) {
+      const uint32_t bins_g = bs.seg_mod / 8;  // L1 bins of this group
+      seg = (sl / bins_g) * bs.seg_mod + group + 8 * (sl % bins_g);  // replica-major segment index
+    }
+    const uint64_t start = (v / nseg_g) * kTile;
     uint64_t cnt = in.counts ? (uint64_t)in.counts[seg] : in.seg_cap;
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (start >= cnt) continue;  // uniform across the block

@@ -50,7 +50,7 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = os.environ.get("MCX_LIB", _build.LIB)  # MCX_LIB: tuning variants built by tools/
+    path = os.environ.get("MCX_LIB") or _build.LIB  # MCX_LIB: tuning variants built by tools/
     if not os.path.exists(path):
         raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build())" % path)
     L = C.CDLL(path)

@@ -20,8 +20,12 @@ run pmc_write --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run pmc_ea --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run pmc_atomic --kernel-trace --pmc TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum TCC_REQ_sum TCC_READ_sum
 run pmc_sq --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_VALU
+run pmc_lds --kernel-trace --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
-find $OUT -name "*.csv" | head -30
-# keep only small summaries
-find $OUT -name "*kernel_trace.csv" -size +2M -delete
+# condense on the box (gpurun copies back at most 64 MiB): summary + small CSVs only
+cd $REPO && python tools/summarize_prof.py $TAG $ARGS > $OUT/summary.txt 2>&1
+cp profiles/${TAG}_* $OUT/ 2>/dev/null
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT
