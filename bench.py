@@ -169,27 +169,46 @@ def main():
     W = graph.W
 
     sharded = world > 1 or force_shard
-    live = []
     if sharded:
+        # double-buffered owner bins: the partition of step n+1 (handle's stream) overlaps with the
+        # RCCL all-to-all of step n (torch's stream); received tuples are then binned for the
+        # deferred insert.  Nothing here reads the graph, so nothing flushes it.
         bin_cap = int(B * (READ_LEN - K + 1) / world * 1.10) + 65536
-        send_keys = torch.empty((world, bin_cap, W), dtype=torch.int64, device=device)
-        send_edges = torch.empty((world, bin_cap), dtype=torch.uint8, device=device)
-        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        send = [(torch.empty((world, bin_cap, W), dtype=torch.int64, device=device),
+                 torch.empty((world, bin_cap), dtype=torch.uint8, device=device),
+                 torch.zeros(world, dtype=torch.int64, device=device)) for _ in range(2)]
+        part_done = [torch.cuda.Event(), torch.cuda.Event()]
 
-    def step(i):
-        s = batches[i]
-        if not sharded:
-            graph.add_stream_dev(0, s, s.numel())
+    def partition(i, buf):
+        sk, se, cnt = send[buf]
+        with torch.cuda.stream(ext):
+            cnt.zero_()
+        graph.partition_stream_dev(batches[i], batches[i].numel(), world, bin_cap, sk, se, cnt)
+        part_done[buf].record(ext)
+
+    def run_steps(idx):
+        idx = list(idx)
+        if not idx:
             return
-        counts.zero_()
-        torch.cuda.current_stream().synchronize()
-        graph.partition_stream_dev(s, s.numel(), world, bin_cap, send_keys, send_edges, counts)
-        graph.sync()      # also: the previous step's insert (same stream) has finished
-        live.clear()      # ... so its receive buffers may now be recycled by the allocator
-        rk, re_, rc_ = shard.exchange(send_keys, send_edges, counts)
-        torch.cuda.current_stream().synchronize()
-        graph.insert_tuples_dev(0, rk, re_, int(sum(rc_)))
-        live.append((rk, re_))
+        if not sharded:
+            for i in idx:
+                graph.add_stream_dev(0, batches[i], batches[i].numel())
+            return
+        live = []
+        partition(idx[0], 0)
+        for n, i in enumerate(idx):
+            buf = n % 2
+            part_done[buf].synchronize()           # this step's bins and counts are complete
+            if n + 1 < len(idx):
+                partition(idx[n + 1], 1 - buf)     # overlaps with the exchange below
+            rk, re_, rc_ = shard.exchange(*send[buf])
+            torch.cuda.current_stream().synchronize()
+            graph.insert_tuples_dev(0, rk, re_, int(sum(rc_)))
+            live.append((rk, re_))                 # keep receive buffers alive until consumed
+            if len(live) > 2:
+                ext.synchronize()
+                del live[:-1]
+        ext.synchronize()
 
     def fence():
         torch.cuda.synchronize()
@@ -198,8 +217,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(nwarm):
-        step(nsteps + i)
+    run_steps(range(nsteps, nsteps + nwarm))
     fence()
     graph.reset()
     fence()
@@ -208,8 +226,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(ext)
-    for i in range(nsteps):
-        step(i)
+    run_steps(range(nsteps))
     fence()
     ev1.record(ext)
     dt = time.perf_counter() - t0

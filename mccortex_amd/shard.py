@@ -7,6 +7,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+MAX_ROUND = 1 << 24  # tuples per peer per all-to-all round (128 MiB of keys at W=1)
+
 
 def exchange(send_keys, send_edges, counts, group=None):
     """send_keys [world, cap, W] int64, send_edges [world, cap] uint8, counts [world] int64 (same
@@ -20,12 +22,36 @@ def exchange(send_keys, send_edges, counts, group=None):
     n_in = int(ro[-1])
     recv_keys = torch.empty((n_in, W), dtype=send_keys.dtype, device=send_keys.device)
     recv_edges = torch.empty((n_in,), dtype=send_edges.dtype, device=send_edges.device)
-    # bins are fixed-capacity: pack the filled prefixes, then one all_to_all_single per array
-    # (works on RCCL and gloo alike; every pair of GPUs is one xGMI hop)
-    pk = torch.cat([send_keys[p, :sc[p]] for p in range(world)])
-    pe = torch.cat([send_edges[p, :sc[p]] for p in range(world)])
-    dist.all_to_all_single(recv_keys, pk, output_split_sizes=rc, input_split_sizes=sc, group=group)
-    dist.all_to_all_single(recv_edges, pe, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    # Messages are cut into rounds of at most MAX_ROUND tuples per peer: RCCL (2.26, ROCm 7.0)
+    # was observed to deliver only part of an all-to-all message larger than ~1 GB
+    # (tools/dbg_shard3.py), and bounded rounds also bound the staging RCCL needs.
+    for r0 in range(0, max(max(sc), max(rc), 1), MAX_ROUND):
+        s_lo = [min(c, r0) for c in sc]
+        s_hi = [min(c, r0 + MAX_ROUND) for c in sc]
+        r_lo = [min(c, r0) for c in rc]
+        r_hi = [min(c, r0 + MAX_ROUND) for c in rc]
+        if dist.get_backend(group) == "nccl":
+            # RCCL takes per-peer tensor lists: the filled bin prefixes go out in place (no packing
+            # copy); every pair of GPUs is one xGMI hop, so this is a direct all-to-all, not a ring
+            dist.all_to_all([recv_keys[ro[p] + r_lo[p]:ro[p] + r_hi[p]] for p in range(world)],
+                            [send_keys[p, s_lo[p]:s_hi[p]] for p in range(world)], group=group)
+            dist.all_to_all([recv_edges[ro[p] + r_lo[p]:ro[p] + r_hi[p]] for p in range(world)],
+                            [send_edges[p, s_lo[p]:s_hi[p]] for p in range(world)], group=group)
+        else:
+            # gloo (CPU tests) has no list all_to_all: pack the round and use split sizes
+            pk = torch.cat([send_keys[p, s_lo[p]:s_hi[p]] for p in range(world)])
+            pe = torch.cat([send_edges[p, s_lo[p]:s_hi[p]] for p in range(world)])
+            ins = [s_hi[p] - s_lo[p] for p in range(world)]
+            outs = [r_hi[p] - r_lo[p] for p in range(world)]
+            tk = torch.empty((sum(outs), W), dtype=send_keys.dtype, device=send_keys.device)
+            te = torch.empty((sum(outs),), dtype=send_edges.dtype, device=send_edges.device)
+            dist.all_to_all_single(tk, pk, output_split_sizes=outs, input_split_sizes=ins, group=group)
+            dist.all_to_all_single(te, pe, output_split_sizes=outs, input_split_sizes=ins, group=group)
+            o = 0
+            for p in range(world):
+                recv_keys[ro[p] + r_lo[p]:ro[p] + r_hi[p]] = tk[o:o + outs[p]]
+                recv_edges[ro[p] + r_lo[p]:ro[p] + r_hi[p]] = te[o:o + outs[p]]
+                o += outs[p]
     return recv_keys, recv_edges, rc
 
 
