@@ -75,10 +75,15 @@ __device__ __forceinline__ void bin_of(const BinSpec &bs, const TableView &t, ui
   }
 }
 
-// After the counting sweep: exclusive scan of the histogram (wave 0) and one global
-// reservation per non-empty bin.  Leaves cnt[] zeroed for the placement sweep.
+// After the counting sweep: exclusive scan of the histogram (wave 0), then every thread issues
+// the global reservations of its bins (one returning atomic per non-empty bin).  The results
+// stay in registers: placement into the LDS staging area only needs off[], so the atomics'
+// round trip overlaps with it; bin_commit() publishes the bases before the write-out.
+template <int NB> struct BinRes { unsigned long long g0[(NB + kThreads - 1) / kThreads]; };
+
 template <int W, int NB>
-__device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs, const BinOut &out, uint32_t seg)
+__device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs, const BinOut &out, uint32_t seg,
+                                            BinRes<NB> &res)
 {
   const int tid = threadIdx.x;
   __syncthreads();
@@ -99,14 +104,31 @@ __device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs,
     if (tid == 0) L.off[bs.nlocal] = carry;
   }
   __syncthreads();
-  for (uint32_t b = tid; b < bs.nlocal; b += kThreads) {
-    const uint32_t c = L.cnt[b];
-    const uint32_t ob = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div + b : b) + (blockIdx.x % bs.rep) * bs.nout;
-    unsigned long long g0 = c ? atomicAdd(&out.counts[ob], (unsigned long long)c) : 0ULL;
-    L.base[b] = g0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g0;  // saturated == beyond any capacity
-    L.cnt[b] = 0;
+#pragma unroll
+  for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
+    const uint32_t b = (uint32_t)q * kThreads + tid;
+    res.g0[q] = 0;
+    if (b < bs.nlocal) {
+      const uint32_t c = L.cnt[b];
+      const uint32_t ob = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div + b : b) + (blockIdx.x % bs.rep) * bs.nout;
+#ifndef MCX_EXP_NORESERVE
+      if (c) res.g0[q] = atomicAdd(&out.counts[ob], (unsigned long long)c);
+#endif
+      L.cnt[b] = 0;
+    }
   }
   __syncthreads();
+}
+
+template <int W, int NB>
+__device__ __forceinline__ void bin_commit(BinLds<W, NB> &L, const BinSpec &bs, const BinRes<NB> &res)
+{
+#pragma unroll
+  for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
+    const uint32_t b = (uint32_t)q * kThreads + threadIdx.x;
+    // saturated == beyond any capacity
+    if (b < bs.nlocal) L.base[b] = res.g0[q] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)res.g0[q];
+  }
 }
 
 // Placement sweep: drop a tuple at its sorted position in the LDS staging area
@@ -170,17 +192,39 @@ __global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec b
   const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
   const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);
 
+  // the chunks of the NEXT tile are fetched into registers while the current one is processed
+  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+  {
+    const uint64_t t0 = a.tile0 + blockIdx.x;
+    if (t0 < a.ntiles) {
+      const int64_t r0 = (int64_t)(t0 * kTile) - 16;
+      pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
+      if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
+    }
+  }
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
-    const int64_t region0 = (int64_t)(tile * kTile) - 16;
-    for (int c = tid; c < kChunks; c += kThreads) {
+    {
       uint32_t code, inv;
-      encode_chunk(a.stream, a.nbytes, region0 + 16 * (int64_t)c, code, inv);
-      s_code[c] = code;
-      reinterpret_cast<uint16_t *>(s_inv)[c ^ 1] = (uint16_t)inv;
+      encode_words(pre0, code, inv);
+      s_code[tid] = code;
+      reinterpret_cast<uint16_t *>(s_inv)[tid ^ 1] = (uint16_t)inv;
+      if (tid < kChunks - kThreads) {
+        encode_words(pre1, code, inv);
+        s_code[tid + kThreads] = code;
+        reinterpret_cast<uint16_t *>(s_inv)[(tid + kThreads) ^ 1] = (uint16_t)inv;
+      }
     }
     for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
+    {
+      const uint64_t tn = tile + gridDim.x;
+      if (tn < a.ntiles) {
+        const int64_t r0 = (int64_t)(tn * kTile) - 16;
+        pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
+        if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
+      }
+    }
     __syncthreads();
 
     const uint32_t pl = 16u * (uint32_t)(tid + 1);
@@ -276,10 +320,12 @@ __global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec b
         }
       }
 #else
-    bin_reserve<W, NB>(L, bs, out, 0);
+    BinRes<NB> res;
+    bin_reserve<W, NB>(L, bs, out, 0, res);
 #pragma unroll
     for (int j = 0; j < kPosPerLane; j++)
       if (vmask & (1u << j)) bin_place<W, NB>(L, tle[j] >> 8, tk[j], tle[j] & 0xffu);
+    bin_commit<W, NB>(L, bs, res);
     bin_writeout<W, ONECOL, NB>(L, bs, out, 0, isink, n_novel, full);
 #endif
   }
@@ -364,12 +410,14 @@ __global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs,
       if (loc[q] >= bs.nlocal) loc[q] = bs.nlocal - 1;  // cannot happen for well-formed bins
       if (i < n) atomicAdd(&L.cnt[loc[q]], 1u);
     }
-    bin_reserve<W, NB>(L, bs, out, seg);
+    BinRes<NB> res;
+    bin_reserve<W, NB>(L, bs, out, seg, res);
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       const uint32_t i = (uint32_t)q * kThreads + tid;
       if (i < n) bin_place<W, NB>(L, loc[q], key[q], ev[q]);
     }
+    bin_commit<W, NB>(L, bs, res);
     bin_writeout<W, ONECOL, NB>(L, bs, out, seg, isink, n_novel, full);
   }
   if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);

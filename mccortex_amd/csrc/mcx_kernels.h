@@ -186,23 +186,24 @@ __device__ __forceinline__ uint64_t inv_win64(const uint32_t *s_inv, uint32_t q)
   return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
 }
 
-// Stage one 16-byte chunk: 16 bases -> 32 code bits (first base on top) and
-// 16 invalid flags (first base = bit 15).
-__device__ __forceinline__ void encode_chunk(const uint8_t *stream, uint64_t nbytes, int64_t g,
-                                             uint32_t &code, uint32_t &inv)
+// Fetch one 16-byte chunk of the stream at byte offset g (bytes outside [0, nbytes) read as 0,
+// which is not ACGT: out-of-range == separator).
+__device__ __forceinline__ uint4 load_chunk(const uint8_t *stream, uint64_t nbytes, int64_t g)
 {
-  uint32_t w[4];
-  if (g >= 0 && (uint64_t)g + 16 <= nbytes) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(stream + g);
-    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-  } else {
-    w[0] = w[1] = w[2] = w[3] = 0;  // byte 0 is not ACGT: out-of-range == separator
-    if (g + 16 > 0 && g < (int64_t)nbytes)
-      for (int i = 0; i < 16; i++) {
-        const int64_t p = g + i;
-        if (p >= 0 && (uint64_t)p < nbytes) w[i >> 2] |= (uint32_t)stream[p] << (8 * (i & 3));
-      }
-  }
+  if (g >= 0 && (uint64_t)g + 16 <= nbytes) return *reinterpret_cast<const uint4 *>(stream + g);
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (g + 16 > 0 && g < (int64_t)nbytes)
+    for (int i = 0; i < 16; i++) {
+      const int64_t p = g + i;
+      if (p >= 0 && (uint64_t)p < nbytes) w[i >> 2] |= (uint32_t)stream[p] << (8 * (i & 3));
+    }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// 16 bases -> 32 code bits (first base on top) and 16 invalid flags (first base = bit 15).
+__device__ __forceinline__ void encode_words(const uint4 v, uint32_t &code, uint32_t &inv)
+{
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
   code = 0; inv = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -218,6 +219,12 @@ __device__ __forceinline__ void encode_chunk(const uint8_t *stream, uint64_t nby
 #undef MCX_NZ
     inv = (inv << 4) | ((((bad >> 7) * 0x08040201u) >> 24) & 0xFu);
   }
+}
+
+__device__ __forceinline__ void encode_chunk(const uint8_t *stream, uint64_t nbytes, int64_t g,
+                                             uint32_t &code, uint32_t &inv)
+{
+  encode_words(load_chunk(stream, nbytes, g), code, inv);
 }
 
 // One k-mer occurrence produced by the front end
