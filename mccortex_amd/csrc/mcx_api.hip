@@ -315,7 +315,7 @@ template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int 
   BinOut bins{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
   SpanGuard sp(g, "k_lds_insert");
   hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(g->nsub, (uint64_t)g->grid * 4)),
-                     dim3(kLdsThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
+                     dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
 }
 
 template <int W, bool ONECOL>

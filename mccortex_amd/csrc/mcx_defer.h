@@ -52,14 +52,22 @@ __device__ __forceinline__ uint32_t sub_of(const TableView &t, uint32_t h)
   return (uint32_t)(bucket_slot(t, h) >> kSubShift);
 }
 
-// LDS working set of one binning block (NB = histogram capacity: 512 keeps three blocks per CU)
+// The sorted tile is staged and written out in kRounds rounds of kStage tuples: the staging
+// area is what limits blocks per CU (W=2: 84 KB for a whole tile = 1 block, 46 KB = 3 blocks).
+#ifndef MCX_ROUNDS
+#define MCX_ROUNDS 2
+#endif
+constexpr int kRounds = MCX_ROUNDS;
+constexpr int kStage = kTile / kRounds;
+
+// LDS working set of one binning block (NB = histogram capacity)
 template <int W, int NB> struct BinLds {
-  uint64_t skey[kTile * W];
+  uint64_t skey[kStage * W];
   uint32_t cnt[NB];
   uint32_t off[NB + 4];
   uint32_t base[NB];  // bin capacities are < 2^32 tuples (checked by the host)
-  uint16_t sbin[kTile];
-  uint8_t se[kTile];
+  uint16_t sbin[kStage];
+  uint8_t se[kStage];
 };
 
 // bin index inside the block's histogram, and output bin, of a tuple
@@ -131,54 +139,72 @@ __device__ __forceinline__ void bin_commit(BinLds<W, NB> &L, const BinSpec &bs, 
   }
 }
 
-// Placement sweep: drop a tuple at its sorted position in the LDS staging area
+// Sorted position of a tuple inside the tile (taken once, kept in a register)
 template <int W, int NB>
-__device__ __forceinline__ void bin_place(BinLds<W, NB> &L, uint32_t local, const Kmer<W> &key, uint32_t e)
+__device__ __forceinline__ uint32_t bin_rank(BinLds<W, NB> &L, uint32_t local)
 {
-  const uint32_t p = L.off[local] + atomicAdd(&L.cnt[local], 1u);
-  L.skey[p * W] = key.w[0];
-  if (W == 2) L.skey[p * W + 1] = key.w[W - 1];
-  L.sbin[p] = (uint16_t)local;
-  L.se[p] = (uint8_t)e;
+  return L.off[local] + atomicAdd(&L.cnt[local], 1u);
 }
 
-// Linear write-out: consecutive lanes write consecutive tuples of a bin.  Tuples beyond a
-// bin's capacity take the direct insert (deferred modes) or raise bin_over (owner mode).
+// Placement: drop a tuple at its sorted position if that position belongs to this round
+template <int W, int NB>
+__device__ __forceinline__ void bin_place(BinLds<W, NB> &L, int round, uint32_t p, uint32_t local,
+                                          const Kmer<W> &key, uint32_t e)
+{
+  if ((int)(p / kStage) != round) return;
+  const uint32_t q = p % kStage;
+  L.skey[q * W] = key.w[0];
+  if (W == 2) L.skey[q * W + 1] = key.w[W - 1];
+  L.sbin[q] = (uint16_t)local;
+  L.se[q] = (uint8_t)e;
+}
+
+// Linear write-out of one round: consecutive lanes write consecutive tuples of a bin.  Tuples
+// beyond a bin's capacity take the direct insert (deferred modes) or raise bin_over (owner mode).
 template <int W, bool ONECOL, int NB>
-__device__ __forceinline__ void bin_writeout(BinLds<W, NB> &L, const BinSpec &bs, const BinOut &out, uint32_t seg,
-                                             const InsertSink<W, ONECOL> &isink, uint32_t &novel, uint32_t &full)
+__device__ __forceinline__ void bin_writeout(BinLds<W, NB> &L, int round, const BinSpec &bs, const BinOut &out,
+                                             uint32_t seg, const InsertSink<W, ONECOL> &isink, uint32_t &novel,
+                                             uint32_t &full)
 {
   __syncthreads();
+#ifdef MCX_EXP_NOWRITE
+  const uint32_t n = 0;
+#else
   const uint32_t n = L.off[bs.nlocal];
-  for (uint32_t p = threadIdx.x; p < n; p += kThreads) {
-    const uint32_t b = L.sbin[p];
+#endif
+  const uint32_t lo = (uint32_t)round * kStage;
+  const uint32_t cnt = n > lo ? min(n - lo, (uint32_t)kStage) : 0;
+  for (uint32_t q = threadIdx.x; q < cnt; q += kThreads) {
+    const uint32_t p = lo + q;
+    const uint32_t b = L.sbin[q];
     const uint64_t gpos = (uint64_t)L.base[b] + (p - L.off[b]);
     const uint32_t ob = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div + b : b) + (blockIdx.x % bs.rep) * bs.nout;
     if (gpos < out.cap) {
       uint64_t *kd = out.keys + ((uint64_t)ob * out.cap + gpos) * W;
-      kd[0] = L.skey[p * W];
-      if (W == 2) kd[1] = L.skey[p * W + 1];
-      out.edges[(uint64_t)ob * out.cap + gpos] = L.se[p];
+      kd[0] = L.skey[q * W];
+      if (W == 2) kd[1] = L.skey[q * W + 1];
+      out.edges[(uint64_t)ob * out.cap + gpos] = L.se[q];
     } else if (bs.mode == BIN_OWNER) {
       full = 2;
     } else {
       Kmer<W> key;
-      key.w[0] = L.skey[p * W];
-      if (W == 2) key.w[W - 1] = L.skey[p * W + 1];
+      key.w[0] = L.skey[q * W];
+      if (W == 2) key.w[W - 1] = L.skey[q * W + 1];
       const uint32_t h = kmer_hash<W>(key, 0, nullptr);
       const uint64_t slot = bucket_slot(isink.t, h);
       const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
       const uint64_t cur = isink.t.rec[slot * S];
-      probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, L.se[p], isink.col, novel, full);
+      probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, L.se[q], isink.col, novel, full);
     }
   }
+  if (round + 1 < kRounds) __syncthreads();  // staging is reused by the next round
 }
 
 // ---------------------------------------------------------------------------
 // 1. reads -> bins
 // ---------------------------------------------------------------------------
 template <int W, bool ONECOL, int NB>
-__global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
+__global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
                                                          InsertSink<W, ONECOL> isink)
 {
   __shared__ uint32_t s_code[kChunks + 4];
@@ -323,10 +349,15 @@ __global__ __launch_bounds__(kThreads) void k_stream_bin(StreamArgs a, BinSpec b
     BinRes<NB> res;
     bin_reserve<W, NB>(L, bs, out, 0, res);
 #pragma unroll
-    for (int j = 0; j < kPosPerLane; j++)
-      if (vmask & (1u << j)) bin_place<W, NB>(L, tle[j] >> 8, tk[j], tle[j] & 0xffu);
+    for (int j = 0; j < kPosPerLane; j++)  // sorted position goes into bits 19..30 of tle
+      if (vmask & (1u << j)) tle[j] |= bin_rank<W, NB>(L, (tle[j] >> 8) & 0x7ffu) << 19;
     bin_commit<W, NB>(L, bs, res);
-    bin_writeout<W, ONECOL, NB>(L, bs, out, 0, isink, n_novel, full);
+    for (int round = 0; round < kRounds; round++) {
+#pragma unroll
+      for (int j = 0; j < kPosPerLane; j++)
+        if (vmask & (1u << j)) bin_place<W, NB>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], tle[j] & 0xffu);
+      bin_writeout<W, ONECOL, NB>(L, round, bs, out, 0, isink, n_novel, full);
+    }
 #endif
   }
 
@@ -350,7 +381,7 @@ struct TupleIn {
 };
 
 template <int W, bool ONECOL, int NB>
-__global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
+__global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
                                                          InsertSink<W, ONECOL> isink, Counters *ctr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -413,12 +444,19 @@ __global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs,
     BinRes<NB> res;
     bin_reserve<W, NB>(L, bs, out, seg, res);
 #pragma unroll
-    for (int q = 0; q < PER; q++) {
+    for (int q = 0; q < PER; q++) {  // sorted position goes into the high half of loc
       const uint32_t i = (uint32_t)q * kThreads + tid;
-      if (i < n) bin_place<W, NB>(L, loc[q], key[q], ev[q]);
+      if (i < n) loc[q] |= bin_rank<W, NB>(L, loc[q]) << 16;
     }
     bin_commit<W, NB>(L, bs, res);
-    bin_writeout<W, ONECOL, NB>(L, bs, out, seg, isink, n_novel, full);
+    for (int round = 0; round < kRounds; round++) {
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const uint32_t i = (uint32_t)q * kThreads + tid;
+        if (i < n) bin_place<W, NB>(L, round, loc[q] >> 16, loc[q] & 0xffffu, key[q], ev[q]);
+      }
+      bin_writeout<W, ONECOL, NB>(L, round, bs, out, seg, isink, n_novel, full);
+    }
   }
   if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
   if (full == 1) ctr->full = 1;
@@ -431,7 +469,8 @@ __global__ __launch_bounds__(kThreads) void k_tuples_bin(TupleIn in, BinSpec bs,
 // The slice is held in LDS as kSubSlots x (W key words + this colour's value word); other
 // colours' value words stay untouched in HBM.  find-or-insert / coverage / edges are the same
 // protocol as probe_insert, with LDS atomics.
-constexpr int kLdsThreads = 512;
+// threads of the LDS-insert workgroup: W=2 slices are 96 KiB (one workgroup per CU), so that one is larger
+template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? 512 : 1024; };
 constexpr int kLdsBatch = 4;
 
 // find-or-insert one tuple in the LDS-resident sub-table
@@ -480,9 +519,10 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const TableVi
 }
 
 template <int W, bool ONECOL>
-__global__ __launch_bounds__(kLdsThreads) void k_lds_insert(TableView t, uint32_t col, BinOut bins, uint32_t nsub,
-                                                            Counters *ctr)
+__global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
+                                                                    uint32_t nsub, Counters *ctr)
 {
+  constexpr int kLdsThreads = LdsCfg<W>::kThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
   constexpr int R = W + 1;  // words per slot in LDS
@@ -496,8 +536,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_insert(TableView t, uint32_
     if (n > bins.cap) n = bins.cap;
     uint64_t *slice = t.rec + (uint64_t)sub * kSubSlots * S;
     __syncthreads();
-    constexpr int PER = (int)(kSubSlots / kLdsThreads);
-    if (W == 1 && ONECOL) {  // record == LDS slot: straight 16-byte copies, all loads in flight
+    constexpr int PER = (int)(kSubSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
+    if (ONECOL) {  // HBM record == LDS slot: straight 16-byte copies, all loads in flight
       const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(slice);
       ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
       ulonglong2 v[PER];
@@ -536,7 +576,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_insert(TableView t, uint32_
     }
     __syncthreads();
 
-    if (W == 1 && ONECOL) {
+    if (ONECOL) {
       const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(lds);
       ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(slice);
 #pragma unroll
