@@ -381,7 +381,7 @@ static int flush_deferred(mcx_graph *g)
   if (!g->pending) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   TupleIn in{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1, g->b1 * g->rep1};
-  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, g->subs_per_bin, 1, g->nsub, g->b1};
+  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, g->subs_per_bin, 1, g->nsub, g->b1, 0};
   BinOut out{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
   DISPATCH_WC(g, launch_bin_tuples_t, g, in, g->pending_colour, bs, out);
   HIP_TRY(hipGetLastError());
@@ -421,7 +421,8 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     if (rc != MCX_OK) return rc;
     StreamLaunch P = L;
     P.pos_lo = lo; P.pos_hi = hi;
-    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1};
+    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1,
+               (uint64_t)g->b1 * g->subs_per_bin == g->nsub ? g->b1 : 0u};
     BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
     DISPATCH_WC(g, launch_bin_stream_t, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
@@ -505,7 +506,7 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  BinSpec bs{BIN_OWNER, (uint32_t)nparts, 1, (uint32_t)nparts, 1, (uint32_t)nparts, 1};
+  BinSpec bs{BIN_OWNER, (uint32_t)nparts, 1, (uint32_t)nparts, 1, (uint32_t)nparts, 1, 0};
   BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity};
   if (g->W == 1) launch_bin_stream_t<1, true>(g, L, 0, bs, out);
   else launch_bin_stream_t<2, true>(g, L, 0, bs, out);
@@ -530,7 +531,8 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
     int rc = defer_reserve(g, colour, cnt);
     if (rc != MCX_OK) return rc;
     TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1};
-    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1};
+    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1,
+               (uint64_t)g->b1 * g->subs_per_bin == g->nsub ? g->b1 : 0u};
     BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
     DISPATCH_WC(g, launch_bin_tuples_t, g, in, colour, bs, out);
     HIP_TRY(hipGetLastError());

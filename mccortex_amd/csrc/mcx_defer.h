@@ -36,6 +36,10 @@ struct BinSpec {
   uint32_t rep;
   uint32_t nout;     // output bins per replica
   uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s belongs to L1 bin s % seg_mod
+  // BIN_GROUP fast path: when the sub-tables divide evenly into the L1 bins,
+  // bin = floor(floor(h * nbuckets / 2^32) / (buckets per bin)) = mulhi(h, nbins): one instruction
+  // instead of a 32-bit division per tuple
+  uint32_t mulhi_bins;  // 0 = use the division
 };
 
 struct BinOut {
@@ -77,9 +81,13 @@ __device__ __forceinline__ void bin_of(const BinSpec &bs, const TableView &t, ui
   if (bs.mode == BIN_OWNER) {
     local = outbin = owner_of(h2, bs.nparts);
   } else {
-    const uint32_t sub = sub_of(t, h);
-    if (bs.mode == BIN_GROUP) { local = outbin = sub / bs.div; }
-    else { local = sub - (seg % bs.seg_mod) * bs.div; outbin = sub; }
+    if (bs.mode == BIN_GROUP) {
+      local = outbin = bs.mulhi_bins ? __umulhi(h, bs.mulhi_bins) : sub_of(t, h) / bs.div;
+    } else {  // `seg` here is the first sub-table of the segment's L1 bin (hoisted by the caller)
+      const uint32_t sub = sub_of(t, h);
+      local = sub - seg;
+      outbin = sub;
+    }
   }
 }
 
@@ -112,13 +120,14 @@ __device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs,
     if (tid == 0) L.off[bs.nlocal] = carry;
   }
   __syncthreads();
+  const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div : 0) + (blockIdx.x % bs.rep) * bs.nout;
 #pragma unroll
   for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
     const uint32_t b = (uint32_t)q * kThreads + tid;
     res.g0[q] = 0;
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
-      const uint32_t ob = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div + b : b) + (blockIdx.x % bs.rep) * bs.nout;
+      const uint32_t ob = ob0 + b;
 #ifndef MCX_EXP_NORESERVE
       if (c) res.g0[q] = atomicAdd(&out.counts[ob], (unsigned long long)c);
 #endif
@@ -174,11 +183,12 @@ __device__ __forceinline__ void bin_writeout(BinLds<W, NB> &L, int round, const 
 #endif
   const uint32_t lo = (uint32_t)round * kStage;
   const uint32_t cnt = n > lo ? min(n - lo, (uint32_t)kStage) : 0;
+  const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div : 0) + (blockIdx.x % bs.rep) * bs.nout;
   for (uint32_t q = threadIdx.x; q < cnt; q += kThreads) {
     const uint32_t p = lo + q;
     const uint32_t b = L.sbin[q];
     const uint64_t gpos = (uint64_t)L.base[b] + (p - L.off[b]);
-    const uint32_t ob = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div + b : b) + (blockIdx.x % bs.rep) * bs.nout;
+    const uint32_t ob = ob0 + b;
     if (gpos < out.cap) {
       uint64_t *kd = out.keys + ((uint64_t)ob * out.cap + gpos) * W;
       kd[0] = L.skey[q * W];
@@ -411,6 +421,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (start >= cnt) continue;  // uniform across the block
     const uint32_t n = (uint32_t)min((uint64_t)kTile, cnt - start);
+    const uint32_t seg_first = bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div : 0;  // block-uniform
     __syncthreads();
     for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
     __syncthreads();
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
       const uint32_t i = (uint32_t)q * kThreads + tid;
       uint32_t h2, ob;
       const uint32_t h = kmer_hash<W>(key[q], 0, &h2);
-      bin_of(bs, isink.t, h, h2, seg, loc[q], ob);
+      bin_of(bs, isink.t, h, h2, seg_first, loc[q], ob);
       if (loc[q] >= bs.nlocal) loc[q] = bs.nlocal - 1;  // cannot happen for well-formed bins
       if (i < n) atomicAdd(&L.cnt[loc[q]], 1u);
     }
