@@ -159,3 +159,32 @@ def test_build_table_full_dies(built, tmp_path):
     fa = _write_inputs(tmp_path, bases, offs, "big", "fa")
     rc, _, err = run(31, "build", "-k", "31", "-n", "1024", "-s", "a", "--seq", fa, str(tmp_path / "o.ctx"))
     assert rc == 1 and "Hash table is full" in err
+
+
+@pytest.mark.gpu
+def test_chunk_seams_and_long_sequences(built, orc, tmp_path):
+    """Reads longer than a staging chunk (chromosome-like FASTA records) and reads that straddle
+    chunk boundaries: MCX_STAGE_BYTES shrinks the 32 MiB staging chunk so the 128-byte carry and
+    the [pos_lo,pos_hi) ownership of k-mer start positions are exercised thousands of times."""
+    g = synth.genome(300_000, 77)
+    g[1000:1040] = ord("N")
+    g[150_000] = ord("n")
+    long_reads = [bytes(g[:120_000]), bytes(g[100_000:300_000]), b"ACGT" * 3000]
+    b1, o1 = orc.pack_reads(long_reads)
+    b2, o2 = synth.reads(3000, 151, seed=5, g=g, n_frac=0.1)
+    f1 = _write_inputs(tmp_path, b1, o1, "long", "fa", width=70)
+    f2 = _write_inputs(tmp_path, b2, o2, "short", "fq")
+    for stage in ("1024", "4096", "65536"):
+        for maxk, k in [(31, 31), (63, 63)]:
+            out = str(tmp_path / ("seam_%s_%d.ctx" % (stage, k)))
+            exe = os.path.join(BIN, "mccortex%d" % maxk)
+            env = dict(os.environ, MCX_STAGE_BYTES=stage)
+            p = subprocess.run([exe, "build", "-q", "-f", "-k", str(k), "-n", "2M", "-S", "-s", "smp", "--seq", f1, "--seq", f2, out],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 0, p.stderr.decode()
+            og = orc.Graph(k, 1, 1 << 21)
+            og.set_sample(0, "smp")
+            for bb, oo in [(b1, o1), (b2, o2)]:
+                st = og.add_reads(0, bb, oo)
+                og.update_stats(0, st)
+            assert open(out, "rb").read() == og.ctx_bytes(True), (stage, k)

@@ -223,3 +223,25 @@ def test_deferred_large_table_many_subtables(mcx, orc):
     prof = g.profile()
     assert "k_stream_bin" in prof and "k_tuples_bin" in prof and "k_lds_insert" in prof
     g.close()
+
+
+def test_configure_profile_and_device_memory(mcx):
+    import ctypes as C
+    free, total = C.c_uint64(), C.c_uint64()
+    assert mcx.lib().mcx_device_memory(0, C.byref(free), C.byref(total)) == 0
+    assert 0 < free.value <= total.value and total.value > (100 << 30)
+    g = mcx.Graph(31, 1, 1 << 16)
+    with pytest.raises(mcx.McxError):
+        g.configure("no_such_key", 1)
+    g.configure("profile", 1)
+    b, o = synth.reads(500, 100, genome_len=5000, seed=1)
+    g.add_reads(0, b, o)
+    n1 = g.nkmers
+    prof = g.profile()
+    assert prof and all(c >= 1 and ms >= 0 for c, ms in prof.values())
+    g.reset()
+    assert g.nkmers == 0 and g.device_stats().num_kmers_loaded == 0
+    g.configure("defer", 0)
+    g.add_reads(0, b, o)
+    assert g.nkmers == n1
+    g.close()
