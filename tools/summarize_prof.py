@@ -41,10 +41,11 @@ for d in sorted(os.listdir(src)):
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(cc)):
         kn = r["Kernel_Name"]
-        if "mcx::" in kn and ("k_stream" in kn or "k_insert" in kn or "k_part" in kn or "k_bin" in kn):
+        if "mcx::k_" in kn:
             key = (kn.split("(")[0].replace("void ", ""), r["Counter_Name"])
             agg.setdefault(key, []).append(float(r["Counter_Value"]))
     for (kn, c), v in agg.items():
-        lines.append("| %s | `%s` %s | %s |" % (d, short(kn), c, ", ".join("%.4g" % x for x in v[:8])))
+        v = [x for x in v if x > 0.01 * max(v)] or v  # drop the tiny warm-up launches
+        lines.append("| %s | `%s` %s | %s |" % (d, short(kn), c, ", ".join("%.4g" % x for x in v[:4])))
 open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
