@@ -350,28 +350,27 @@ static int ensure_defer(mcx_graph *g)
     const char *e = getenv("MCX_DEFER_TUPLES");
     tcap = e ? strtoull(e, nullptr, 10) : std::min<uint64_t>(std::max<uint64_t>(4 * g->t.nslots, 1ull << 20), 1ull << 31);
   }
-  g->defer_tuples = tcap;
-  g->cap1 = (uint64_t)((double)tcap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + 8192;
-  g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
-  if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "defer_tuples too large for this table");
-  const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
-#define DEFER_TRY(expr)                                                                                   \
-  do {                                                                                                    \
-    hipError_t _e = (expr);                                                                               \
-    if (_e != hipSuccess) {                                                                               \
-      free_defer(g);                                                                                      \
-      return fail(MCX_ERR_NOMEM, "deferred-insert workspace (%.1f GB): %s", (double)(n1 + n2) * (8 * g->W + 1) / 1e9, hipGetErrorString(_e)); \
-    }                                                                                                     \
-  } while (0)
-  DEFER_TRY(hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W));
-  DEFER_TRY(hipMalloc((void **)&g->l1_edges, n1));
-  DEFER_TRY(hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * g->rep1 * 8));
-  DEFER_TRY(hipMalloc((void **)&g->l2_keys, n2 * 8 * g->W));
-  DEFER_TRY(hipMalloc((void **)&g->l2_edges, n2));
-  DEFER_TRY(hipMalloc((void **)&g->l2_cnt, (size_t)g->nsub * 8));
-  DEFER_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
-  DEFER_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
-#undef DEFER_TRY
+  // Allocate the bins; if HBM is short halve the flush size (down to 1M occurrences), and if even
+  // that does not fit build with the direct path (same graph, just slower).
+  for (;; tcap /= 2) {
+    if (tcap < (1ull << 20)) { g->defer = false; g->defer_tuples = 0; (void)hipGetLastError(); return MCX_OK; }
+    g->defer_tuples = tcap;
+    g->cap1 = (uint64_t)((double)tcap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + 8192;
+    g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
+    if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) continue;
+    const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
+    const bool ok = hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W) == hipSuccess &&
+                    hipMalloc((void **)&g->l1_edges, n1) == hipSuccess &&
+                    hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * g->rep1 * 8) == hipSuccess &&
+                    hipMalloc((void **)&g->l2_keys, n2 * 8 * g->W) == hipSuccess &&
+                    hipMalloc((void **)&g->l2_edges, n2) == hipSuccess &&
+                    hipMalloc((void **)&g->l2_cnt, (size_t)g->nsub * 8) == hipSuccess;
+    if (ok) break;
+    free_defer(g);
+    (void)hipGetLastError();  // clear the sticky out-of-memory error
+  }
+  HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
+  HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
   return MCX_OK;
 }
 
