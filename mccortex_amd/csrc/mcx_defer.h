@@ -128,9 +128,7 @@ __device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs,
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
       const uint32_t ob = ob0 + b;
-#ifndef MCX_EXP_NORESERVE
       if (c) res.g0[q] = atomicAdd(&out.counts[ob], (unsigned long long)c);
-#endif
       L.cnt[b] = 0;
     }
   }
@@ -176,11 +174,7 @@ __device__ __forceinline__ void bin_writeout(BinLds<W, NB> &L, int round, const 
                                              uint32_t &full)
 {
   __syncthreads();
-#ifdef MCX_EXP_NOWRITE
-  const uint32_t n = 0;
-#else
   const uint32_t n = L.off[bs.nlocal];
-#endif
   const uint32_t lo = (uint32_t)round * kStage;
   const uint32_t cnt = n > lo ? min(n - lo, (uint32_t)kStage) : 0;
   const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div : 0) + (blockIdx.x % bs.rep) * bs.nout;
@@ -330,32 +324,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
         }
       }
     }
-#ifdef MCX_L1_SCATTER
-    // experiment: no LDS staging -- reserve per bin, then every lane stores its tuples itself
-    __syncthreads();
-    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) {
-      const uint32_t c = L.cnt[b];
-      unsigned long long g0 = c ? atomicAdd(&out.counts[b + (blockIdx.x % bs.rep) * bs.nout], (unsigned long long)c) : 0ULL;
-      L.base[b] = g0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g0;
-      L.cnt[b] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kPosPerLane; j++)
-      if (vmask & (1u << j)) {
-        const uint32_t local = tle[j] >> 8;
-        const uint64_t gpos = (uint64_t)L.base[local] + atomicAdd(&L.cnt[local], 1u);
-        if (gpos < out.cap) {
-          const uint64_t sg = local + (uint64_t)(blockIdx.x % bs.rep) * bs.nout;
-          uint64_t *kd = out.keys + (sg * out.cap + gpos) * W;
-          kd[0] = tk[j].w[0];
-          if (W == 2) kd[1] = tk[j].w[W - 1];
-          out.edges[sg * out.cap + gpos] = (uint8_t)(tle[j] & 0xffu);
-        } else {
-          full = 2;
-        }
-      }
-#else
     BinRes<NB> res;
     bin_reserve<W, NB>(L, bs, out, 0, res);
 #pragma unroll
@@ -368,7 +336,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
         if (vmask & (1u << j)) bin_place<W, NB>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], tle[j] & 0xffu);
       bin_writeout<W, ONECOL, NB>(L, round, bs, out, 0, isink, n_novel, full);
     }
-#endif
   }
 
   if (n_kmers) atomicAdd(&a.ctr->kmers, (unsigned long long)n_kmers);

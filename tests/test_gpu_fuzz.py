@@ -1,0 +1,71 @@
+"""Randomised parity: arbitrary byte streams, every odd k, ragged stream lengths."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_body(orc, k, stream_bytes, ncap=1 << 20):
+    og = orc.Graph(k, 1, ncap)
+    b = np.frombuffer(stream_bytes, np.uint8)
+    st = og.add_reads(0, b, np.array([0, len(b)], np.uint64))  # one "read": any non-ACGT byte splits it
+    return og, st, og.ctx_bytes(True)[og.header_size():]
+
+
+def _gpu_stream(mcx, k, stream_bytes, defer, ncap=1 << 20):
+    import torch
+    g = mcx.Graph(k, 1, ncap)
+    g.configure("defer", defer)
+    n = len(stream_bytes)
+    t = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")  # slack after the stream is never read as data
+    t[n:] = ord("A")                                            # ... even if it looks like bases
+    if n:
+        t[:n] = torch.frombuffer(bytearray(stream_bytes), dtype=torch.uint8).cuda()
+    g.add_stream_dev(0, t, n)
+    g.sync()
+    return g
+
+
+@pytest.mark.parametrize("k", list(range(3, 64, 2)))
+def test_every_odd_k(mcx, orc, k):
+    rng = np.random.default_rng(k)
+    s = bytes(rng.choice(np.frombuffer(b"ACGTACGTACGTacgtN\n", np.uint8), 6000))
+    og, st, want = _oracle_body(orc, k, s)
+    g = _gpu_stream(mcx, k, s, defer=k % 4 == 1)
+    assert g.export(True) == want
+    d = g.device_stats()
+    assert (d.num_kmers_loaded, d.contigs_parsed, d.total_bases_loaded) == (st.num_kmers_loaded, st.contigs_parsed, st.total_bases_loaded)
+    g.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_arbitrary_bytes_and_ragged_lengths(mcx, orc, seed):
+    rng = np.random.default_rng(100 + seed)
+    alphabet = np.concatenate([np.frombuffer(b"ACGT" * 40 + b"acgtNn\n\r\t @+>", np.uint8), rng.integers(0, 256, 30).astype(np.uint8)])
+    for n in (0, 1, 30, 31, 32, 4095, 4096, 4097, 4096 + 15, 8192 + 33, 50001):
+        s = bytes(rng.choice(alphabet, n)) if n else b""
+        for k in (31, 63, 5):
+            og, st, want = _oracle_body(orc, k, s)
+            for defer in (0, 1):
+                g = _gpu_stream(mcx, k, s, defer)
+                assert g.export(True) == want, (n, k, defer)
+                assert g.device_stats().num_kmers_loaded == st.num_kmers_loaded
+                g.close()
+
+
+def test_stream_boundaries_are_separators(mcx, orc):
+    """A k-mer must never span two add_stream_dev calls, nor read beyond nbytes."""
+    import torch
+    a, b = b"ACGT" * 20, b"TTGCA" * 20
+    og = orc.Graph(31, 1, 1 << 16)
+    bases, offs = orc.pack_reads([a, b])
+    og.add_reads(0, bases, offs)
+    want = og.ctx_bytes(True)[og.header_size():]
+    buf = torch.frombuffer(bytearray(a + b + b"ACGT" * 16), dtype=torch.uint8).cuda()
+    g = mcx.Graph(31, 1, 1 << 16)
+    pad = torch.zeros(16 * 20, dtype=torch.uint8, device="cuda")
+    pad[:len(b) + 64] = buf[len(a):len(a) + len(b) + 64]   # 16-byte aligned copy of the second read + trailing bases
+    g.add_stream_dev(0, buf, len(a))
+    g.add_stream_dev(0, pad, len(b))
+    assert g.export(True) == want
+    g.close()
