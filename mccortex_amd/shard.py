@@ -25,7 +25,10 @@ def exchange(send_keys, send_edges, counts, group=None):
     # Messages are cut into rounds of at most MAX_ROUND tuples per peer: RCCL (2.26, ROCm 7.0)
     # was observed to deliver only part of an all-to-all message larger than ~1 GB
     # (tools/dbg_shard3.py), and bounded rounds also bound the staging RCCL needs.
-    for r0 in range(0, max(max(sc), max(rc), 1), MAX_ROUND):
+    # every rank must run the same number of rounds: agree on the largest per-peer message
+    gmax = torch.tensor([max(max(sc), max(rc), 1)], dtype=torch.int64, device=counts.device)
+    dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    for r0 in range(0, int(gmax.item()), MAX_ROUND):
         s_lo = [min(c, r0) for c in sc]
         s_hi = [min(c, r0 + MAX_ROUND) for c in sc]
         r_lo = [min(c, r0) for c in rc]

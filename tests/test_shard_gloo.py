@@ -27,6 +27,7 @@ def _worker(rank, world, port, k, tmpdir):
     import mccortex_amd as mcx
     from mccortex_amd import shard
     from oracle import orc
+    shard.MAX_ROUND = 30000   # several rounds; per-rank counts differ, the round count must not
     g = synth.genome(20000, 1)
     bases, offs = synth.reads(1500, 100, seed=100 + rank, g=g, n_frac=0.05)
     keys, edges = orc.tuples(k, bases, offs)
