@@ -75,8 +75,7 @@ struct mcx_graph {
   uint32_t b1 = 0, subs_per_bin = 0;
   uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 (replica, bin) segment / per L2 (sub-table) bin
   uint32_t rep1 = 8;            // replicas of every L1 bin (one per XCD)
-  uint64_t *l1_keys = nullptr, *l2_keys = nullptr;
-  uint8_t *l1_edges = nullptr, *l2_edges = nullptr;
+  uint64_t *l1_keys = nullptr, *l2_keys = nullptr;  // packed tuples: W words each
   unsigned long long *l1_cnt = nullptr, *l2_cnt = nullptr;
   uint64_t pending = 0;         // upper bound of tuples sitting in the L1 bins
   int pending_colour = 0;
@@ -136,11 +135,18 @@ extern "C" int mcx_graph_create(mcx_graph **out, int kmer_size, int ncols, uint6
   g->W = words_for_k(kmer_size);
   g->ncols = ncols;
   g->device = device;
-  uint64_t slots = std::max<uint64_t>(capacity_kmers, 1024);
-  slots = (slots + kSubSlots - 1) / kSubSlots * kSubSlots;  // whole sub-tables
-  if (slots / kBucket > 0xFFFFFFFFull) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }
+  // geometry of the quotient-hashed table: 2^lb1 regions x spb sub-tables x 4096 slots
+  uint64_t nsub = (std::max<uint64_t>(capacity_kmers, 1024) + kSubSlots - 1) / kSubSlots;
+  uint32_t lb1 = 0;
+  while (lb1 < 9 && (2ull << lb1) <= nsub) lb1++;                 // up to 512 regions ...
+  while (lb1 < 11 && ((nsub + (1ull << lb1) - 1) >> lb1) > (uint64_t)kMaxBins) lb1++;  // ... more for huge tables
+  const uint64_t spb = (nsub + (1ull << lb1) - 1) >> lb1;
+  nsub = spb << lb1;
+  if (nsub >= (1ull << 31)) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }
+  const uint64_t slots = nsub * kSubSlots;
   g->t.nslots = slots;
-  g->t.nbuckets = (uint32_t)(slots / kBucket);
+  g->t.lb1 = lb1;
+  g->t.spb = (uint32_t)spb;
   g->t.S = (uint32_t)(g->W + ncols);
   g->t.max_probe = (uint32_t)kSubSlots;  // a probe sequence never leaves its sub-table
   { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
@@ -266,7 +272,7 @@ template <int W, bool ONECOL> static void launch_direct_t(mcx_graph *g, const St
                      g->stream, a, is);
 }
 
-template <int W, bool ONECOL>
+template <int W, bool ONECOL, bool FULL>
 static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour, BinSpec bs, BinOut out)
 {
   const StreamArgs a = make_args(g, L);
@@ -275,19 +281,19 @@ static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour,
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
   static bool once = false;
   if (!once) {
-    allow_lds(k_stream_bin<W, ONECOL, 512>, sizeof(BinLds<W, 512>));
-    allow_lds(k_stream_bin<W, ONECOL, kMaxBins>, sizeof(BinLds<W, kMaxBins>));
+    allow_lds(k_stream_bin<W, ONECOL, 512, FULL>, sizeof(BinLds<W, 512, FULL>));
+    allow_lds(k_stream_bin<W, ONECOL, kMaxBins, FULL>, sizeof(BinLds<W, kMaxBins, FULL>));
     once = true;
   }
   SpanGuard sp(g, "k_stream_bin");
   const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
   if (bs.nlocal <= 512)
-    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512>), grid, dim3(kThreads), sizeof(BinLds<W, 512>), g->stream, a, bs, out, is);
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL>), grid, dim3(kThreads), sizeof(BinLds<W, 512, FULL>), g->stream, a, bs, out, is);
   else
-    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins>), g->stream, a, bs, out, is);
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins, FULL>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, FULL>), g->stream, a, bs, out, is);
 }
 
-template <int W, bool ONECOL>
+template <int W, bool ONECOL, bool IN_FULL>
 static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
 {
   const uint64_t nchunks = (in.seg_cap + kTile - 1) / kTile * in.nseg;
@@ -295,24 +301,30 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
   static bool once = false;
   if (!once) {
-    allow_lds(k_tuples_bin<W, ONECOL, 512>, sizeof(BinLds<W, 512>));
-    allow_lds(k_tuples_bin<W, ONECOL, kMaxBins>, sizeof(BinLds<W, kMaxBins>));
+    allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL>, sizeof(BinLds<W, 512, false>));
+    allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL>, sizeof(BinLds<W, kMaxBins, false>));
     once = true;
   }
   SpanGuard sp(g, "k_tuples_bin");
   const dim3 grid((unsigned)std::min<uint64_t>(nchunks, (uint64_t)g->grid * 4));
   if (bs.nlocal <= 512)
-    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512>), grid, dim3(kThreads), sizeof(BinLds<W, 512>), g->stream, in, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL>), grid, dim3(kThreads), sizeof(BinLds<W, 512, false>), g->stream, in, bs, out, is, g->d_ctr);
   else
-    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, kMaxBins>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins>), g->stream, in, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, false>), g->stream, in, bs, out, is, g->d_ctr);
 }
+template <int W, bool ONECOL> static void launch_bin_region_stream(mcx_graph *g, const StreamLaunch &L, int colour, BinSpec bs, BinOut out)
+{ launch_bin_stream_t<W, ONECOL, false>(g, L, colour, bs, out); }
+template <int W, bool ONECOL> static void launch_split_regions(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
+{ launch_bin_tuples_t<W, ONECOL, false>(g, in, colour, bs, out); }
+template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
+{ launch_bin_tuples_t<W, ONECOL, true>(g, in, colour, bs, out); }
 
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour)
 {
   const size_t lds = kSubSlots * (W + 1) * 8;
   static bool once = false;
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
-  BinOut bins{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
+  BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2};
   SpanGuard sp(g, "k_lds_insert");
   hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(g->nsub, (uint64_t)g->grid * 4)),
                      dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
@@ -330,9 +342,9 @@ static void launch_insert_tuples_t(mcx_graph *g, int colour, const uint64_t *key
 // ---- deferred path bookkeeping -------------------------------------------------------------
 static void free_defer(mcx_graph *g)
 {
-  (void)hipFree(g->l1_keys); (void)hipFree(g->l1_edges); (void)hipFree(g->l1_cnt);
-  (void)hipFree(g->l2_keys); (void)hipFree(g->l2_edges); (void)hipFree(g->l2_cnt);
-  g->l1_keys = g->l2_keys = nullptr; g->l1_edges = g->l2_edges = nullptr; g->l1_cnt = g->l2_cnt = nullptr;
+  (void)hipFree(g->l1_keys); (void)hipFree(g->l1_cnt);
+  (void)hipFree(g->l2_keys); (void)hipFree(g->l2_cnt);
+  g->l1_keys = g->l2_keys = nullptr; g->l1_cnt = g->l2_cnt = nullptr;
   g->cap1 = g->cap2 = 0;
 }
 
@@ -340,11 +352,10 @@ static int ensure_defer(mcx_graph *g)
 {
   if (g->l1_keys) return MCX_OK;
   g->nsub = (uint32_t)(g->t.nslots >> kSubShift);
-  g->b1 = std::min<uint32_t>(g->nsub, 512);
-  g->subs_per_bin = (g->nsub + g->b1 - 1) / g->b1;
-  if (g->subs_per_bin > (uint32_t)kMaxBins) { g->b1 = 1024; g->subs_per_bin = (g->nsub + 1023) / 1024; }
-  if (g->subs_per_bin > (uint32_t)kMaxBins) { g->defer = false; return MCX_OK; }  // > 2^33 slots: direct path
-  g->b1 = (g->nsub + g->subs_per_bin - 1) / g->subs_per_bin;
+  g->b1 = 1u << g->t.lb1;        // L1 bins = regions of the quotient hash
+  g->subs_per_bin = g->t.spb;
+  // packed tuples need 2k - lb1 <= 56 quotient bits in the top word, and the histograms must fit
+  if (g->t.lb1 < 6 || g->b1 > (uint32_t)kMaxBins || g->subs_per_bin > (uint32_t)kMaxBins) { g->defer = false; return MCX_OK; }
   uint64_t tcap = g->defer_tuples;
   if (!tcap) {
     const char *e = getenv("MCX_DEFER_TUPLES");
@@ -360,10 +371,8 @@ static int ensure_defer(mcx_graph *g)
     if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) continue;
     const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
     const bool ok = hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W) == hipSuccess &&
-                    hipMalloc((void **)&g->l1_edges, n1) == hipSuccess &&
                     hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * g->rep1 * 8) == hipSuccess &&
                     hipMalloc((void **)&g->l2_keys, n2 * 8 * g->W) == hipSuccess &&
-                    hipMalloc((void **)&g->l2_edges, n2) == hipSuccess &&
                     hipMalloc((void **)&g->l2_cnt, (size_t)g->nsub * 8) == hipSuccess;
     if (ok) break;
     free_defer(g);
@@ -379,10 +388,10 @@ static int flush_deferred(mcx_graph *g)
 {
   if (!g->pending) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
-  TupleIn in{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1, g->b1 * g->rep1};
-  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, g->subs_per_bin, 1, g->nsub, g->b1, 0};
-  BinOut out{g->l2_keys, g->l2_edges, g->l2_cnt, g->cap2};
-  DISPATCH_WC(g, launch_bin_tuples_t, g, in, g->pending_colour, bs, out);
+  TupleIn in{g->l1_keys, nullptr, g->l1_cnt, g->cap1, g->b1 * g->rep1};
+  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1};
+  BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2};
+  DISPATCH_WC(g, launch_split_regions, g, in, g->pending_colour, bs, out);
   HIP_TRY(hipGetLastError());
   DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour);
   HIP_TRY(hipGetLastError());
@@ -420,10 +429,9 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     if (rc != MCX_OK) return rc;
     StreamLaunch P = L;
     P.pos_lo = lo; P.pos_hi = hi;
-    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1,
-               (uint64_t)g->b1 * g->subs_per_bin == g->nsub ? g->b1 : 0u};
-    BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
-    DISPATCH_WC(g, launch_bin_stream_t, g, P, colour, bs, out);
+    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1};
+    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1};
+    DISPATCH_WC(g, launch_bin_region_stream, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
     g->pending += hi - lo;
     lo = hi;
@@ -505,10 +513,10 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  BinSpec bs{BIN_OWNER, (uint32_t)nparts, 1, (uint32_t)nparts, 1, (uint32_t)nparts, 1, 0};
+  BinSpec bs{BIN_OWNER, (uint32_t)nparts, (uint32_t)nparts, 1, (uint32_t)nparts, 1};
   BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity};
-  if (g->W == 1) launch_bin_stream_t<1, true>(g, L, 0, bs, out);
-  else launch_bin_stream_t<2, true>(g, L, 0, bs, out);
+  if (g->W == 1) launch_bin_stream_t<1, true, true>(g, L, 0, bs, out);
+  else launch_bin_stream_t<2, true, true>(g, L, 0, bs, out);
   HIP_TRY(hipGetLastError());
   return MCX_OK;
 }
@@ -530,10 +538,9 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
     int rc = defer_reserve(g, colour, cnt);
     if (rc != MCX_OK) return rc;
     TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1};
-    BinSpec bs{BIN_GROUP, 0, g->subs_per_bin, g->b1, g->rep1, g->b1, 1,
-               (uint64_t)g->b1 * g->subs_per_bin == g->nsub ? g->b1 : 0u};
-    BinOut out{g->l1_keys, g->l1_edges, g->l1_cnt, g->cap1};
-    DISPATCH_WC(g, launch_bin_tuples_t, g, in, colour, bs, out);
+    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1};
+    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1};
+    DISPATCH_WC(g, launch_bin_received, g, in, colour, bs, out);
     HIP_TRY(hipGetLastError());
     g->pending += cnt;
     lo += cnt;

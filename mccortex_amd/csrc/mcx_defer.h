@@ -6,15 +6,18 @@
 // Infinity Cache) -- profiles/r01_ubench_atomics*.log.  The fused kernel already runs at that
 // ceiling, so the only way past it is to stop issuing one HBM atomic per k-mer occurrence:
 //
-//   1. k_stream_bin      k-merise reads, radix-partition the per-occurrence tuples
-//                        (key words + edge byte) by table region into L1 bins      (streaming)
+//   1. k_stream_bin      k-merise reads, radix-partition the per-occurrence tuples by table
+//                        region (the 2^lb1 "L1 bins" of the quotient hash)         (streaming)
 //   2. k_tuples_bin      split every L1 bin by sub-table (4096 slots) into L2 bins  (streaming)
 //   3. k_lds_insert      one workgroup per sub-table: slice -> LDS, apply its tuples with
 //                        LDS atomics (find-or-insert, coverage +1, edge OR), slice -> HBM
 //
-// All HBM traffic is coalesced streaming; tuples that do not fit a bin (hot k-mers, skew)
-// fall back to the lock-free direct insert of mcx_kernels.h, so no input can overflow.
-// The same binning kernels with BIN_OWNER produce the per-GPU bins of the sharded build.
+// Inside the bins an occurrence is ONE 64-bit word per key word: the quotient q of the key
+// (mcx_kernels.h, "Table addressing") with the edge byte in bits 56..63 of the top word; the
+// remainder r is implied by the region the tuple sits in.  All HBM traffic is coalesced
+// streaming; tuples that do not fit a bin (hot k-mers, skew) fall back to the lock-free direct
+// insert of mcx_kernels.h, so no input can overflow.  The same binning kernel with BIN_OWNER
+// produces the per-GPU bins of the sharded build (full keys + edge bytes, the exchange format).
 #pragma once
 #include "mcx_kernels.h"
 
@@ -25,7 +28,6 @@ enum : int { BIN_OWNER = 0, BIN_GROUP = 1, BIN_SUBLOCAL = 2 };
 struct BinSpec {
   int mode;
   uint32_t nparts;  // BIN_OWNER: number of owners
-  uint32_t div;     // BIN_GROUP: sub-tables per L1 bin; BIN_SUBLOCAL: sub-tables per input segment
   uint32_t nlocal;  // bins a block can meet (size of the LDS histogram), <= kMaxBins
   // Output replication (replica-major): every output bin exists `rep` times (own counter, own
   // storage) and a block appends to replica blockIdx % rep.  All blocks reserving from the same
@@ -35,25 +37,33 @@ struct BinSpec {
   // which merges the 8-tuple runs into full-line write-backs (speed only, never correctness).
   uint32_t rep;
   uint32_t nout;     // output bins per replica
-  uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s belongs to L1 bin s % seg_mod
-  // BIN_GROUP fast path: when the sub-tables divide evenly into the L1 bins,
-  // bin = floor(floor(h * nbuckets / 2^32) / (buckets per bin)) = mulhi(h, nbins): one instruction
-  // instead of a 32-bit division per tuple
-  uint32_t mulhi_bins;  // 0 = use the division
+  uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s holds region s % seg_mod
 };
 
+// Output bins.  Packed format (deferred path): `keys` holds W words per tuple, `edges` unused.
+// Full format (owner bins): W key words + one edge byte per tuple.
 struct BinOut {
   uint64_t *keys;              // [rep][nbins][cap][W]
-  uint8_t *edges;              // [rep][nbins][cap]
+  uint8_t *edges;              // [rep][nbins][cap] (full format only)
   unsigned long long *counts;  // [rep][nbins] fill (may exceed cap: the excess went to the fallback)
   uint64_t cap;                // tuples per (replica, bin) segment
 };
 
 constexpr int kMaxBins = 2048;
+constexpr uint64_t kQMask = (1ull << 56) - 1;  // quotient bits of the top tuple word
 
-__device__ __forceinline__ uint32_t sub_of(const TableView &t, uint32_t h)
+// pack / unpack a tuple of the deferred path
+template <int W> __device__ __forceinline__ Kmer<W> tuple_pack(const Kmer<W> &q, uint32_t e)
 {
-  return (uint32_t)(bucket_slot(t, h) >> kSubShift);
+  Kmer<W> t = q;
+  t.w[0] |= (uint64_t)e << 56;
+  return t;
+}
+template <int W> __device__ __forceinline__ Kmer<W> tuple_q(const Kmer<W> &t)
+{
+  Kmer<W> q = t;
+  q.w[0] &= kQMask;
+  return q;
 }
 
 // The sorted tile is staged and written out in kRounds rounds of kStage tuples: the staging
@@ -65,31 +75,14 @@ constexpr int kRounds = MCX_ROUNDS;
 constexpr int kStage = kTile / kRounds;
 
 // LDS working set of one binning block (NB = histogram capacity)
-template <int W, int NB> struct BinLds {
+template <int W, int NB, bool FULL> struct BinLds {
   uint64_t skey[kStage * W];
+  unsigned long long gbase[NB];  // where this tile's run of every bin starts in its segment
   uint32_t cnt[NB];
   uint32_t off[NB + 4];
-  uint32_t base[NB];  // bin capacities are < 2^32 tuples (checked by the host)
   uint16_t sbin[kStage];
-  uint8_t se[kStage];
+  uint8_t se[FULL ? kStage : 16];
 };
-
-// bin index inside the block's histogram, and output bin, of a tuple
-__device__ __forceinline__ void bin_of(const BinSpec &bs, const TableView &t, uint32_t h, uint32_t h2,
-                                       uint32_t seg, uint32_t &local, uint32_t &outbin)
-{
-  if (bs.mode == BIN_OWNER) {
-    local = outbin = owner_of(h2, bs.nparts);
-  } else {
-    if (bs.mode == BIN_GROUP) {
-      local = outbin = bs.mulhi_bins ? __umulhi(h, bs.mulhi_bins) : sub_of(t, h) / bs.div;
-    } else {  // `seg` here is the first sub-table of the segment's L1 bin (hoisted by the caller)
-      const uint32_t sub = sub_of(t, h);
-      local = sub - seg;
-      outbin = sub;
-    }
-  }
-}
 
 // After the counting sweep: exclusive scan of the histogram (wave 0), then every thread issues
 // the global reservations of its bins (one returning atomic per non-empty bin).  The results
@@ -97,9 +90,8 @@ __device__ __forceinline__ void bin_of(const BinSpec &bs, const TableView &t, ui
 // round trip overlaps with it; bin_commit() publishes the bases before the write-out.
 template <int NB> struct BinRes { unsigned long long g0[(NB + kThreads - 1) / kThreads]; };
 
-template <int W, int NB>
-__device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs, const BinOut &out, uint32_t seg,
-                                            BinRes<NB> &res)
+template <class LDS, int NB>
+__device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, BinRes<NB> &res)
 {
   const int tid = threadIdx.x;
   __syncthreads();
@@ -120,107 +112,110 @@ __device__ __forceinline__ void bin_reserve(BinLds<W, NB> &L, const BinSpec &bs,
     if (tid == 0) L.off[bs.nlocal] = carry;
   }
   __syncthreads();
-  const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div : 0) + (blockIdx.x % bs.rep) * bs.nout;
 #pragma unroll
   for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
     const uint32_t b = (uint32_t)q * kThreads + tid;
     res.g0[q] = 0;
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
-      const uint32_t ob = ob0 + b;
-      if (c) res.g0[q] = atomicAdd(&out.counts[ob], (unsigned long long)c);
+      if (c) res.g0[q] = atomicAdd(&out.counts[ob0 + b], (unsigned long long)c);
       L.cnt[b] = 0;
     }
   }
   __syncthreads();
 }
 
-template <int W, int NB>
-__device__ __forceinline__ void bin_commit(BinLds<W, NB> &L, const BinSpec &bs, const BinRes<NB> &res)
+template <class LDS, int NB>
+__device__ __forceinline__ void bin_commit(LDS &L, const BinSpec &bs, const BinRes<NB> &res)
 {
 #pragma unroll
   for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
     const uint32_t b = (uint32_t)q * kThreads + threadIdx.x;
-    // saturated == beyond any capacity
-    if (b < bs.nlocal) L.base[b] = res.g0[q] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)res.g0[q];
+    if (b < bs.nlocal) L.gbase[b] = res.g0[q];
   }
 }
 
 // Sorted position of a tuple inside the tile (taken once, kept in a register)
-template <int W, int NB>
-__device__ __forceinline__ uint32_t bin_rank(BinLds<W, NB> &L, uint32_t local)
+template <class LDS> __device__ __forceinline__ uint32_t bin_rank(LDS &L, uint32_t local)
 {
   return L.off[local] + atomicAdd(&L.cnt[local], 1u);
 }
 
 // Placement: drop a tuple at its sorted position if that position belongs to this round
-template <int W, int NB>
-__device__ __forceinline__ void bin_place(BinLds<W, NB> &L, int round, uint32_t p, uint32_t local,
-                                          const Kmer<W> &key, uint32_t e)
+template <int W, bool FULL, class LDS>
+__device__ __forceinline__ void bin_place(LDS &L, int round, uint32_t p, uint32_t local, const Kmer<W> &t, uint32_t e)
 {
   if ((int)(p / kStage) != round) return;
   const uint32_t q = p % kStage;
-  L.skey[q * W] = key.w[0];
-  if (W == 2) L.skey[q * W + 1] = key.w[W - 1];
+  L.skey[q * W] = t.w[0];
+  if (W == 2) L.skey[q * W + 1] = t.w[W - 1];
   L.sbin[q] = (uint16_t)local;
-  L.se[q] = (uint8_t)e;
+  if (FULL) L.se[q] = (uint8_t)e;
 }
 
 // Linear write-out of one round: consecutive lanes write consecutive tuples of a bin.  Tuples
-// beyond a bin's capacity take the direct insert (deferred modes) or raise bin_over (owner mode).
-template <int W, bool ONECOL, int NB>
-__device__ __forceinline__ void bin_writeout(BinLds<W, NB> &L, int round, const BinSpec &bs, const BinOut &out,
-                                             uint32_t seg, const InsertSink<W, ONECOL> &isink, uint32_t &novel,
-                                             uint32_t &full)
+// beyond a bin's capacity take the direct insert (deferred modes; the region of a packed tuple
+// is its bin in BIN_GROUP and `region_of_seg` in BIN_SUBLOCAL) or raise bin_over (owner mode).
+template <int W, bool ONECOL, bool FULL, class LDS>
+__device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &bs, const BinOut &out, uint32_t ob0,
+                                             uint32_t region_of_seg, const InsertSink<W, ONECOL> &isink,
+                                             uint32_t &novel, uint32_t &full)
 {
   __syncthreads();
   const uint32_t n = L.off[bs.nlocal];
   const uint32_t lo = (uint32_t)round * kStage;
   const uint32_t cnt = n > lo ? min(n - lo, (uint32_t)kStage) : 0;
-  const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div : 0) + (blockIdx.x % bs.rep) * bs.nout;
   for (uint32_t q = threadIdx.x; q < cnt; q += kThreads) {
-    const uint32_t p = lo + q;
     const uint32_t b = L.sbin[q];
-    const uint64_t gpos = (uint64_t)L.base[b] + (p - L.off[b]);
-    const uint32_t ob = ob0 + b;
+    const uint64_t gpos = L.gbase[b] + ((lo + q) - L.off[b]);
     if (gpos < out.cap) {
-      uint64_t *kd = out.keys + ((uint64_t)ob * out.cap + gpos) * W;
+      const uint64_t at = (uint64_t)(ob0 + b) * out.cap + gpos;
+      uint64_t *kd = out.keys + at * W;
       kd[0] = L.skey[q * W];
       if (W == 2) kd[1] = L.skey[q * W + 1];
-      out.edges[(uint64_t)ob * out.cap + gpos] = L.se[q];
+      if (FULL) out.edges[at] = L.se[q];
     } else if (bs.mode == BIN_OWNER) {
       full = 2;
-    } else {
-      Kmer<W> key;
-      key.w[0] = L.skey[q * W];
-      if (W == 2) key.w[W - 1] = L.skey[q * W + 1];
-      const uint32_t h = kmer_hash<W>(key, 0, nullptr);
-      const uint64_t slot = bucket_slot(isink.t, h);
+    } else {  // packed tuple -> full key -> lock-free insert into the HBM table
+      Kmer<W> tq;
+      tq.w[0] = L.skey[q * W];
+      if (W == 2) tq.w[W - 1] = L.skey[q * W + 1];
+      const uint32_t e = (uint32_t)(tq.w[0] >> 56);
+      const Kmer<W> qq = tuple_q<W>(tq);
+      const uint32_t region = bs.mode == BIN_GROUP ? b : region_of_seg;
+      uint32_t hb;
+      const uint32_t c = kmer_hash<W>(qq, 0, &hb);
+      const uint32_t r = region ^ (c & ((1u << isink.t.lb1) - 1u));
+      const Kmer<W> key = key_unquot<W>(qq, isink.t.lb1, r);
+      const uint64_t slot = key_slot<W>(isink.t, key);
       const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
       const uint64_t cur = isink.t.rec[slot * S];
-      probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, L.se[q], isink.col, novel, full);
+      probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
     }
   }
   if (round + 1 < kRounds) __syncthreads();  // staging is reused by the next round
 }
 
 // ---------------------------------------------------------------------------
-// 1. reads -> bins
+// 1. reads -> bins.  FULL = owner bins (key words + edge byte, nparts bins);
+//    !FULL = region bins of the local table (packed tuples)
 // ---------------------------------------------------------------------------
-template <int W, bool ONECOL, int NB>
+template <int W, bool ONECOL, int NB, bool FULL>
 __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
-                                                         InsertSink<W, ONECOL> isink)
+                                                                         InsertSink<W, ONECOL> isink)
 {
   __shared__ uint32_t s_code[kChunks + 4];
   __shared__ uint32_t s_inv[kChunks / 2 + 4];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  BinLds<W, NB> &L = *reinterpret_cast<BinLds<W, NB> *>(dyn_lds);
+  using LDS = BinLds<W, NB, FULL>;
+  LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
 
   const int tid = threadIdx.x;
   const int k = a.k;
   uint32_t n_kmers = 0, n_contigs = 0, n_novel = 0, full = 0;
   const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
   const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);
+  const uint32_t ob0 = (blockIdx.x % bs.rep) * bs.nout;
 
   // the chunks of the NEXT tile are fetched into registers while the current one is processed
   uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
@@ -273,8 +268,8 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
 
     // One pass over the lane's 16 positions: the tuples stay in registers (static indices
     // after unrolling) while the block histograms, reserves and then places them.
-    Kmer<W> tk[kPosPerLane];
-    uint32_t tle[kPosPerLane];  // local bin << 8 | edge byte
+    Kmer<W> tk[kPosPerLane];    // FULL: canonical key; packed: quotient | edges << 56
+    uint32_t tle[kPosPerLane];  // edge byte (FULL) | local bin << 8 | sorted position << 19
     uint32_t vmask = 0;
     if (any) {
       Kmer<W> fw, rc;
@@ -299,14 +294,25 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
         tle[j] = 0;
         tk[j] = fw;
         if (valid) {
-          uint32_t o, h2, local, ob;
-          tk[j] = canonical<W>(fw, rc, o);
-          const uint32_t h = kmer_hash<W>(tk[j], 0, &h2);
-          bin_of(bs, isink.t, h, h2, 0, local, ob);
+          uint32_t o, local;
+          const Kmer<W> key = canonical<W>(fw, rc, o);
           uint32_t e = 0;
           if (next_ok) e |= 1u << (nuc_next + 4u * o);
           if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
-          tle[j] = (local << 8) | e;
+          if (FULL) {
+            uint32_t h2;
+            kmer_hash<W>(key, 0, &h2);
+            local = owner_of(h2, bs.nparts);
+            tk[j] = key;
+            tle[j] = (local << 8) | e;
+          } else {
+            uint32_t r, hb;
+            const Kmer<W> q = key_quot<W>(key, isink.t.lb1, r);
+            const uint32_t c = kmer_hash<W>(q, 0, &hb);
+            local = r ^ (c & ((1u << isink.t.lb1) - 1u));  // region of the key
+            tk[j] = tuple_pack<W>(q, e);
+            tle[j] = local << 8;
+          }
           vmask |= 1u << j;
           atomicAdd(&L.cnt[local], 1u);
           n_kmers++;
@@ -325,16 +331,17 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
       }
     }
     BinRes<NB> res;
-    bin_reserve<W, NB>(L, bs, out, 0, res);
+    bin_reserve<LDS, NB>(L, bs, out, ob0, res);
 #pragma unroll
     for (int j = 0; j < kPosPerLane; j++)  // sorted position goes into bits 19..30 of tle
-      if (vmask & (1u << j)) tle[j] |= bin_rank<W, NB>(L, (tle[j] >> 8) & 0x7ffu) << 19;
-    bin_commit<W, NB>(L, bs, res);
+      if (vmask & (1u << j)) tle[j] |= bin_rank<LDS>(L, (tle[j] >> 8) & 0x7ffu) << 19;
+    bin_commit<LDS, NB>(L, bs, res);
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
-        if (vmask & (1u << j)) bin_place<W, NB>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], tle[j] & 0xffu);
-      bin_writeout<W, ONECOL, NB>(L, round, bs, out, 0, isink, n_novel, full);
+        if (vmask & (1u << j))
+          bin_place<W, FULL, LDS>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], tle[j] & 0xffu);
+      bin_writeout<W, ONECOL, FULL, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
     }
   }
 
@@ -347,28 +354,32 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
 }
 
 // ---------------------------------------------------------------------------
-// 2. tuples -> bins (L2 split of the L1 bins; L1 binning of tuples received from other GPUs)
+// 2. tuples -> bins.
+//    IN_FULL  (tuples received from other GPUs: keys + edge bytes) -> region bins, BIN_GROUP
+//    !IN_FULL (packed tuples of the region bins)                    -> sub-table bins, BIN_SUBLOCAL
+//    Output is always packed.
 // ---------------------------------------------------------------------------
 struct TupleIn {
   const uint64_t *keys;              // [nseg][seg_cap][W]
-  const uint8_t *edges;              // [nseg][seg_cap]
+  const uint8_t *edges;              // [nseg][seg_cap] (IN_FULL only)
   const unsigned long long *counts;  // [nseg] or nullptr (every segment holds seg_cap tuples)
   uint64_t seg_cap;
   uint32_t nseg;
 };
 
-template <int W, bool ONECOL, int NB>
+template <int W, bool ONECOL, int NB, bool IN_FULL>
 __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
-                                                         InsertSink<W, ONECOL> isink, Counters *ctr)
+                                                                         InsertSink<W, ONECOL> isink, Counters *ctr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  BinLds<W, NB> &L = *reinterpret_cast<BinLds<W, NB> *>(dyn_lds);
+  using LDS = BinLds<W, NB, false>;
+  LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
   const uint64_t chunks_per_seg = (in.seg_cap + kTile - 1) / kTile;
-  // Work order.  Blocks that run at the same time must not all split the same L1 bin: they
+  // Work order.  Blocks that run at the same time must not all split the same region: they
   // would reserve from the same 64 counter lines (~12 ns per same-line atomic).  So chunks are
-  // taken segment-interleaved, and -- XCD-aware -- block x only takes L1 bins b with
+  // taken segment-interleaved, and -- XCD-aware -- block x only takes regions b with
   // b % 8 == x % 8: with the observed block -> XCD round-robin every sub-table bin is then
   // written from one XCD, whose L2 merges the 8-tuple runs into full lines (speed only).
   const bool xcd = bs.mode == BIN_SUBLOCAL && gridDim.x % 8 == 0 && bs.seg_mod % 8 == 0 && in.nseg % bs.seg_mod == 0;
@@ -376,11 +387,12 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
   const uint32_t nseg_g = xcd ? in.nseg / 8 : in.nseg;  // segments this block may take
   const uint64_t nchunks = chunks_per_seg * nseg_g;
   const uint64_t v0 = xcd ? blockIdx.x / 8 : blockIdx.x, vstep = xcd ? gridDim.x / 8 : gridDim.x;
+  const uint32_t lmask = (1u << isink.t.lb1) - 1u;
   for (uint64_t v = v0; v < nchunks; v += vstep) {
     const uint32_t sl = (uint32_t)(v % nseg_g);  // segment-interleaved
     uint32_t seg = sl;
     if (xcd) {
-      const uint32_t bins_g = bs.seg_mod / 8;  // L1 bins of this group
+      const uint32_t bins_g = bs.seg_mod / 8;  // regions of this group
       seg = (sl / bins_g) * bs.seg_mod + group + 8 * (sl % bins_g);  // replica-major segment index
     }
     const uint64_t start = (v / nseg_g) * kTile;
@@ -388,52 +400,61 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (start >= cnt) continue;  // uniform across the block
     const uint32_t n = (uint32_t)min((uint64_t)kTile, cnt - start);
-    const uint32_t seg_first = bs.mode == BIN_SUBLOCAL ? (seg % bs.seg_mod) * bs.div : 0;  // block-uniform
+    const uint32_t region = bs.mode == BIN_SUBLOCAL ? seg % bs.seg_mod : 0;  // block-uniform
+    const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? region * isink.t.spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
     __syncthreads();
     for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
     __syncthreads();
     const uint64_t *kin = in.keys + ((uint64_t)seg * in.seg_cap + start) * W;
-    const uint8_t *ein = in.edges + (uint64_t)seg * in.seg_cap + start;
+    const uint8_t *ein = IN_FULL ? in.edges + (uint64_t)seg * in.seg_cap + start : nullptr;
     // each lane keeps its kTile/kThreads tuples in registers: all loads are issued up front
     // (memory-level parallelism) and the placement sweep does not re-read HBM
     constexpr int PER = kTile / kThreads;
-    Kmer<W> key[PER];
-    uint32_t ev[PER], loc[PER];
+    Kmer<W> tk[PER];
+    uint32_t ev[IN_FULL ? PER : 1], loc[PER];
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       const uint32_t i = (uint32_t)q * kThreads + tid;
-      key[q].w[0] = 0; if (W == 2) key[q].w[W - 1] = 0;
-      ev[q] = 0;
+      tk[q].w[0] = 0; if (W == 2) tk[q].w[W - 1] = 0;
+      if (IN_FULL) ev[q] = 0;
       if (i < n) {
-        key[q].w[0] = kin[(uint64_t)i * W];
-        if (W == 2) key[q].w[W - 1] = kin[(uint64_t)i * W + 1];
-        ev[q] = ein[i];
+        tk[q].w[0] = kin[(uint64_t)i * W];
+        if (W == 2) tk[q].w[W - 1] = kin[(uint64_t)i * W + 1];
+        if (IN_FULL) ev[q] = ein[i];
       }
     }
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       const uint32_t i = (uint32_t)q * kThreads + tid;
-      uint32_t h2, ob;
-      const uint32_t h = kmer_hash<W>(key[q], 0, &h2);
-      bin_of(bs, isink.t, h, h2, seg_first, loc[q], ob);
+      uint32_t hb;
+      if (IN_FULL) {  // full key -> region, packed tuple
+        uint32_t r;
+        const Kmer<W> qq = key_quot<W>(tk[q], isink.t.lb1, r);
+        const uint32_t c = kmer_hash<W>(qq, 0, &hb);
+        loc[q] = r ^ (c & lmask);
+        tk[q] = tuple_pack<W>(qq, ev[q]);
+      } else {        // packed tuple of a known region -> sub-table inside the region
+        kmer_hash<W>(tuple_q<W>(tk[q]), 0, &hb);
+        loc[q] = __umulhi(hb, isink.t.spb);
+      }
       if (loc[q] >= bs.nlocal) loc[q] = bs.nlocal - 1;  // cannot happen for well-formed bins
       if (i < n) atomicAdd(&L.cnt[loc[q]], 1u);
     }
     BinRes<NB> res;
-    bin_reserve<W, NB>(L, bs, out, seg, res);
+    bin_reserve<LDS, NB>(L, bs, out, ob0, res);
 #pragma unroll
     for (int q = 0; q < PER; q++) {  // sorted position goes into the high half of loc
       const uint32_t i = (uint32_t)q * kThreads + tid;
-      if (i < n) loc[q] |= bin_rank<W, NB>(L, loc[q]) << 16;
+      if (i < n) loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
     }
-    bin_commit<W, NB>(L, bs, res);
+    bin_commit<LDS, NB>(L, bs, res);
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int q = 0; q < PER; q++) {
         const uint32_t i = (uint32_t)q * kThreads + tid;
-        if (i < n) bin_place<W, NB>(L, round, loc[q] >> 16, loc[q] & 0xffffu, key[q], ev[q]);
+        if (i < n) bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);
       }
-      bin_writeout<W, ONECOL, NB>(L, round, bs, out, seg, isink, n_novel, full);
+      bin_writeout<W, ONECOL, false, LDS>(L, round, bs, out, ob0, region, isink, n_novel, full);
     }
   }
   if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
@@ -451,14 +472,13 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
 template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? 512 : 1024; };
 constexpr int kLdsBatch = 4;
 
-// find-or-insert one tuple in the LDS-resident sub-table
+// find-or-insert one occurrence in the LDS-resident sub-table
 template <int W>
-__device__ __forceinline__ void lds_apply(unsigned long long *lds, const TableView &t, const Kmer<W> &key, uint32_t e,
+__device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W> &key, uint32_t bucket, uint32_t e,
                                           uint32_t &n_novel, uint32_t &full)
 {
   constexpr int R = W + 1;
-  const uint32_t h = kmer_hash<W>(key, 0, nullptr);
-  uint32_t slot = (uint32_t)(bucket_slot(t, h) & (kSubSlots - 1));
+  uint32_t slot = bucket * kBucket;
   const unsigned long long want = key.w[0] | kFlag;
   uint32_t probes = 0;
   for (;;) {
@@ -506,12 +526,14 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
   constexpr int R = W + 1;  // words per slot in LDS
   const int tid = threadIdx.x;
   const uint32_t S = ONECOL ? (uint32_t)(W + 1) : t.S;
+  const uint32_t lmask = (1u << t.lb1) - 1u;
   uint32_t n_novel = 0, full = 0;
 
   for (uint32_t sub = blockIdx.x; sub < nsub; sub += gridDim.x) {
     uint64_t n = bins.counts[sub];
     if (n == 0) continue;  // uniform
     if (n > bins.cap) n = bins.cap;
+    const uint32_t region = sub / t.spb;  // uniform
     uint64_t *slice = t.rec + (uint64_t)sub * kSubSlots * S;
     __syncthreads();
     constexpr int PER = (int)(kSubSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
@@ -535,22 +557,26 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
     __syncthreads();
 
     const uint64_t *kin = bins.keys + (uint64_t)sub * bins.cap * W;
-    const uint8_t *ein = bins.edges + (uint64_t)sub * bins.cap;
     for (uint64_t i0 = tid; i0 < n; i0 += (uint64_t)kLdsThreads * kLdsBatch) {
-      Kmer<W> key[kLdsBatch];
-      uint32_t e[kLdsBatch];
+      Kmer<W> tk[kLdsBatch];
 #pragma unroll
       for (int q = 0; q < kLdsBatch; q++) {
         const uint64_t i = i0 + (uint64_t)q * kLdsThreads;
         if (i < n) {
-          key[q].w[0] = kin[i * W];
-          if (W == 2) key[q].w[W - 1] = kin[i * W + 1];
-          e[q] = ein[i];
+          tk[q].w[0] = kin[i * W];
+          if (W == 2) tk[q].w[W - 1] = kin[i * W + 1];
         }
       }
 #pragma unroll
       for (int q = 0; q < kLdsBatch; q++)
-        if (i0 + (uint64_t)q * kLdsThreads < n) lds_apply<W>(lds, t, key[q], e[q], n_novel, full);
+        if (i0 + (uint64_t)q * kLdsThreads < n) {  // packed tuple + region -> full key, start bucket
+          const uint32_t e = (uint32_t)(tk[q].w[0] >> 56);
+          const Kmer<W> qq = tuple_q<W>(tk[q]);
+          uint32_t hb;
+          const uint32_t c = kmer_hash<W>(qq, 0, &hb);
+          const Kmer<W> key = key_unquot<W>(qq, t.lb1, region ^ (c & lmask));
+          lds_apply<W>(lds, key, (c >> t.lb1) & (kSubBuckets - 1), e, n_novel, full);
+        }
     }
     __syncthreads();
 

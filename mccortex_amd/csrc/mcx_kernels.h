@@ -32,13 +32,67 @@ constexpr int kBucket = 4;  // slots per hash bucket (64 B when S == 2)
 constexpr int kSubShift = 12;
 constexpr uint64_t kSubSlots = 1ull << kSubShift;
 
+constexpr uint32_t kSubBuckets = (uint32_t)(kSubSlots / kBucket);  // 1024 buckets per sub-table
+
 struct TableView {
   uint64_t *rec;
-  uint64_t nslots;    // multiple of kSubSlots
-  uint32_t nbuckets;  // nslots / kBucket
-  uint32_t S;         // words per record
+  uint64_t nslots;   // = (spb << lb1) sub-tables of kSubSlots slots
+  uint32_t lb1;      // log2 of the number of top-level regions ("L1 bins") of the table
+  uint32_t spb;      // sub-tables per region
+  uint32_t S;        // words per record
   uint32_t max_probe;
 };
+
+// ---------------------------------------------------------------------------
+// Table addressing: a quotient hash built on Lookup3
+// ---------------------------------------------------------------------------
+// key = (q << lb1) | r.  With (c, b) = lookup3(q) (the reference's bklk3 hash, both result
+// words):
+//     region  = r ^ (c & (2^lb1 - 1))            one Feistel round: uniform whatever r is
+//     sub     = region * spb + mulhi(b, spb)     sub-table
+//     bucket  = (c >> lb1) & 1023                start bucket inside the sub-table
+// Given the region, r = region ^ (c & mask) is recoverable from q alone, so a k-mer occurrence
+// that has been binned by region travels as q plus its edge byte in ONE 64-bit word per key
+// word (2k - lb1 <= 56 bits of q in the top word, edges in bits 56..63) -- mcx_defer.h.
+template <int W> __device__ __host__ __forceinline__ Kmer<W> key_quot(const Kmer<W> &key, uint32_t lb1, uint32_t &r)
+{
+  Kmer<W> q = key;
+  r = 0;
+  if (lb1) {
+    r = (uint32_t)key.w[W - 1] & ((1u << lb1) - 1u);
+    if (W == 2) q.w[W - 1] = (key.w[W - 1] >> lb1) | (key.w[0] << (64 - lb1));
+    q.w[0] = key.w[0] >> lb1;
+  }
+  return q;
+}
+template <int W> __device__ __host__ __forceinline__ Kmer<W> key_unquot(const Kmer<W> &q, uint32_t lb1, uint32_t r)
+{
+  Kmer<W> key = q;
+  if (lb1) {
+    key.w[0] = q.w[0] << lb1;
+    if (W == 2) { key.w[0] |= q.w[W - 1] >> (64 - lb1); key.w[W - 1] = q.w[W - 1] << lb1; }
+    key.w[W - 1] |= r;
+  }
+  return key;
+}
+struct TableAddr { uint32_t region, sub, bucket; };
+template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t, const Kmer<W> &q, uint32_t r)
+{
+  uint32_t b;
+  const uint32_t c = kmer_hash<W>(q, 0, &b);
+  TableAddr a;
+  a.region = r ^ (c & ((1u << t.lb1) - 1u));
+  a.sub = a.region * t.spb + __umulhi(b, t.spb);
+  a.bucket = (c >> t.lb1) & (kSubBuckets - 1);
+  return a;
+}
+template <int W> __device__ __forceinline__ uint64_t key_slot(const TableView &t, const Kmer<W> &key)
+{
+  uint32_t r;
+  const Kmer<W> q = key_quot<W>(key, t.lb1, r);
+  const TableAddr a = addr_of<W>(t, q, r);
+  return ((uint64_t)a.sub << kSubShift) + (uint64_t)a.bucket * kBucket;
+}
 
 struct Counters {  // device-resident, 64-bit each
   unsigned long long novel;     // nodes created (== hash_table num_kmers)
@@ -133,11 +187,6 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
   }
 }
 
-__device__ __forceinline__ uint64_t bucket_slot(const TableView &t, uint32_t h)
-{
-  return (((uint64_t)h * t.nbuckets) >> 32) * kBucket;
-}
-
 // Sink of the fused kernel: insert straight into the local table.
 template <int W, bool ONECOL> struct InsertSink {
   TableView t;
@@ -230,7 +279,7 @@ __device__ __forceinline__ void encode_chunk(const uint8_t *stream, uint64_t nby
 // One k-mer occurrence produced by the front end
 template <int W> struct Occ {
   Kmer<W> key;
-  uint32_t h, h2, e;
+  uint32_t e;
 };
 
 template <int W, bool ONECOL>
@@ -243,7 +292,7 @@ __device__ __forceinline__ void flush_batch(const InsertSink<W, ONECOL> &sink, c
   for (int i = 0; i < kBatch; i++) {  // issue all first probes before looking at any
     cur[i] = 0; hint[i] = 0; slot[i] = 0;
     if (ov[i]) {
-      slot[i] = bucket_slot(sink.t, occ[i].h);
+      slot[i] = key_slot<W>(sink.t, occ[i].key);
       const uint64_t *r = sink.t.rec + slot[i] * S;
       if (W == 1 && ONECOL) {
         const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(r);
@@ -341,7 +390,6 @@ __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a
             if (next_ok) e |= 1u << (nuc_next + 4u * o);
             if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
             x.e = e;
-            x.h = kmer_hash<W>(x.key, 0, &x.h2);
             n_kmers++;
             n_contigs += prev_ok ? 0u : 1u;
           }
@@ -392,7 +440,6 @@ __global__ __launch_bounds__(kThreads) void k_insert_tuples(InsertSink<W, ONECOL
         x.key.w[0] = keys[i * W];
         if (W == 2) x.key.w[W - 1] = keys[i * W + 1];
         x.e = edges[i];
-        x.h = kmer_hash<W>(x.key, 0, &x.h2);
       }
     }
     flush_batch<W, ONECOL>(sink, occ, ov, n_novel, full);
