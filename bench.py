@@ -32,7 +32,7 @@ ALG_BYTES_PER_NOVEL = 8.0    # key write when the node is new
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DEFER_TUPLES = 8_000_000_000  # k-mer occurrences buffered per flush of the partition->LDS-insert path
 # algorithmic bytes per k-mer occurrence of every kernel of that path
-KERNEL_ALG_BYTES = {"k_stream": 21.25, "k_stream_bin": 1.25 + 9.0, "k_tuples_bin": 18.0, "k_lds_insert": 9.0,
+KERNEL_ALG_BYTES = {"k_stream": 21.25, "k_stream_bin": 1.25 + 8.0, "k_tuples_bin": 16.0, "k_lds_insert": 8.0,
                     "k_insert_tuples": 29.0}
 
 
