@@ -150,6 +150,7 @@ def main():
                for i in range(nsteps + nwarm)]
     del genome
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()  # hand the generator's temporaries back before the graph allocates
 
     graph = mcx.Graph(K, 1, args.table_slots, device=local_rank)
     if args.direct:

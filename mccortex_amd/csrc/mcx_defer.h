@@ -385,17 +385,32 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
   const bool xcd = bs.mode == BIN_SUBLOCAL && gridDim.x % 8 == 0 && bs.seg_mod % 8 == 0 && in.nseg % bs.seg_mod == 0;
   const uint32_t group = xcd ? blockIdx.x % 8 : 0;
   const uint32_t nseg_g = xcd ? in.nseg / 8 : in.nseg;  // segments this block may take
-  const uint64_t nchunks = chunks_per_seg * nseg_g;
+  // ... and within an XCD only kWin regions are split at a time, so that their 512 write fronts
+  // each (64 B) stay resident in that XCD's L2 until the runs have filled whole lines.
+  constexpr uint32_t kWin = 8;
+  const uint32_t bins_g = xcd ? bs.seg_mod / 8 : 1;      // regions of this group
+  const uint32_t reps = xcd ? in.nseg / bs.seg_mod : 1;  // replicas per region
+  const uint32_t win_segs = kWin * reps;
+  const uint32_t nwin = (bins_g + kWin - 1) / kWin;
+  const uint64_t nchunks = xcd ? (uint64_t)nwin * chunks_per_seg * win_segs : chunks_per_seg * nseg_g;
   const uint64_t v0 = xcd ? blockIdx.x / 8 : blockIdx.x, vstep = xcd ? gridDim.x / 8 : gridDim.x;
   const uint32_t lmask = (1u << isink.t.lb1) - 1u;
   for (uint64_t v = v0; v < nchunks; v += vstep) {
-    const uint32_t sl = (uint32_t)(v % nseg_g);  // segment-interleaved
-    uint32_t seg = sl;
+    uint32_t seg;
+    uint64_t start;
     if (xcd) {
-      const uint32_t bins_g = bs.seg_mod / 8;  // regions of this group
-      seg = (sl / bins_g) * bs.seg_mod + group + 8 * (sl % bins_g);  // replica-major segment index
+      const uint64_t per_win = chunks_per_seg * win_segs;
+      const uint32_t win = (uint32_t)(v / per_win);
+      const uint64_t rem = v % per_win;
+      const uint32_t s = (uint32_t)(rem % win_segs);  // segment-interleaved inside the window
+      const uint32_t rgi = win * kWin + s % kWin;      // region index inside this XCD's group
+      if (rgi >= bins_g) continue;                     // uniform
+      seg = (s / kWin) * bs.seg_mod + group + 8 * rgi; // replica-major segment index
+      start = (rem / win_segs) * kTile;
+    } else {
+      seg = (uint32_t)(v % nseg_g);  // segment-interleaved
+      start = (v / nseg_g) * kTile;
     }
-    const uint64_t start = (v / nseg_g) * kTile;
     uint64_t cnt = in.counts ? (uint64_t)in.counts[seg] : in.seg_cap;
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (start >= cnt) continue;  // uniform across the block
