@@ -136,6 +136,21 @@ static void mcx_check(int rc, const char *what)
   if (rc != MCX_OK) die("%s: %s", what, mcx_last_error());
 }
 
+/* one batch of parsed reads -> the GPU (callback of the parallel parser and body of the sequential loop) */
+typedef struct { mcx_graph *g; build_task *bt; bool use_q; uint8_t fq_abs; } submit_ctx;
+static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
+{
+  submit_ctx *sc = arg;
+  if (!b->nreads) return;
+  if (sc->use_q && !sc->fq_abs) { /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 */
+    int off = sc->bt->fq_offset ? sc->bt->fq_offset : fq_offset_guess;
+    if (!off) off = 33;
+    sc->fq_abs = (uint8_t)(sc->bt->fq_cutoff + off);
+  }
+  mcx_check(mcx_graph_add_reads(sc->g, sc->bt->colour, b->bases, sc->use_q ? b->quals : NULL, b->offsets, b->nreads,
+                                sc->fq_abs, sc->bt->hp_cutoff, &sc->bt->stats), "add reads");
+}
+
 int ctx_build(int argc, char **argv)
 {
   size_t nthreads = 0, kmer_size = 0, mem_to_use = DEFAULT_MEM, num_kmers = 0;
@@ -310,25 +325,25 @@ int ctx_build(int argc, char **argv)
   memset(&prev, 0, sizeof(prev));
   for (size_t t = 0; t < ntasks; t++) {
     build_task *bt = &tasks[t];
-    seq_in *in = seq_in_open(bt->path);
-    if (!in) die("Cannot open -1 file: %s", bt->path);
-    const bool use_q = bt->fq_cutoff > 0 && seq_in_format(in) == SEQ_FMT_FASTQ;
-    read_batch_init(&batch, use_q);
-    uint8_t fq_abs = 0;
-    size_t nread_total = 0;
-    while (seq_in_fill(in, &batch, BATCH_BASES) > 0 || batch.nreads) {
-      if (use_q && !fq_abs) { /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 */
-        int off = bt->fq_offset ? bt->fq_offset : seq_in_guess_fq_offset(in);
-        if (!off) off = 33;
-        fq_abs = (uint8_t)(bt->fq_cutoff + off);
+    /* -t threads parse an uncompressed regular file in parallel; gzip, stdin and files the fast
+     * path declines go through the sequential parser */
+    submit_ctx sc = {g, bt, bt->fq_cutoff > 0 && bt->fmt == SEQ_FMT_FASTQ, 0};
+    int prc = 1;
+    if (nthreads > 1 && strcmp(bt->path, "-") != 0)
+      prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, BATCH_BASES, submit_batch, &sc);
+    if (prc == 2) die("Irregular %s record in %s (multi-line FASTQ?): rerun with -t 1", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
+    if (prc == 1) {
+      seq_in *in = seq_in_open(bt->path);
+      if (!in) die("Cannot open -1 file: %s", bt->path);
+      sc.use_q = bt->fq_cutoff > 0 && seq_in_format(in) == SEQ_FMT_FASTQ;
+      read_batch_init(&batch, sc.use_q);
+      while (seq_in_fill(in, &batch, BATCH_BASES) > 0 || batch.nreads) {
+        submit_batch(&sc, &batch, seq_in_guess_fq_offset(in));
+        read_batch_clear(&batch);
       }
-      mcx_check(mcx_graph_add_reads(g, bt->colour, batch.bases, use_q ? batch.quals : NULL, batch.offsets,
-                                    batch.nreads, fq_abs, bt->hp_cutoff, &bt->stats), "add reads");
-      nread_total += batch.nreads;
-      read_batch_clear(&batch);
+      read_batch_free(&batch);
+      seq_in_close(in);
     }
-    read_batch_free(&batch);
-    seq_in_close(in);
     /* per-file contig statistics = device counter delta around the file */
     mcx_load_stats cur;
     mcx_check(mcx_graph_device_stats(g, &cur), "device stats");
@@ -340,7 +355,6 @@ int ctx_build(int argc, char **argv)
     bt->stats.num_kmers_novel = cur.num_kmers_novel - prev.num_kmers_novel;
     prev = cur;
     col_info_update(&cols[bt->colour], bt->stats.total_bases_loaded, bt->stats.contigs_parsed);
-    (void)nread_total;
   }
   mcx_check(mcx_graph_sync(g), "sync");
 

@@ -63,6 +63,12 @@ size_t seq_in_fill(seq_in *s, read_batch *b, size_t max_bases);
 /* FASTQ offset guess from the qualities seen so far (33 or 64); 0 if no qualities */
 int seq_in_guess_fq_offset(const seq_in *s);
 
+/* Multi-threaded parse of an uncompressed regular file (par_ingest.c): `submit` is called on the
+ * calling thread for every batch.  Returns 0 = done, 1 = not suitable (nothing submitted: use the
+ * sequential parser), 2 = irregular record met after submission began. */
+int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, size_t batch_bases,
+               void (*submit)(void *arg, read_batch *b, int fq_offset_guess), void *arg);
+
 /* ---- .ctx v6 header (src/graph/graph_writer.c:11-110, src/basic/graph_info.c:116-175) ---- */
 typedef struct {
   uint32_t mean_read_length;

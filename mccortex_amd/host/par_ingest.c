@@ -1,0 +1,264 @@
+/* par_ingest.c -- multi-threaded parsing of uncompressed FASTA / FASTQ / plain files.
+ *
+ * The reference parses every input file with ONE reader thread (src/basic/async_read_io.c:204-213)
+ * and `-t` worker threads insert; with the insert on the GPU the parser is what bounds `build`,
+ * so here `-t` threads parse disjoint byte ranges of the memory-mapped file into flat read batches
+ * (bases, quals, offsets) and the submitting thread hands them to mcx_graph_add_reads().
+ * Record boundaries inside a byte range:
+ *   FASTQ  a line starting with '@' whose line+2 starts with '+' (a quality line may start with
+ *          '@', but then line+2 is a sequence line and cannot start with '+'); 4-line records only
+ *          -- anything else makes the caller fall back to the sequential parser (seq_in.c)
+ *   FASTA  a line starting with '>'
+ *   plain  any line start
+ * gzip'd input and stdin keep the sequential parser. */
+#define _GNU_SOURCE
+#include "host.h"
+
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+typedef struct {
+  const unsigned char *p, *end; /* byte range, starts at a record boundary */
+  seq_fmt fmt;
+  bool want_quals;
+  size_t max_bases;
+  int qmin, qmax;
+  bool bad; /* structure the fast path does not handle */
+} range_parser;
+
+static inline const unsigned char *line_end(const unsigned char *p, const unsigned char *end)
+{
+  const unsigned char *nl = memchr(p, '\n', (size_t)(end - p));
+  return nl ? nl : end;
+}
+
+static void batch_append(read_batch *b, const unsigned char *seq, size_t n, const unsigned char *qual)
+{
+  if (b->nbases + n > b->cap_bases) {
+    while (b->nbases + n > b->cap_bases) b->cap_bases *= 2;
+    b->bases = realloc(b->bases, b->cap_bases);
+    if (b->want_quals) b->quals = realloc(b->quals, b->cap_bases);
+    if (!b->bases || (b->want_quals && !b->quals)) die("Out of memory");
+  }
+  memcpy(b->bases + b->nbases, seq, n);
+  if (b->want_quals) {
+    if (qual) memcpy(b->quals + b->nbases, qual, n);
+    else memset(b->quals + b->nbases, 0, n);
+  }
+  b->nbases += n;
+}
+
+static void batch_close_read(read_batch *b)
+{
+  if (b->nreads + 1 > b->cap_reads) {
+    b->cap_reads *= 2;
+    b->offsets = realloc(b->offsets, (b->cap_reads + 1) * sizeof(uint64_t));
+    if (!b->offsets) die("Out of memory");
+  }
+  b->offsets[++b->nreads] = b->nbases;
+}
+
+static inline size_t strip_cr(const unsigned char *s, size_t n) { return (n && s[n - 1] == '\r') ? n - 1 : n; }
+
+/* Parse records until the batch holds max_bases or the range ends.  Returns reads appended. */
+static size_t range_fill(range_parser *rp, read_batch *b)
+{
+  size_t added = 0;
+  const unsigned char *p = rp->p, *end = rp->end;
+  while (p < end && b->nbases < rp->max_bases && !rp->bad) {
+    if (rp->fmt == SEQ_FMT_PLAIN) {
+      const unsigned char *e = line_end(p, end);
+      size_t n = strip_cr(p, (size_t)(e - p));
+      if (n) { batch_append(b, p, n, NULL); batch_close_read(b); added++; }
+      p = e < end ? e + 1 : end;
+    } else if (rp->fmt == SEQ_FMT_FASTA) {
+      if (*p == '\n' || *p == '\r') { p++; continue; }
+      if (*p != '>') { rp->bad = true; break; }
+      const unsigned char *e = line_end(p, end);
+      p = e < end ? e + 1 : end;
+      while (p < end && *p != '>') {
+        e = line_end(p, end);
+        size_t n = strip_cr(p, (size_t)(e - p));
+        if (n) batch_append(b, p, n, NULL);
+        p = e < end ? e + 1 : end;
+      }
+      batch_close_read(b); added++;
+    } else { /* FASTQ, 4-line records */
+      if (*p == '\n' || *p == '\r') { p++; continue; }
+      if (*p != '@') { rp->bad = true; break; }
+      const unsigned char *h = line_end(p, end);
+      if (h >= end) { rp->bad = true; break; }
+      const unsigned char *s = h + 1, *se = line_end(s, end);
+      if (se >= end) { rp->bad = true; break; }
+      const unsigned char *pl = se + 1;
+      if (pl >= end || *pl != '+') { rp->bad = true; break; }
+      const unsigned char *ple = line_end(pl, end);
+      if (ple >= end) { rp->bad = true; break; }
+      const unsigned char *q = ple + 1, *qe = line_end(q, end);
+      size_t n = strip_cr(s, (size_t)(se - s)), qn = strip_cr(q, (size_t)(qe - q));
+      if (qn != n) { rp->bad = true; break; }
+      for (size_t i = 0; i < (qn < 64 ? qn : 64); i++) { /* sample for the offset guess */
+        if (q[i] < rp->qmin) rp->qmin = q[i];
+        if (q[i] > rp->qmax) rp->qmax = q[i];
+      }
+      batch_append(b, s, n, rp->want_quals ? q : NULL);
+      batch_close_read(b); added++;
+      p = qe < end ? qe + 1 : end;
+    }
+  }
+  rp->p = p;
+  return added;
+}
+
+/* first record boundary at or after `pos` */
+static const unsigned char *find_record(const unsigned char *base, size_t size, size_t pos, seq_fmt fmt)
+{
+  const unsigned char *end = base + size, *p = base + pos;
+  if (pos == 0) return base;
+  /* move to the start of the next line */
+  p = line_end(p - 1, end);
+  if (p >= end) return end;
+  p++;
+  if (fmt == SEQ_FMT_PLAIN) return p;
+  for (; p < end;) {
+    const unsigned char *e1 = line_end(p, end);
+    if (fmt == SEQ_FMT_FASTA) { if (*p == '>') return p; }
+    else if (*p == '@' && e1 < end) {
+      const unsigned char *l2 = e1 + 1, *e2 = line_end(l2, end);
+      if (e2 < end && e2 + 1 < end && e2[1] == '+') return p;
+    }
+    if (e1 >= end) return end;
+    p = e1 + 1;
+  }
+  return end;
+}
+
+/* ---- worker pool ---- */
+typedef struct par_ctx par_ctx;
+typedef struct {
+  par_ctx *ctx;
+  range_parser rp;
+  read_batch batch[2]; /* double buffered: one being filled, one with the submitter */
+  int ready;           /* index of a full batch waiting for the submitter, or -1 */
+  bool done;
+  pthread_t th;
+} worker;
+
+struct par_ctx {
+  pthread_mutex_t mu;
+  pthread_cond_t cv_ready, cv_free;
+  worker *w;
+  int nw;
+};
+
+static void *worker_main(void *arg)
+{
+  worker *w = arg;
+  par_ctx *c = w->ctx;
+  int cur = 0;
+  for (;;) {
+    read_batch_clear(&w->batch[cur]);
+    size_t n = range_fill(&w->rp, &w->batch[cur]);
+    pthread_mutex_lock(&c->mu);
+    while (w->ready >= 0) pthread_cond_wait(&c->cv_free, &c->mu); /* previous batch not taken yet */
+    if (n) w->ready = cur;
+    const bool fin = w->rp.bad || w->rp.p >= w->rp.end;
+    if (fin) w->done = true;
+    pthread_cond_signal(&c->cv_ready);
+    pthread_mutex_unlock(&c->mu);
+    if (fin) break;
+    cur ^= 1;
+  }
+  return NULL;
+}
+
+/* Parse `path` with nthreads threads, calling submit(batch) for every batch on the calling thread.
+ * Returns 0 on success, 1 if the file is not suitable (caller uses the sequential parser; nothing
+ * has been submitted), 2 if an irregular record was met after submission began. */
+int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, size_t batch_bases,
+               void (*submit)(void *arg, read_batch *b, int fq_offset_guess), void *arg)
+{
+  if (nthreads < 2 || (fmt != SEQ_FMT_FASTA && fmt != SEQ_FMT_FASTQ && fmt != SEQ_FMT_PLAIN)) return 1;
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return 1;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < (off_t)(1 << 20)) { close(fd); return 1; }
+  const size_t size = (size_t)st.st_size;
+  const unsigned char *base = mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (base == MAP_FAILED) return 1;
+  if (size >= 2 && base[0] == 0x1f && base[1] == 0x8b) { munmap((void *)base, size); return 1; } /* gzip */
+  madvise((void *)base, size, MADV_SEQUENTIAL | MADV_WILLNEED);
+
+  /* probe: the first records must have the regular structure */
+  {
+    range_parser rp = {base, base + (size < (4u << 20) ? size : (4u << 20)), fmt, false, 1u << 20, 255, 0, false};
+    read_batch b;
+    read_batch_init(&b, false);
+    range_fill(&rp, &b);
+    read_batch_free(&b);
+    if (rp.bad && rp.p < rp.end - 65536) { munmap((void *)base, size); return 1; }
+  }
+
+  par_ctx c;
+  pthread_mutex_init(&c.mu, NULL);
+  pthread_cond_init(&c.cv_ready, NULL);
+  pthread_cond_init(&c.cv_free, NULL);
+  c.nw = nthreads;
+  c.w = calloc((size_t)nthreads, sizeof(worker));
+  const unsigned char *prev = base;
+  for (int t = 0; t < nthreads; t++) {
+    worker *w = &c.w[t];
+    const unsigned char *next = t + 1 == nthreads ? base + size : find_record(base, size, size / (size_t)nthreads * (size_t)(t + 1), fmt);
+    if (next < prev) next = prev;
+    w->ctx = &c;
+    w->rp = (range_parser){prev, next, fmt, want_quals, batch_bases, 255, 0, false};
+    w->ready = -1;
+    read_batch_init(&w->batch[0], want_quals);
+    read_batch_init(&w->batch[1], want_quals);
+    prev = next;
+  }
+  for (int t = 0; t < nthreads; t++) pthread_create(&c.w[t].th, NULL, worker_main, &c.w[t]);
+
+  int rc = 0, live = nthreads;
+  pthread_mutex_lock(&c.mu);
+  while (live > 0) {
+    bool progressed = false;
+    for (int t = 0; t < nthreads; t++) {
+      worker *w = &c.w[t];
+      if (w->ready >= 0) {
+        const int idx = w->ready;
+        pthread_mutex_unlock(&c.mu);
+        int guess = w->rp.qmax ? (w->rp.qmin >= 59 ? 64 : 33) : 0;
+        submit(arg, &w->batch[idx], guess);
+        pthread_mutex_lock(&c.mu);
+        w->ready = -1;
+        pthread_cond_broadcast(&c.cv_free);
+        progressed = true;
+      }
+      if (w->done && w->ready < 0 && w->th) {
+        pthread_mutex_unlock(&c.mu);
+        pthread_join(w->th, NULL);
+        pthread_mutex_lock(&c.mu);
+        w->th = 0;
+        if (w->rp.bad) rc = 2;
+        live--;
+        progressed = true;
+      }
+    }
+    if (!progressed && live > 0) pthread_cond_wait(&c.cv_ready, &c.mu);
+  }
+  pthread_mutex_unlock(&c.mu);
+  for (int t = 0; t < nthreads; t++) { read_batch_free(&c.w[t].batch[0]); read_batch_free(&c.w[t].batch[1]); }
+  free(c.w);
+  pthread_mutex_destroy(&c.mu);
+  pthread_cond_destroy(&c.cv_ready);
+  pthread_cond_destroy(&c.cv_free);
+  munmap((void *)base, size);
+  return rc;
+}

@@ -188,3 +188,55 @@ def test_chunk_seams_and_long_sequences(built, orc, tmp_path):
                 st = og.add_reads(0, bb, oo)
                 og.update_stats(0, st)
             assert open(out, "rb").read() == og.ctx_bytes(True), (stage, k)
+
+
+@pytest.mark.gpu
+def test_parallel_ingest_matches_sequential_and_oracle(built, orc, tmp_path):
+    """-t N parses uncompressed files > 1 MB with N threads over byte ranges (host/par_ingest.c):
+    FASTQ (incl. qualities that start with '@' and '+'), wrapped FASTA, plain; -Q through the fast
+    path; a multi-line FASTQ is declined by the probe and parsed sequentially."""
+    g = synth.genome(400_000, 11)
+    b, o = synth.reads(30000, 150, seed=3, g=g, n_frac=0.05, lower_frac=0.02)
+    rng = np.random.default_rng(9)
+    quals = rng.integers(33, 75, len(b)).astype(np.uint8)
+    quals[o[:-1].astype(np.int64)[::3]] = ord("@")   # quality lines that look like headers
+    quals[o[:-1].astype(np.int64)[1::3]] = ord("+")
+    fq = _write_inputs(tmp_path, b, o, "par", "fq", qual=quals)
+    fa = _write_inputs(tmp_path, b, o, "par", "fa", width=61)
+    tx = _write_inputs(tmp_path, b, o, "par", "txt")
+    assert os.path.getsize(fq) > (1 << 20) and os.path.getsize(fa) > (1 << 20)
+
+    def oracle(**kw):
+        og = orc.Graph(31, 1, 1 << 22)
+        og.set_sample(0, "s")
+        st = og.add_reads(0, b, o, **kw)
+        og.update_stats(0, st)
+        return og.ctx_bytes(True)
+
+    want = oracle()
+    for f in (fq, fa, tx):
+        for t in ("1", "3", "8"):
+            out = str(tmp_path / "p.ctx")
+            rc, _, err = run(31, "build", "-f", "-t", t, "-k", "31", "-n", "4M", "-S", "-s", "s", "--seq", f, out)
+            assert rc == 0, err
+            assert open(out, "rb").read() == want, (f, t)
+            assert "SE reads: 30,000" in err and "bases read: 4,500,000" in err
+    wantq = oracle(quals=quals, fq_cutoff=33 + 15, hp_cutoff=0)
+    for t in ("1", "5"):
+        out = str(tmp_path / "q.ctx")
+        rc, _, err = run(31, "build", "-f", "-t", t, "-k", "31", "-n", "4M", "-S", "-s", "s", "-Q", "15", "--seq", fq, out)
+        assert rc == 0, err
+        assert open(out, "rb").read() == wantq, t
+    # multi-line FASTQ: sequence and quality wrapped at 50 columns
+    recs = []
+    for i in range(len(o) - 1):
+        r = bytes(b[int(o[i]):int(o[i + 1])])
+        q = b"I" * len(r)
+        recs.append(b"@r%d\n" % i + b"\n".join(r[j:j + 50] for j in range(0, len(r), 50)) + b"\n+\n" +
+                    b"\n".join(q[j:j + 50] for j in range(0, len(q), 50)) + b"\n")
+    ml = tmp_path / "multi.fq"
+    ml.write_bytes(b"".join(recs))
+    out = str(tmp_path / "m.ctx")
+    rc, _, err = run(31, "build", "-f", "-t", "4", "-k", "31", "-n", "4M", "-S", "-s", "s", "--seq", str(ml), out)
+    assert rc == 0, err
+    assert open(out, "rb").read() == want

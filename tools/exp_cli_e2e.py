@@ -1,0 +1,40 @@
+"""End-to-end CLI timing: write a synthetic FASTQ/FASTA, run mccortex31 build --sort, report stages."""
+import os, sys, time, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+
+NR = int(os.environ.get("NR", "5000000"))
+dev = torch.device("cuda", 0)
+genome = bench.make_genome(100_000_000, dev, 42)
+s = bench.make_batch(genome, NR, 7, dev).reshape(NR, 151).cpu().numpy()
+del genome
+torch.cuda.empty_cache()
+out = "/tmp/e2e"
+os.makedirs(out, exist_ok=True)
+# FASTQ: @r\nSEQ\n+\nQUAL\n with fixed-width header "@r%08d"
+hdr = np.frombuffer(b"@r00000000\n", np.uint8)
+rec = np.empty((NR, 11 + 151 + 2 + 151), np.uint8)
+rec[:, :11] = hdr
+ids = np.arange(NR)
+for d in range(8):
+    rec[:, 9 - d] = 48 + (ids // 10 ** d) % 10
+rec[:, 11:162] = s
+rec[:, 162] = ord("+"); rec[:, 163] = ord("\n")
+rec[:, 164:314] = ord("I"); rec[:, 314] = ord("\n")
+fq = os.path.join(out, "reads.fq")
+rec.tofile(fq)
+print("wrote %s: %.2f GB, %d reads" % (fq, os.path.getsize(fq) / 1e9, NR), flush=True)
+exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mccortex_amd", "bin", "mccortex31")
+for args in (["--sort"], []):
+    t0 = time.perf_counter()
+    p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp"] + args + ["--seq", fq, os.path.join(out, "o.ctx")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    err = p.stderr.decode()
+    lines = [l for l in err.splitlines() if "kmers" in l.lower() or "time" in l.lower() or "Dumped" in l]
+    print("build %s: rc=%d wall %.2f s (%.2f G bases/s, %.2f G k-mers/s end to end)" % (" ".join(args), p.returncode, dt, NR * 150 / dt / 1e9, NR * 120 / dt / 1e9))
+    for l in lines[-4:]:
+        print("   ", l[-150:])
+print("ctx size %.2f GB" % (os.path.getsize(os.path.join(out, "o.ctx")) / 1e9))
