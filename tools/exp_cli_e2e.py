@@ -27,9 +27,9 @@ fq = os.path.join(out, "reads.fq")
 rec.tofile(fq)
 print("wrote %s: %.2f GB, %d reads" % (fq, os.path.getsize(fq) / 1e9, NR), flush=True)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mccortex_amd", "bin", "mccortex31")
-for args in (["--sort"], []):
+for args in (["--sort", "-t", "1"], ["--sort", "-t", "2"], ["--sort", "-t", "8"], ["--sort", "-t", "32"], ["-t", "32"]):
     t0 = time.perf_counter()
-    p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp"] + args + ["--seq", fq, os.path.join(out, "o.ctx")],
+    p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp"] + args + ["--seq", fq, os.environ.get("OUT", os.path.join(out, "o.ctx"))],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     dt = time.perf_counter() - t0
     err = p.stderr.decode()
@@ -38,3 +38,8 @@ for args in (["--sort"], []):
     for l in lines[-4:]:
         print("   ", l[-150:])
 print("ctx size %.2f GB" % (os.path.getsize(os.path.join(out, "o.ctx")) / 1e9))
+# stages of one run, from the status lines
+p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp", "--sort", "-t", "32", "--seq", fq, os.path.join(out, "o.ctx")],
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+for l in p.stderr.decode().splitlines():
+    print("   ", l[:160])
