@@ -119,7 +119,7 @@ int mcx_graph_add_stream_dev(mcx_graph *g, int colour,
 
 /* Sharded build.  Step 1 on every rank: k-merise a device
  * stream and bin the per-occurrence tuples (canonical key words, edge byte) by
- * owner = lookup3-secondary-hash(key) % nparts.  d_keys holds nparts bins of
+ * owner = (second result word of lookup3(key) * nparts) >> 32 (= mcx_key_owner()).  d_keys holds nparts bins of
  * bin_capacity tuples, W words each; d_edges likewise one byte per tuple;
  * d_counts[nparts] (uint64) receives the fill of every bin (must be zeroed by
  * the caller).  Overflowing a bin sets MCX_ERR_FULL at the next sync. */
