@@ -485,7 +485,10 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
 // protocol as probe_insert, with LDS atomics.
 // threads of the LDS-insert workgroup: W=2 slices are 96 KiB (one workgroup per CU), so that one is larger
 template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? 512 : 1024; };
-constexpr int kLdsBatch = 4;
+#ifndef MCX_LDS_BATCH
+#define MCX_LDS_BATCH 4
+#endif
+constexpr int kLdsBatch = MCX_LDS_BATCH;
 
 // find-or-insert one occurrence in the LDS-resident sub-table
 template <int W>
