@@ -67,6 +67,11 @@ int mcx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
  *   device          HIP device ordinal */
 int mcx_graph_create(mcx_graph **g, int kmer_size, int ncols,
                      uint64_t capacity_kmers, int device);
+/* One shard of a graph whose table is split over `nparts` GPUs (a power of two, <= 32) by hash
+ * prefix: the key's owner is the top bits of the quotient-hash region index (mcx_graph_key_owner).
+ * mcx_graph_create == nparts 1.  Every shard must be created with the same k / ncols / capacity. */
+int mcx_graph_create_shard(mcx_graph **g, int kmer_size, int ncols, uint64_t capacity_kmers,
+                           int device, int nparts, int part);
 void mcx_graph_destroy(mcx_graph *g);
 
 /* Empty the table and zero the statistics (graph stays allocated). */
@@ -129,8 +134,30 @@ int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream, uint64_t 
 /* Step 2 on the owner, after the exchange: insert n tuples. */
 int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void *d_keys,
                                 const void *d_edges, uint64_t n);
-/* Owner of a canonical key (host-side helper for tests / the exchange). */
+/* Owner of a canonical key in the exchange above (host-side helper for tests). */
 uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts);
+
+/* Sharded build, compact exchange: the sender bins packed occurrences (one 64-bit word per key
+ * word) by (owner, region) of the sharded table, so every owner's block is one fixed-size message
+ * and the receiver consumes it without re-binning.
+ *   mcx_graph_shard_layout      segments per owner, tuples per segment and overflow capacity for
+ *                               calls of at most `tuples_per_call` occurrences
+ *   mcx_graph_shard_bins_dev    k-merise a stream into d_keys[nparts][segs][seg_cap][W] with fills
+ *                               d_counts[nparts][segs] (zeroed by the caller); occurrences beyond a
+ *                               segment go to the owner's overflow bin (full keys + edge bytes,
+ *                               d_ov_counts[nparts] zeroed by the caller), beyond that: MCX_ERR_FULL
+ *   mcx_graph_add_segments_dev  owner side: split received blocks (nseg segments of packed tuples
+ *                               of THIS shard, `ntuples` in total) by sub-table; applied at the
+ *                               next flush.  Overflow bins go through mcx_graph_insert_tuples_dev.
+ *   mcx_graph_key_owner         owner of a canonical key under this graph's geometry */
+int mcx_graph_shard_layout(mcx_graph *g, uint64_t tuples_per_call, uint32_t *segs_per_owner,
+                           uint64_t *seg_cap, uint64_t *ov_cap);
+int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, void *d_keys,
+                             void *d_counts, uint64_t seg_cap, void *d_ov_keys, void *d_ov_edges,
+                             void *d_ov_counts, uint64_t ov_cap);
+int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_counts,
+                               uint32_t nseg, uint64_t seg_cap, uint64_t ntuples);
+uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_words);
 
 /* Wait for all submitted work; reports MCX_ERR_FULL if any insert ran out of
  * slots (the reference dies with "Hash table is full"). */

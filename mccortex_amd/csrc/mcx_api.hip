@@ -78,6 +78,7 @@ struct mcx_graph {
   uint64_t *l1_keys = nullptr, *l2_keys = nullptr;  // packed tuples: W words each
   unsigned long long *l1_cnt = nullptr, *l2_cnt = nullptr;
   uint64_t pending = 0;         // upper bound of tuples sitting in the L1 bins
+  uint64_t pending_l2 = 0;      // tuples already split into the sub-table bins (sharded receive path)
   int pending_colour = 0;
   // ---- optional per-kernel timing (mcx_graph_configure("profile", 1)) ----
   bool profile = false;
@@ -120,9 +121,17 @@ static int check_k(int k)
 
 extern "C" int mcx_graph_create(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers, int device)
 {
+  return mcx_graph_create_shard(out, kmer_size, ncols, capacity_kmers, device, 1, 0);
+}
+
+extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers, int device,
+                                      int nparts, int part)
+{
   if (!out) return fail(MCX_ERR_ARG, "null handle pointer");
   *out = nullptr;
   if (check_k(kmer_size) != MCX_OK) return MCX_ERR_ARG;
+  if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1)) || part < 0 || part >= nparts)
+    return fail(MCX_ERR_ARG, "shards must be a power of two <= 32 and 0 <= part < shards (got %d of %d)", part, nparts);
   if (ncols < 1 || ncols > 4096) return fail(MCX_ERR_ARG, "ncols out of range: %d", ncols);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -137,8 +146,11 @@ extern "C" int mcx_graph_create(mcx_graph **out, int kmer_size, int ncols, uint6
   g->device = device;
   // geometry of the quotient-hashed table: 2^lb1 regions x spb sub-tables x 4096 slots
   uint64_t nsub = (std::max<uint64_t>(capacity_kmers, 1024) + kSubSlots - 1) / kSubSlots;
+  uint32_t lbo = 0;
+  while ((1 << lbo) < nparts) lbo++;
   uint32_t lb1 = 0;
-  while (lb1 < 9 && (2ull << lb1) <= nsub) lb1++;                 // up to 512 regions ...
+  const uint32_t lb1_max = lbo ? std::min<uint32_t>(9, 11 - lbo) : 9;  // shards x regions <= 2048 sender bins
+  while (lb1 < lb1_max && (2ull << lb1) <= nsub) lb1++;             // up to 512 regions ...
   while (lb1 < 11 && ((nsub + (1ull << lb1) - 1) >> lb1) > (uint64_t)kMaxBins) lb1++;  // ... more for huge tables
   const uint64_t spb = (nsub + (1ull << lb1) - 1) >> lb1;
   nsub = spb << lb1;
@@ -146,6 +158,8 @@ extern "C" int mcx_graph_create(mcx_graph **out, int kmer_size, int ncols, uint6
   const uint64_t slots = nsub * kSubSlots;
   g->t.nslots = slots;
   g->t.lb1 = lb1;
+  g->t.lbo = lbo;
+  g->t.part = (uint32_t)part;
   g->t.spb = (uint32_t)spb;
   g->t.S = (uint32_t)(g->W + ncols);
   g->t.max_probe = (uint32_t)kSubSlots;  // a probe sequence never leaves its sub-table
@@ -203,7 +217,8 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
   if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
-  g->pending = 0;  // buffered tuples are discarded with the table
+  if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
+  g->pending = g->pending_l2 = 0;  // buffered tuples are discarded with the table
   return MCX_OK;
 }
 
@@ -324,7 +339,7 @@ template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int 
   const size_t lds = kSubSlots * (W + 1) * 8;
   static bool once = false;
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
-  BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2};
+  BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
   SpanGuard sp(g, "k_lds_insert");
   hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(g->nsub, (uint64_t)g->grid * 4)),
                      dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
@@ -386,18 +401,21 @@ static int ensure_defer(mcx_graph *g)
 // Split every L1 bin by sub-table, then let one workgroup per sub-table apply its tuples in LDS.
 static int flush_deferred(mcx_graph *g)
 {
-  if (!g->pending) return MCX_OK;
+  if (!g->pending && !g->pending_l2) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
-  TupleIn in{g->l1_keys, nullptr, g->l1_cnt, g->cap1, g->b1 * g->rep1};
-  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1};
-  BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2};
-  DISPATCH_WC(g, launch_split_regions, g, in, g->pending_colour, bs, out);
-  HIP_TRY(hipGetLastError());
+  if (g->pending) {
+    TupleIn in{g->l1_keys, nullptr, g->l1_cnt, g->cap1, g->b1 * g->rep1};
+    BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1, 0};
+    BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
+    DISPATCH_WC(g, launch_split_regions, g, in, g->pending_colour, bs, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
+  }
   DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
   g->pending = 0;
+  g->pending_l2 = 0;
   return MCX_OK;
 }
 
@@ -406,7 +424,8 @@ static int defer_reserve(mcx_graph *g, int colour, uint64_t ub)
 {
   int rc = ensure_defer(g);
   if (rc != MCX_OK || !g->defer) return rc;
-  if (g->pending && (colour != g->pending_colour || g->pending + ub > g->defer_tuples)) {
+  if ((g->pending || g->pending_l2) &&
+      (colour != g->pending_colour || g->pending + g->pending_l2 + ub > g->defer_tuples)) {
     rc = flush_deferred(g);
     if (rc != MCX_OK) return rc;
   }
@@ -429,8 +448,8 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     if (rc != MCX_OK) return rc;
     StreamLaunch P = L;
     P.pos_lo = lo; P.pos_hi = hi;
-    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1};
-    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1};
+    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0};
+    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
     DISPATCH_WC(g, launch_bin_region_stream, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
     g->pending += hi - lo;
@@ -513,8 +532,8 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  BinSpec bs{BIN_OWNER, (uint32_t)nparts, (uint32_t)nparts, 1, (uint32_t)nparts, 1};
-  BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity};
+  BinSpec bs{BIN_OWNER, (uint32_t)nparts, (uint32_t)nparts, 1, (uint32_t)nparts, 1, 0};
+  BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity, nullptr, nullptr, nullptr, 0};
   if (g->W == 1) launch_bin_stream_t<1, true, true>(g, L, 0, bs, out);
   else launch_bin_stream_t<2, true, true>(g, L, 0, bs, out);
   HIP_TRY(hipGetLastError());
@@ -538,14 +557,91 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
     int rc = defer_reserve(g, colour, cnt);
     if (rc != MCX_OK) return rc;
     TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1};
-    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1};
-    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1};
+    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0};
+    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
     DISPATCH_WC(g, launch_bin_received, g, in, colour, bs, out);
     HIP_TRY(hipGetLastError());
     g->pending += cnt;
     lo += cnt;
   }
   return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sharded build, exchange format v2: packed tuples binned by (owner, region) on the sender
+// ---------------------------------------------------------------------------
+static const uint32_t kShardRep = 8;
+
+extern "C" int mcx_graph_shard_layout(mcx_graph *g, uint64_t tuples_per_call, uint32_t *segs_per_owner,
+                                      uint64_t *seg_cap, uint64_t *ov_cap)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  const uint32_t nparts = 1u << g->t.lbo, b1 = 1u << g->t.lb1;
+  const uint64_t nseg = (uint64_t)nparts * kShardRep * b1;
+  if (segs_per_owner) *segs_per_owner = kShardRep * b1;
+  // Poisson spread of a segment is ~sqrt(mean): 6 % + 2048 covers > 10 sigma for the bench shapes;
+  // anything beyond (hot k-mers) goes to the owner's overflow bin
+  if (seg_cap) *seg_cap = (uint64_t)((double)tuples_per_call / (double)nseg * 1.06) + 2048;
+  if (ov_cap) *ov_cap = std::max<uint64_t>(1u << 16, tuples_per_call / nparts / 64);
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, void *d_keys,
+                                        void *d_counts, uint64_t seg_cap, void *d_ov_keys, void *d_ov_edges,
+                                        void *d_ov_counts, uint64_t ov_cap)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  if (g->t.lb1 + g->t.lbo > 11) return fail(MCX_ERR_ARG, "too many (owner, region) bins");
+  if (seg_cap >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "segment capacity must be below 2^32 tuples");
+  if (!nbytes) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  const uint32_t nparts = 1u << g->t.lbo, b1 = 1u << g->t.lb1;
+  StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
+  BinSpec bs{BIN_GLOBAL, nparts, nparts * b1, kShardRep, b1, 1, g->t.lb1};
+  BinOut out{(uint64_t *)d_keys, nullptr, (unsigned long long *)d_counts, seg_cap,
+             (uint64_t *)d_ov_keys, (uint8_t *)d_ov_edges, (unsigned long long *)d_ov_counts, ov_cap};
+  if (g->W == 1) launch_bin_stream_t<1, true, false>(g, L, 0, bs, out);
+  else launch_bin_stream_t<2, true, false>(g, L, 0, bs, out);
+  HIP_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_counts,
+                                          uint32_t nseg, uint64_t seg_cap, uint64_t ntuples)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+  if (!nseg) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  int rc = ensure_defer(g);
+  if (rc != MCX_OK) return rc;
+  if (!g->defer) return fail(MCX_ERR_ARG, "packed segments need the deferred insert path (table too small or defer=0)");
+  if (nseg % g->b1) return fail(MCX_ERR_ARG, "segments must cover whole sets of %u regions", g->b1);
+  rc = defer_reserve(g, colour, ntuples);
+  if (rc != MCX_OK) return rc;
+  TupleIn in{(const uint64_t *)d_keys, nullptr, (const unsigned long long *)d_counts, seg_cap, nseg};
+  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1, 0};
+  BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
+  DISPATCH_WC(g, launch_split_regions, g, in, colour, bs, out);
+  HIP_TRY(hipGetLastError());
+  g->pending_l2 += ntuples;
+  return MCX_OK;
+}
+
+extern "C" uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_words)
+{
+  if (!g) return 0;
+  const uint32_t lbq = g->t.lb1 + g->t.lbo;
+  uint32_t r = 0, b = 0, c;
+  if (g->W == 1) {
+    Kmer<1> q = key_quot<1>(Kmer<1>{{key_words[0]}}, lbq, r);
+    c = kmer_hash<1>(q, 0, &b);
+  } else {
+    Kmer<2> q = key_quot<2>(Kmer<2>{{key_words[0], key_words[1]}}, lbq, r);
+    c = kmer_hash<2>(q, 0, &b);
+  }
+  return (r ^ (c & ((1u << lbq) - 1u))) >> g->t.lb1;
 }
 
 extern "C" uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts)

@@ -23,7 +23,12 @@
 
 namespace mcx {
 
-enum : int { BIN_OWNER = 0, BIN_GROUP = 1, BIN_SUBLOCAL = 2 };
+// BIN_OWNER    reads -> per-owner bins of full tuples, owner from lookup3's 2nd word (exchange format v1)
+// BIN_GROUP    tuples of THIS shard -> its region bins (packed)
+// BIN_SUBLOCAL packed tuples of one region -> its sub-table bins
+// BIN_GLOBAL   reads -> bins of every (owner, region) of the sharded table (packed), laid out
+//              [owner][replica][region] so that each owner's block is one contiguous message
+enum : int { BIN_OWNER = 0, BIN_GROUP = 1, BIN_SUBLOCAL = 2, BIN_GLOBAL = 3 };
 
 struct BinSpec {
   int mode;
@@ -38,7 +43,16 @@ struct BinSpec {
   uint32_t rep;
   uint32_t nout;     // output bins per replica
   uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s holds region s % seg_mod
+  uint32_t lb1;      // BIN_GLOBAL: log2 regions per owner
 };
+
+// index of the output segment of local bin b
+__device__ __forceinline__ uint32_t out_seg(const BinSpec &bs, uint32_t ob0, uint32_t b)
+{
+  if (bs.mode == BIN_GLOBAL)
+    return ((((b >> bs.lb1) * bs.rep + blockIdx.x % bs.rep) << bs.lb1) | (b & ((1u << bs.lb1) - 1u)));
+  return ob0 + b;
+}
 
 // Output bins.  Packed format (deferred path): `keys` holds W words per tuple, `edges` unused.
 // Full format (owner bins): W key words + one edge byte per tuple.
@@ -47,6 +61,11 @@ struct BinOut {
   uint8_t *edges;              // [rep][nbins][cap] (full format only)
   unsigned long long *counts;  // [rep][nbins] fill (may exceed cap: the excess went to the fallback)
   uint64_t cap;                // tuples per (replica, bin) segment
+  // BIN_GLOBAL only: per-owner overflow bins in full format for tuples beyond a segment's capacity
+  uint64_t *ov_keys;           // [nparts][ov_cap][W]
+  uint8_t *ov_edges;           // [nparts][ov_cap]
+  unsigned long long *ov_counts;
+  uint64_t ov_cap;
 };
 
 constexpr int kMaxBins = 2048;
@@ -118,7 +137,7 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     res.g0[q] = 0;
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
-      if (c) res.g0[q] = atomicAdd(&out.counts[ob0 + b], (unsigned long long)c);
+      if (c) res.g0[q] = atomicAdd(&out.counts[out_seg(bs, ob0, b)], (unsigned long long)c);
       L.cnt[b] = 0;
     }
   }
@@ -169,31 +188,57 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
     const uint32_t b = L.sbin[q];
     const uint64_t gpos = L.gbase[b] + ((lo + q) - L.off[b]);
     if (gpos < out.cap) {
-      const uint64_t at = (uint64_t)(ob0 + b) * out.cap + gpos;
+      const uint64_t at = (uint64_t)out_seg(bs, ob0, b) * out.cap + gpos;
       uint64_t *kd = out.keys + at * W;
       kd[0] = L.skey[q * W];
       if (W == 2) kd[1] = L.skey[q * W + 1];
       if (FULL) out.edges[at] = L.se[q];
     } else if (bs.mode == BIN_OWNER) {
       full = 2;
-    } else {  // packed tuple -> full key -> lock-free insert into the HBM table
+    } else {  // packed tuple -> full key
       Kmer<W> tq;
       tq.w[0] = L.skey[q * W];
       if (W == 2) tq.w[W - 1] = L.skey[q * W + 1];
       const uint32_t e = (uint32_t)(tq.w[0] >> 56);
       const Kmer<W> qq = tuple_q<W>(tq);
-      const uint32_t region = bs.mode == BIN_GROUP ? b : region_of_seg;
       uint32_t hb;
       const uint32_t c = kmer_hash<W>(qq, 0, &hb);
-      const uint32_t r = region ^ (c & ((1u << isink.t.lb1) - 1u));
-      const Kmer<W> key = key_unquot<W>(qq, isink.t.lb1, r);
-      const uint64_t slot = key_slot<W>(isink.t, key);
-      const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
-      const uint64_t cur = isink.t.rec[slot * S];
-      probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
+      const uint32_t lbq = lbq_of(isink.t);
+      if (bs.mode == BIN_GLOBAL) {  // ... appended to the owner's overflow bin (full format)
+        const Kmer<W> key = key_unquot<W>(qq, lbq, b ^ (c & ((1u << lbq) - 1u)));
+        const uint32_t owner = b >> bs.lb1;
+        const unsigned long long pos = atomicAdd(&out.ov_counts[owner], 1ULL);
+        if (pos < out.ov_cap) {
+          uint64_t *kd = out.ov_keys + ((uint64_t)owner * out.ov_cap + pos) * W;
+          kd[0] = key.w[0];
+          if (W == 2) kd[1] = key.w[W - 1];
+          out.ov_edges[(uint64_t)owner * out.ov_cap + pos] = (uint8_t)e;
+        } else {
+          full = 2;
+        }
+      } else {                      // ... lock-free insert into the HBM table
+        const uint32_t region = bs.mode == BIN_GROUP ? b : region_of_seg;
+        const Kmer<W> key = key_unquot<W>(qq, lbq, r_of(isink.t, region, c));
+        const uint64_t slot = key_slot<W>(isink.t, key);
+        const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
+        const uint64_t cur = isink.t.rec[slot * S];
+        probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
+      }
     }
   }
   if (round + 1 < kRounds) __syncthreads();  // staging is reused by the next round
+}
+
+// A key owned by another shard cannot be packed for this one (its remainder would be rebuilt
+// with the wrong owner bits): it takes the direct insert.  Never happens when nparts == 1.
+template <int W, bool ONECOL>
+__device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, Kmer<W> key, uint32_t e,
+                                            uint32_t &novel, uint32_t &full)
+{
+  const uint64_t slot = key_slot<W>(isink.t, key);
+  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
+  const uint64_t cur = isink.t.rec[slot * S];
+  probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
 }
 
 // ---------------------------------------------------------------------------
@@ -307,16 +352,24 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
             tle[j] = (local << 8) | e;
           } else {
             uint32_t r, hb;
-            const Kmer<W> q = key_quot<W>(key, isink.t.lb1, r);
+            const uint32_t lbq = lbq_of(isink.t);
+            const Kmer<W> q = key_quot<W>(key, lbq, r);
             const uint32_t c = kmer_hash<W>(q, 0, &hb);
-            local = r ^ (c & ((1u << isink.t.lb1) - 1u));  // region of the key
+            const uint32_t G = r ^ (c & ((1u << lbq) - 1u));  // (owner, region) of the key
+            local = bs.mode == BIN_GLOBAL ? G : (G & ((1u << isink.t.lb1) - 1u));
             tk[j] = tuple_pack<W>(q, e);
             tle[j] = local << 8;
+            if (bs.mode != BIN_GLOBAL && (G >> isink.t.lb1) != isink.t.part) {
+              foreign_insert<W, ONECOL>(isink, key, e, n_novel, full);
+              local = kMaxBins;  // not binned
+            }
           }
-          vmask |= 1u << j;
-          atomicAdd(&L.cnt[local], 1u);
           n_kmers++;
           n_contigs += prev_ok ? 0u : 1u;
+          if (local < (uint32_t)kMaxBins) {
+            vmask |= 1u << j;
+            atomicAdd(&L.cnt[local], 1u);
+          }
         }
         prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
         if (W == 1) {
@@ -427,9 +480,11 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
     constexpr int PER = kTile / kThreads;
     Kmer<W> tk[PER];
     uint32_t ev[IN_FULL ? PER : 1], loc[PER];
+    uint32_t okm = 0;  // tuples of this lane that are binned
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       const uint32_t i = (uint32_t)q * kThreads + tid;
+      if (i < n) okm |= 1u << q;
       tk[q].w[0] = 0; if (W == 2) tk[q].w[W - 1] = 0;
       if (IN_FULL) ev[q] = 0;
       if (i < n) {
@@ -444,30 +499,36 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
       uint32_t hb;
       if (IN_FULL) {  // full key -> region, packed tuple
         uint32_t r;
-        const Kmer<W> qq = key_quot<W>(tk[q], isink.t.lb1, r);
+        const uint32_t lbq = lbq_of(isink.t);
+        const Kmer<W> key = tk[q];
+        const Kmer<W> qq = key_quot<W>(key, lbq, r);
         const uint32_t c = kmer_hash<W>(qq, 0, &hb);
-        loc[q] = r ^ (c & lmask);
+        const uint32_t G = r ^ (c & ((1u << lbq) - 1u));
+        loc[q] = G & lmask;
         tk[q] = tuple_pack<W>(qq, ev[q]);
+        if ((okm >> q & 1u) && (G >> isink.t.lb1) != isink.t.part) {
+          foreign_insert<W, ONECOL>(isink, key, ev[q], n_novel, full);
+          okm &= ~(1u << q);
+        }
       } else {        // packed tuple of a known region -> sub-table inside the region
         kmer_hash<W>(tuple_q<W>(tk[q]), 0, &hb);
         loc[q] = __umulhi(hb, isink.t.spb);
       }
       if (loc[q] >= bs.nlocal) loc[q] = bs.nlocal - 1;  // cannot happen for well-formed bins
-      if (i < n) atomicAdd(&L.cnt[loc[q]], 1u);
+      if (okm >> q & 1u) atomicAdd(&L.cnt[loc[q]], 1u);
+      (void)i;
     }
     BinRes<NB> res;
     bin_reserve<LDS, NB>(L, bs, out, ob0, res);
 #pragma unroll
     for (int q = 0; q < PER; q++) {  // sorted position goes into the high half of loc
-      const uint32_t i = (uint32_t)q * kThreads + tid;
-      if (i < n) loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
+      if (okm >> q & 1u) loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
     }
     bin_commit<LDS, NB>(L, bs, res);
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int q = 0; q < PER; q++) {
-        const uint32_t i = (uint32_t)q * kThreads + tid;
-        if (i < n) bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);
+        if (okm >> q & 1u) bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);
       }
       bin_writeout<W, ONECOL, false, LDS>(L, round, bs, out, ob0, region, isink, n_novel, full);
     }
@@ -544,7 +605,6 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
   constexpr int R = W + 1;  // words per slot in LDS
   const int tid = threadIdx.x;
   const uint32_t S = ONECOL ? (uint32_t)(W + 1) : t.S;
-  const uint32_t lmask = (1u << t.lb1) - 1u;
   uint32_t n_novel = 0, full = 0;
 
   for (uint32_t sub = blockIdx.x; sub < nsub; sub += gridDim.x) {
@@ -592,8 +652,8 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
           const Kmer<W> qq = tuple_q<W>(tk[q]);
           uint32_t hb;
           const uint32_t c = kmer_hash<W>(qq, 0, &hb);
-          const Kmer<W> key = key_unquot<W>(qq, t.lb1, region ^ (c & lmask));
-          lds_apply<W>(lds, key, (c >> t.lb1) & (kSubBuckets - 1), e, n_novel, full);
+          const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), r_of(t, region, c));
+          lds_apply<W>(lds, key, (c >> lbq_of(t)) & (kSubBuckets - 1), e, n_novel, full);
         }
     }
     __syncthreads();

@@ -38,6 +38,8 @@ struct TableView {
   uint64_t *rec;
   uint64_t nslots;   // = (spb << lb1) sub-tables of kSubSlots slots
   uint32_t lb1;      // log2 of the number of top-level regions ("L1 bins") of the table
+  uint32_t lbo;      // log2 of the number of shards (GPUs) the global table is split over
+  uint32_t part;     // which shard this table is (0 when lbo == 0)
   uint32_t spb;      // sub-tables per region
   uint32_t S;        // words per record
   uint32_t max_probe;
@@ -46,15 +48,17 @@ struct TableView {
 // ---------------------------------------------------------------------------
 // Table addressing: a quotient hash built on Lookup3
 // ---------------------------------------------------------------------------
-// key = (q << lb1) | r.  With (c, b) = lookup3(q) (the reference's bklk3 hash, both result
-// words):
-//     region  = r ^ (c & (2^lb1 - 1))            one Feistel round: uniform whatever r is
+// key = (q << lbq) | r with lbq = lb1 + lbo.  With (c, b) = lookup3(q) (the reference's bklk3
+// hash, both result words):
+//     G       = r ^ (c & (2^lbq - 1))            one Feistel round: uniform whatever r is
+//     owner   = G >> lb1                         shard (GPU) that holds the key: a hash prefix
+//     region  = G & (2^lb1 - 1)                  region of that shard's table
 //     sub     = region * spb + mulhi(b, spb)     sub-table
-//     bucket  = (c >> lb1) & 1023                start bucket inside the sub-table
-// Given the region, r = region ^ (c & mask) is recoverable from q alone, so a k-mer occurrence
+//     bucket  = (c >> lbq) & 1023                start bucket inside the sub-table
+// Given (owner, region), r = G ^ (c & mask) is recoverable from q alone, so a k-mer occurrence
 // that has been binned by region travels as q plus its edge byte in ONE 64-bit word per key
-// word (2k - lb1 <= 56 bits of q in the top word, edges in bits 56..63) -- mcx_defer.h.
-template <int W> __device__ __host__ __forceinline__ Kmer<W> key_quot(const Kmer<W> &key, uint32_t lb1, uint32_t &r)
+// word (2k - lbq <= 56 bits of q in the top word, edges in bits 56..63) -- mcx_defer.h.
+template <int W> __device__ __host__ __forceinline__ Kmer<W> key_quot(const Kmer<W> &key, uint32_t lb1 /* bits to split off */, uint32_t &r)
 {
   Kmer<W> q = key;
   r = 0;
@@ -75,21 +79,31 @@ template <int W> __device__ __host__ __forceinline__ Kmer<W> key_unquot(const Km
   }
   return key;
 }
-struct TableAddr { uint32_t region, sub, bucket; };
+__device__ __host__ __forceinline__ uint32_t lbq_of(const TableView &t) { return t.lb1 + t.lbo; }
+
+struct TableAddr { uint32_t G, region, sub, bucket; };
+// address from the quotient q and remainder r (r = low lbq bits of the key)
 template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t, const Kmer<W> &q, uint32_t r)
 {
   uint32_t b;
   const uint32_t c = kmer_hash<W>(q, 0, &b);
+  const uint32_t lbq = lbq_of(t);
   TableAddr a;
-  a.region = r ^ (c & ((1u << t.lb1) - 1u));
+  a.G = r ^ (c & ((1u << lbq) - 1u));
+  a.region = a.G & ((1u << t.lb1) - 1u);
   a.sub = a.region * t.spb + __umulhi(b, t.spb);
-  a.bucket = (c >> t.lb1) & (kSubBuckets - 1);
+  a.bucket = (c >> lbq) & (kSubBuckets - 1);
   return a;
+}
+// remainder of a key of THIS shard from its quotient hash word c and its region
+__device__ __forceinline__ uint32_t r_of(const TableView &t, uint32_t region, uint32_t c)
+{
+  return ((t.part << t.lb1) | region) ^ (c & ((1u << lbq_of(t)) - 1u));
 }
 template <int W> __device__ __forceinline__ uint64_t key_slot(const TableView &t, const Kmer<W> &key)
 {
   uint32_t r;
-  const Kmer<W> q = key_quot<W>(key, t.lb1, r);
+  const Kmer<W> q = key_quot<W>(key, lbq_of(t), r);
   const TableAddr a = addr_of<W>(t, q, r);
   return ((uint64_t)a.sub << kSubShift) + (uint64_t)a.bucket * kBucket;
 }

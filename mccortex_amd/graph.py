@@ -11,7 +11,9 @@ MCX_OK, MCX_ERR_ARG, MCX_ERR_NODEVICE, MCX_ERR_NOMEM, MCX_ERR_FULL, MCX_ERR_HIP,
 _LIB = None
 
 SYMBOLS = [
-    "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create", "mcx_graph_destroy",
+    "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
+    "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
+    "mcx_graph_key_owner", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
@@ -59,6 +61,12 @@ def lib():
     L.mcx_version.restype = C.c_char_p
     L.mcx_device_count.restype = C.c_int
     L.mcx_graph_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint64, C.c_int]
+    L.mcx_graph_create_shard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    L.mcx_graph_shard_layout.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), u64p, u64p]
+    L.mcx_graph_shard_bins_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64]
+    L.mcx_graph_add_segments_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.mcx_graph_key_owner.restype = C.c_uint32
+    L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
     L.mcx_graph_destroy.restype = None
     L.mcx_graph_reset.argtypes = [vp]
@@ -144,11 +152,12 @@ def _ptr(x):
 class Graph:
     """One coloured de Bruijn graph resident in the HBM of one GPU."""
 
-    def __init__(self, kmer_size, ncols=1, capacity=1 << 20, device=0):
+    def __init__(self, kmer_size, ncols=1, capacity=1 << 20, device=0, nparts=1, part=0):
         self.L = lib()
         self.k, self.ncols, self.W = kmer_size, ncols, _words(kmer_size)
+        self.nparts, self.part = nparts, part
         h = C.c_void_p()
-        _check(self.L.mcx_graph_create(C.byref(h), kmer_size, ncols, capacity, device))
+        _check(self.L.mcx_graph_create_shard(C.byref(h), kmer_size, ncols, capacity, device, nparts, part))
         self.h = h
 
     def close(self):
@@ -198,6 +207,23 @@ class Graph:
 
     def insert_tuples_dev(self, colour, d_keys, d_edges, n):
         _check(self.L.mcx_graph_insert_tuples_dev(self.h, colour, _ptr(d_keys), _ptr(d_edges), n))
+
+    def shard_layout(self, tuples_per_call):
+        """(segments per owner, tuples per segment, overflow capacity per owner)"""
+        segs, cap, ov = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(self.L.mcx_graph_shard_layout(self.h, int(tuples_per_call), C.byref(segs), C.byref(cap), C.byref(ov)))
+        return int(segs.value), int(cap.value), int(ov.value)
+
+    def shard_bins_dev(self, d_stream, nbytes, d_keys, d_counts, seg_cap, d_ov_keys, d_ov_edges, d_ov_counts, ov_cap):
+        _check(self.L.mcx_graph_shard_bins_dev(self.h, _ptr(d_stream), nbytes, _ptr(d_keys), _ptr(d_counts), seg_cap,
+                                               _ptr(d_ov_keys), _ptr(d_ov_edges), _ptr(d_ov_counts), ov_cap))
+
+    def add_segments_dev(self, colour, d_keys, d_counts, nseg, seg_cap, ntuples):
+        _check(self.L.mcx_graph_add_segments_dev(self.h, colour, _ptr(d_keys), _ptr(d_counts), nseg, seg_cap, int(ntuples)))
+
+    def key_owner(self, words):
+        a = (C.c_uint64 * 2)(*words)
+        return int(self.L.mcx_graph_key_owner(self.h, a))
 
     def sync(self):
         _check(self.L.mcx_graph_sync(self.h))

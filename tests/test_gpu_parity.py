@@ -245,3 +245,58 @@ def test_configure_profile_and_device_memory(mcx):
     g.add_reads(0, b, o)
     assert g.nkmers == n1
     g.close()
+
+
+@pytest.mark.parametrize("k,nparts", [(31, 4), (63, 2), (31, 8)])
+def test_sharded_table_compact_exchange(mcx, orc, k, nparts):
+    """N shards of one hash-prefix-sharded table, simulated on one GPU: every 'rank' k-merises its
+    own reads into per-(owner, region) bins of packed tuples (exchange format v2), every owner
+    consumes the blocks addressed to it; the union of the shard exports is the oracle's graph, every
+    key sits on the shard mcx_graph_key_owner names, and tiny segments exercise the overflow bins."""
+    import torch
+    from mccortex_amd import shard
+    g0 = synth.genome(60000, 31)
+    cap = 1 << 20
+    graphs = [mcx.Graph(k, 1, cap, nparts=nparts, part=p) for p in range(nparts)]
+    W = graphs[0].W
+    all_b, all_o = [], []
+    for r in range(nparts):
+        bases, offs = synth.reads(3000, 140, seed=70 + r, g=g0, n_frac=0.05)
+        if r == 0:  # hot keys
+            hb, ho = orc.pack_reads(["A" * 150] * 300 + ["ACGTTGCA" * 20] * 200)
+            bases = np.concatenate([bases, hb]); offs = np.concatenate([offs, offs[-1] + ho[1:]])
+        all_b.append(bases); all_o.append(offs)
+        stream = torch.from_numpy(synth.to_stream(bases, offs)).cuda()
+        ntup = 3500 * 120
+        segs, seg_cap, ov_cap = graphs[r].shard_layout(ntup)
+        if r == 1:
+            seg_cap = 16  # almost everything overflows
+            ov_cap = 1 << 20
+        keys = torch.zeros((nparts, segs, seg_cap, W), dtype=torch.int64, device="cuda")
+        counts = torch.zeros((nparts, segs), dtype=torch.int64, device="cuda")
+        ovk = torch.zeros((nparts, ov_cap, W), dtype=torch.int64, device="cuda")
+        ove = torch.zeros((nparts, ov_cap), dtype=torch.uint8, device="cuda")
+        ovc = torch.zeros(nparts, dtype=torch.int64, device="cuda")
+        graphs[r].shard_bins_dev(stream, stream.numel(), keys, counts, seg_cap, ovk, ove, ovc, ov_cap)
+        torch.cuda.synchronize(); graphs[r].sync()
+        cnt = torch.clamp(counts, max=seg_cap)
+        for o in range(nparts):  # "exchange": owner o takes block o
+            graphs[o].add_segments_dev(0, keys[o], counts[o], segs, seg_cap, int(cnt[o].sum()))
+            n_ov = int(ovc[o])
+            assert n_ov <= ov_cap
+            if n_ov:
+                graphs[o].insert_tuples_dev(0, ovk[o], ove[o], n_ov)
+            graphs[o].sync()
+    og = orc.Graph(k, 1, 1 << 21)
+    for b, o in zip(all_b, all_o):
+        og.add_reads(0, b, o)
+    want = og.ctx_bytes(True)[og.header_size():]
+    bodies = []
+    for p, g in enumerate(graphs):
+        kk, cc, ee = g.records(True)
+        for row in kk[::37]:
+            assert g.key_owner([int(x) for x in row]) == p
+        bodies.append(g.export(True))
+        g.close()
+    assert shard.merge_sorted_bodies(bodies, 8 * W + 5, 8 * W) == want
+    assert all(len(b) > 0 for b in bodies)
