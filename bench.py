@@ -8,7 +8,8 @@ resident in HBM as a '\\n'-separated byte stream; the default 10 steps are the 5
 
 N>1 (one process per GPU, torchrun): weak scaling -- every rank k-merises its own 5M-read batch
 per step (genome scaled to N x 200 Mbp so every shard sees the same load), bins the tuples by
-owner hash, exchanges them with one RCCL all-to-all and inserts what it owns.
+(owner shard, table region), exchanges fixed-size blocks of packed tuples with one RCCL all-to-all
+and inserts what it owns.
 """
 import argparse
 import json
@@ -118,6 +119,12 @@ def main():
     ap.add_argument("--defer-tuples", type=int, default=DEFER_TUPLES)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 (make,
+    # RCCL's version banner, ...) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,7 +159,10 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()  # hand the generator's temporaries back before the graph allocates
 
-    graph = mcx.Graph(K, 1, args.table_slots, device=local_rank)
+    sharded = world > 1 or force_shard
+    # N > 1: the table is sharded by quotient-hash prefix; every rank holds one shard of the same
+    # per-GPU size (weak scaling)
+    graph = mcx.Graph(K, 1, args.table_slots, device=local_rank, nparts=world, part=rank)
     if args.direct:
         graph.configure("defer", 0)
     else:
@@ -165,23 +175,28 @@ def main():
     ext = torch.cuda.ExternalStream(graph.stream, device=device)
     W = graph.W
 
-    sharded = world > 1 or force_shard
     if sharded:
-        # double-buffered owner bins: the partition of step n+1 (handle's stream) overlaps with the
-        # RCCL all-to-all of step n (torch's stream); received tuples are then binned for the
-        # deferred insert.  Nothing here reads the graph, so nothing flushes it.
-        bin_cap = int(B * (READ_LEN - K + 1) / world * 1.10) + 65536
-        send = [(torch.empty((world, bin_cap, W), dtype=torch.int64, device=device),
-                 torch.empty((world, bin_cap), dtype=torch.uint8, device=device),
-                 torch.zeros(world, dtype=torch.int64, device=device)) for _ in range(2)]
-        part_done = [torch.cuda.Event(), torch.cuda.Event()]
+        # Exchange format v2: the sender bins packed tuples by (owner, region); every owner's block
+        # has a fixed size, so one all-to-all per step moves them with no count round trip and no
+        # host synchronisation.  Send and receive sets are double buffered: k-merising step n+1
+        # (handle's stream) overlaps with the RCCL all-to-all of step n (torch's stream) and with
+        # the owner-side split of step n-1.  Nothing here reads the graph, so nothing flushes it.
+        ntup = B * (READ_LEN - K + 1)
+        segs, seg_cap, ov_cap = graph.shard_layout(ntup)
+        send = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
+        recv = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
+        filled = [torch.cuda.Event() for _ in range(2)]     # send[b] k-merised          (ext)
+        sent = [torch.cuda.Event() for _ in range(2)]       # send[b] -> recv[b] exchanged (torch)
+        consumed = [torch.cuda.Event() for _ in range(2)]   # recv[b] split by the owner  (ext)
+        cur = torch.cuda.current_stream()
 
-    def partition(i, buf):
-        sk, se, cnt = send[buf]
+    def partition(i, buf, first):
         with torch.cuda.stream(ext):
-            cnt.zero_()
-        graph.partition_stream_dev(batches[i], batches[i].numel(), world, bin_cap, sk, se, cnt)
-        part_done[buf].record(ext)
+            if not first:
+                ext.wait_event(sent[buf])       # the previous exchange out of this send set is over
+            send[buf].zero_counts()
+        send[buf].fill(graph, batches[i], batches[i].numel())
+        filled[buf].record(ext)
 
     def run_steps(idx):
         idx = list(idx)
@@ -191,21 +206,24 @@ def main():
             for i in idx:
                 graph.add_stream_dev(0, batches[i], batches[i].numel())
             return
-        live = []
-        partition(idx[0], 0)
+        partition(idx[0], 0, True)
         for n, i in enumerate(idx):
             buf = n % 2
-            part_done[buf].synchronize()           # this step's bins and counts are complete
             if n + 1 < len(idx):
-                partition(idx[n + 1], 1 - buf)     # overlaps with the exchange below
-            rk, re_, rc_ = shard.exchange(*send[buf])
-            torch.cuda.current_stream().synchronize()
-            graph.insert_tuples_dev(0, rk, re_, int(sum(rc_)))
-            live.append((rk, re_))                 # keep receive buffers alive until consumed
-            if len(live) > 2:
-                ext.synchronize()
-                del live[:-1]
+                partition(idx[n + 1], 1 - buf, n < 1)   # overlaps with the exchange below
+            cur.wait_event(filled[buf])
+            if n >= 2:
+                cur.wait_event(consumed[buf])           # recv[buf] is free again
+            send[buf].exchange_into(recv[buf])
+            sent[buf].record(cur)
+            ext.wait_event(sent[buf])
+            recv[buf].consume(graph, 0, ntup)
+            consumed[buf].record(ext)
         ext.synchronize()
+        cur.synchronize()
+        for b in send:
+            if b.overflowed():
+                raise SystemExit("an exchange overflow bin overflowed (tuples lost): raise ov_cap")
 
     def fence():
         torch.cuda.synchronize()
@@ -255,34 +273,34 @@ def main():
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel)},
         }
-        if not sharded:
-            prof = graph.profile()  # {kernel: (launches, total ms)} measured live with HIP events
-            gpu_ms = ev0.elapsed_time(ev1)
-            dom = max(prof, key=lambda n: prof[n][1])
-            calls, tot_ms = prof[dom]
-            avg_ms = tot_ms / calls
-            # algorithmic bytes of ONE launch of the dominant kernel: its per-occurrence figure
-            #  x the occurrences one launch processes
-            alg_bytes = KERNEL_ALG_BYTES[dom] * kmers_local / calls
-            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-            pipe_bytes = ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                               "avg_kernel_ms": avg_ms, "launches": calls, "alg_bytes_per_launch": alg_bytes,
-                               "kernels": {n: {"launches": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4)}
-                                           for n, (c, t) in prof.items()},
-                               "pipeline": {"gpu_ms": gpu_ms, "alg_bytes": pipe_bytes,
-                                            "achieved": pipe_bytes / (gpu_ms * 1e-3) / 1e9,
-                                            "frac": pipe_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "note": "SURVEY 8(d) 21.25 B per occurrence (+8 B per novel key) over the whole timed region"}}
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(batches[0], rank)
+        prof = graph.profile()  # {kernel: (launches, total ms)} measured live with HIP events
+        gpu_ms = ev0.elapsed_time(ev1)
+        dom = max(prof, key=lambda n: prof[n][1])
+        calls, tot_ms = prof[dom]
+        avg_ms = tot_ms / calls
+        # algorithmic bytes of ONE launch of the dominant kernel: its per-occurrence figure
+        #  x the occurrences one launch processes
+        alg_bytes = KERNEL_ALG_BYTES[dom] * kmers_local / calls
+        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+        pipe_bytes = ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_kernel_ms": avg_ms, "launches": calls, "alg_bytes_per_launch": alg_bytes,
+                           "kernels": {n: {"launches": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4)}
+                                       for n, (c, t) in prof.items()},
+                           "pipeline": {"gpu_ms": gpu_ms, "alg_bytes": pipe_bytes,
+                                        "achieved": pipe_bytes / (gpu_ms * 1e-3) / 1e9,
+                                        "frac": pipe_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "note": "SURVEY 8(d) 21.25 B per occurrence (+8 B per novel key) over the whole timed region"}}
+        if not args.no_cpu_baseline and not sharded:
+            out["cpu_baseline"] = cpu_baseline(batches[0], rank)
     if world > 1 or force_shard:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        sys.stdout.flush()
         sys.stderr.flush()
-        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing printed
+        os.write(json_fd, (json.dumps(out) + "\n").encode())  # the ONE JSON line on stdout
 
 
 if __name__ == "__main__":

@@ -137,6 +137,13 @@ int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void *d_keys,
 /* Owner of a canonical key in the exchange above (host-side helper for tests). */
 uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts);
 
+/* Like mcx_graph_insert_tuples_dev for tuples that sit in `nseg` segments of `seg_cap` slots with
+ * the fills in device memory (d_counts[nseg], u64; a fill above seg_cap is read as seg_cap), so the
+ * caller needs no host round trip to learn how many arrived: the overflow bins of the sharded
+ * exchange are consumed this way. */
+int mcx_graph_insert_tuple_segments_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_edges,
+                                        const void *d_counts, uint32_t nseg, uint64_t seg_cap);
+
 /* Sharded build, compact exchange: the sender bins packed occurrences (one 64-bit word per key
  * word) by (owner, region) of the sharded table, so every owner's block is one fixed-size message
  * and the receiver consumes it without re-binning.

@@ -287,7 +287,7 @@ template <int W, bool ONECOL> static void launch_direct_t(mcx_graph *g, const St
                      g->stream, a, is);
 }
 
-template <int W, bool ONECOL, bool FULL>
+template <int W, bool ONECOL, bool FULL, int SH>
 static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour, BinSpec bs, BinOut out)
 {
   const StreamArgs a = make_args(g, L);
@@ -296,19 +296,19 @@ static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour,
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
   static bool once = false;
   if (!once) {
-    allow_lds(k_stream_bin<W, ONECOL, 512, FULL>, sizeof(BinLds<W, 512, FULL>));
-    allow_lds(k_stream_bin<W, ONECOL, kMaxBins, FULL>, sizeof(BinLds<W, kMaxBins, FULL>));
+    allow_lds(k_stream_bin<W, ONECOL, 512, FULL, SH>, sizeof(BinLds<W, 512, FULL>));
+    allow_lds(k_stream_bin<W, ONECOL, kMaxBins, FULL, SH>, sizeof(BinLds<W, kMaxBins, FULL>));
     once = true;
   }
   SpanGuard sp(g, "k_stream_bin");
   const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
   if (bs.nlocal <= 512)
-    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL>), grid, dim3(kThreads), sizeof(BinLds<W, 512, FULL>), g->stream, a, bs, out, is);
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, 512, FULL>), g->stream, a, bs, out, is);
   else
-    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins, FULL>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, FULL>), g->stream, a, bs, out, is);
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, FULL>), g->stream, a, bs, out, is);
 }
 
-template <int W, bool ONECOL, bool IN_FULL>
+template <int W, bool ONECOL, bool IN_FULL, bool SHARD>
 static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
 {
   const uint64_t nchunks = (in.seg_cap + kTile - 1) / kTile * in.nseg;
@@ -316,23 +316,30 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
   static bool once = false;
   if (!once) {
-    allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL>, sizeof(BinLds<W, 512, false>));
-    allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL>, sizeof(BinLds<W, kMaxBins, false>));
+    allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>, sizeof(BinLds<W, 512, false>));
+    allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD>, sizeof(BinLds<W, kMaxBins, false>));
     once = true;
   }
   SpanGuard sp(g, "k_tuples_bin");
   const dim3 grid((unsigned)std::min<uint64_t>(nchunks, (uint64_t)g->grid * 4));
   if (bs.nlocal <= 512)
-    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL>), grid, dim3(kThreads), sizeof(BinLds<W, 512, false>), g->stream, in, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>), grid, dim3(kThreads), sizeof(BinLds<W, 512, false>), g->stream, in, bs, out, is, g->d_ctr);
   else
-    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, false>), g->stream, in, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, false>), g->stream, in, bs, out, is, g->d_ctr);
 }
+// keys of other shards can only show up in a sharded table (lbo > 0): the check is compiled apart
 template <int W, bool ONECOL> static void launch_bin_region_stream(mcx_graph *g, const StreamLaunch &L, int colour, BinSpec bs, BinOut out)
-{ launch_bin_stream_t<W, ONECOL, false>(g, L, colour, bs, out); }
+{
+  if (g->t.lbo) launch_bin_stream_t<W, ONECOL, false, 1>(g, L, colour, bs, out);
+  else launch_bin_stream_t<W, ONECOL, false, 0>(g, L, colour, bs, out);
+}
 template <int W, bool ONECOL> static void launch_split_regions(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
-{ launch_bin_tuples_t<W, ONECOL, false>(g, in, colour, bs, out); }
+{ launch_bin_tuples_t<W, ONECOL, false, false>(g, in, colour, bs, out); }
 template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
-{ launch_bin_tuples_t<W, ONECOL, true>(g, in, colour, bs, out); }
+{
+  if (g->t.lbo) launch_bin_tuples_t<W, ONECOL, true, true>(g, in, colour, bs, out);
+  else launch_bin_tuples_t<W, ONECOL, true, false>(g, in, colour, bs, out);
+}
 
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour)
 {
@@ -534,8 +541,8 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
   BinSpec bs{BIN_OWNER, (uint32_t)nparts, (uint32_t)nparts, 1, (uint32_t)nparts, 1, 0};
   BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity, nullptr, nullptr, nullptr, 0};
-  if (g->W == 1) launch_bin_stream_t<1, true, true>(g, L, 0, bs, out);
-  else launch_bin_stream_t<2, true, true>(g, L, 0, bs, out);
+  if (g->W == 1) launch_bin_stream_t<1, true, true, 0>(g, L, 0, bs, out);
+  else launch_bin_stream_t<2, true, true, 0>(g, L, 0, bs, out);
   HIP_TRY(hipGetLastError());
   return MCX_OK;
 }
@@ -564,6 +571,29 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
     g->pending += cnt;
     lo += cnt;
   }
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_insert_tuple_segments_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_edges,
+                                                   const void *d_counts, uint32_t nseg, uint64_t seg_cap)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+  if (!nseg || !seg_cap) return MCX_OK;
+  if (!d_keys || !d_edges || !d_counts) return fail(MCX_ERR_ARG, "null tuple buffers");
+  HIP_TRY(hipSetDevice(g->device));
+  int rc = ensure_defer(g);
+  if (rc != MCX_OK) return rc;
+  if (!g->defer) return fail(MCX_ERR_ARG, "tuple segments need the deferred insert path (table too small or defer=0)");
+  const uint64_t ub = (uint64_t)nseg * seg_cap;  // the fills are only known on the device
+  rc = defer_reserve(g, colour, ub);
+  if (rc != MCX_OK) return rc;
+  TupleIn in{(const uint64_t *)d_keys, (const uint8_t *)d_edges, (const unsigned long long *)d_counts, seg_cap, nseg};
+  BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0};
+  BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
+  DISPATCH_WC(g, launch_bin_received, g, in, colour, bs, out);
+  HIP_TRY(hipGetLastError());
+  g->pending += ub;
   return MCX_OK;
 }
 
@@ -601,8 +631,8 @@ extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint
   BinSpec bs{BIN_GLOBAL, nparts, nparts * b1, kShardRep, b1, 1, g->t.lb1};
   BinOut out{(uint64_t *)d_keys, nullptr, (unsigned long long *)d_counts, seg_cap,
              (uint64_t *)d_ov_keys, (uint8_t *)d_ov_edges, (unsigned long long *)d_ov_counts, ov_cap};
-  if (g->W == 1) launch_bin_stream_t<1, true, false>(g, L, 0, bs, out);
-  else launch_bin_stream_t<2, true, false>(g, L, 0, bs, out);
+  if (g->W == 1) launch_bin_stream_t<1, true, false, 2>(g, L, 0, bs, out);
+  else launch_bin_stream_t<2, true, false, 2>(g, L, 0, bs, out);
   HIP_TRY(hipGetLastError());
   return MCX_OK;
 }

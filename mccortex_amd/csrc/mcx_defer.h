@@ -175,7 +175,7 @@ __device__ __forceinline__ void bin_place(LDS &L, int round, uint32_t p, uint32_
 // Linear write-out of one round: consecutive lanes write consecutive tuples of a bin.  Tuples
 // beyond a bin's capacity take the direct insert (deferred modes; the region of a packed tuple
 // is its bin in BIN_GROUP and `region_of_seg` in BIN_SUBLOCAL) or raise bin_over (owner mode).
-template <int W, bool ONECOL, bool FULL, class LDS>
+template <int W, bool ONECOL, bool FULL, int SH, class LDS>
 __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &bs, const BinOut &out, uint32_t ob0,
                                              uint32_t region_of_seg, const InsertSink<W, ONECOL> &isink,
                                              uint32_t &novel, uint32_t &full)
@@ -193,7 +193,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
       kd[0] = L.skey[q * W];
       if (W == 2) kd[1] = L.skey[q * W + 1];
       if (FULL) out.edges[at] = L.se[q];
-    } else if (bs.mode == BIN_OWNER) {
+    } else if (FULL || bs.mode == BIN_OWNER) {
       full = 2;
     } else {  // packed tuple -> full key
       Kmer<W> tq;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
       uint32_t hb;
       const uint32_t c = kmer_hash<W>(qq, 0, &hb);
       const uint32_t lbq = lbq_of(isink.t);
-      if (bs.mode == BIN_GLOBAL) {  // ... appended to the owner's overflow bin (full format)
+      if (SH == 2) {  // BIN_GLOBAL ... appended to the owner's overflow bin (full format)
         const Kmer<W> key = key_unquot<W>(qq, lbq, b ^ (c & ((1u << lbq) - 1u)));
         const uint32_t owner = b >> bs.lb1;
         const unsigned long long pos = atomicAdd(&out.ov_counts[owner], 1ULL);
@@ -243,9 +243,11 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
 
 // ---------------------------------------------------------------------------
 // 1. reads -> bins.  FULL = owner bins (key words + edge byte, nparts bins);
-//    !FULL = region bins of the local table (packed tuples)
+//    !FULL = region bins (packed tuples): SH 0 of an unsharded table, SH 1 of this shard (keys of
+//    other shards take the direct insert), SH 2 of every shard (BIN_GLOBAL, exchange blocks).
+//    The variants are compiled apart: code of the rare paths costs the common one registers.
 // ---------------------------------------------------------------------------
-template <int W, bool ONECOL, int NB, bool FULL>
+template <int W, bool ONECOL, int NB, bool FULL, int SH>
 __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
                                                                          InsertSink<W, ONECOL> isink)
 {
@@ -356,10 +358,10 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
             const Kmer<W> q = key_quot<W>(key, lbq, r);
             const uint32_t c = kmer_hash<W>(q, 0, &hb);
             const uint32_t G = r ^ (c & ((1u << lbq) - 1u));  // (owner, region) of the key
-            local = bs.mode == BIN_GLOBAL ? G : (G & ((1u << isink.t.lb1) - 1u));
+            local = SH == 2 ? G : (G & ((1u << isink.t.lb1) - 1u));
             tk[j] = tuple_pack<W>(q, e);
             tle[j] = local << 8;
-            if (bs.mode != BIN_GLOBAL && (G >> isink.t.lb1) != isink.t.part) {
+            if (SH == 1 && (G >> isink.t.lb1) != isink.t.part) {
               foreign_insert<W, ONECOL>(isink, key, e, n_novel, full);
               local = kMaxBins;  // not binned
             }
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
       for (int j = 0; j < kPosPerLane; j++)
         if (vmask & (1u << j))
           bin_place<W, FULL, LDS>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], tle[j] & 0xffu);
-      bin_writeout<W, ONECOL, FULL, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
+      bin_writeout<W, ONECOL, FULL, SH, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
     }
   }
 
@@ -420,7 +422,7 @@ struct TupleIn {
   uint32_t nseg;
 };
 
-template <int W, bool ONECOL, int NB, bool IN_FULL>
+template <int W, bool ONECOL, int NB, bool IN_FULL, bool SHARD>
 __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
                                                                          InsertSink<W, ONECOL> isink, Counters *ctr)
 {
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
         const uint32_t G = r ^ (c & ((1u << lbq) - 1u));
         loc[q] = G & lmask;
         tk[q] = tuple_pack<W>(qq, ev[q]);
-        if ((okm >> q & 1u) && (G >> isink.t.lb1) != isink.t.part) {
+        if (SHARD && (okm >> q & 1u) && (G >> isink.t.lb1) != isink.t.part) {
           foreign_insert<W, ONECOL>(isink, key, ev[q], n_novel, full);
           okm &= ~(1u << q);
         }
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
       for (int q = 0; q < PER; q++) {
         if (okm >> q & 1u) bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);
       }
-      bin_writeout<W, ONECOL, false, LDS>(L, round, bs, out, ob0, region, isink, n_novel, full);
+      bin_writeout<W, ONECOL, false, 0, LDS>(L, round, bs, out, ob0, region, isink, n_novel, full);
     }
   }
   if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);

@@ -13,7 +13,7 @@ _LIB = None
 SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
-    "mcx_graph_key_owner", "mcx_graph_destroy",
+    "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
@@ -65,6 +65,7 @@ def lib():
     L.mcx_graph_shard_layout.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), u64p, u64p]
     L.mcx_graph_shard_bins_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64]
     L.mcx_graph_add_segments_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.mcx_graph_insert_tuple_segments_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32, C.c_uint64]
     L.mcx_graph_key_owner.restype = C.c_uint32
     L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
@@ -220,6 +221,10 @@ class Graph:
 
     def add_segments_dev(self, colour, d_keys, d_counts, nseg, seg_cap, ntuples):
         _check(self.L.mcx_graph_add_segments_dev(self.h, colour, _ptr(d_keys), _ptr(d_counts), nseg, seg_cap, int(ntuples)))
+
+    def insert_tuple_segments_dev(self, colour, d_keys, d_edges, d_counts, nseg, seg_cap):
+        _check(self.L.mcx_graph_insert_tuple_segments_dev(self.h, colour, _ptr(d_keys), _ptr(d_edges), _ptr(d_counts),
+                                                          nseg, seg_cap))
 
     def key_owner(self, words):
         a = (C.c_uint64 * 2)(*words)

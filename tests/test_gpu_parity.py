@@ -272,20 +272,17 @@ def test_sharded_table_compact_exchange(mcx, orc, k, nparts):
         if r == 1:
             seg_cap = 16  # almost everything overflows
             ov_cap = 1 << 20
-        keys = torch.zeros((nparts, segs, seg_cap, W), dtype=torch.int64, device="cuda")
-        counts = torch.zeros((nparts, segs), dtype=torch.int64, device="cuda")
-        ovk = torch.zeros((nparts, ov_cap, W), dtype=torch.int64, device="cuda")
-        ove = torch.zeros((nparts, ov_cap), dtype=torch.uint8, device="cuda")
-        ovc = torch.zeros(nparts, dtype=torch.int64, device="cuda")
-        graphs[r].shard_bins_dev(stream, stream.numel(), keys, counts, seg_cap, ovk, ove, ovc, ov_cap)
+        blk = shard.BlockExchange(nparts, segs, seg_cap, ov_cap, W, "cuda")
+        blk.fill(graphs[r], stream, stream.numel())
         torch.cuda.synchronize(); graphs[r].sync()
-        cnt = torch.clamp(counts, max=seg_cap)
-        for o in range(nparts):  # "exchange": owner o takes block o
-            graphs[o].add_segments_dev(0, keys[o], counts[o], segs, seg_cap, int(cnt[o].sum()))
-            n_ov = int(ovc[o])
-            assert n_ov <= ov_cap
-            if n_ov:
-                graphs[o].insert_tuples_dev(0, ovk[o], ove[o], n_ov)
+        assert not blk.overflowed()
+        if r == 1:
+            assert int(blk.ov_counts.sum()) > 10000
+        for o in range(nparts):  # "exchange": owner o takes block o of every sender
+            rb = shard.BlockExchange(1, segs, seg_cap, ov_cap, W, "cuda")
+            rb.keys[0], rb.counts[0], rb.ov_keys[0], rb.ov_edges[0], rb.ov_counts[0] = \
+                blk.keys[o], blk.counts[o], blk.ov_keys[o], blk.ov_edges[o], blk.ov_counts[o]
+            rb.consume(graphs[o], 0, ntup // nparts)
             graphs[o].sync()
     og = orc.Graph(k, 1, 1 << 21)
     for b, o in zip(all_b, all_o):

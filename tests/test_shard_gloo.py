@@ -75,3 +75,40 @@ def test_two_rank_exchange_equals_single_graph(mcx, orc, tmp_path, k):
         o = np.load(tmp_path / ("off%d.npy" % r))
         og.add_reads(0, b, o)
     assert merged == og.ctx_bytes(True)[og.header_size():]
+
+
+def _block_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mccortex_amd import shard
+    shard.MAX_BLOCK_BYTES = 4096  # several rounds over the segment axis
+    segs, seg_cap, ov_cap, W = 24, 50, 33, 2
+
+    def stamp(src, dst):  # what rank `src` addresses to rank `dst`
+        g = torch.Generator().manual_seed(1000 * src + dst)
+        return (torch.randint(-2**62, 2**62, (segs, seg_cap, W), generator=g),
+                torch.randint(0, seg_cap + 5, (segs,), generator=g),
+                torch.randint(-2**62, 2**62, (ov_cap, W), generator=g),
+                torch.randint(0, 256, (ov_cap,), generator=g).to(torch.uint8),
+                torch.randint(0, ov_cap, (1,), generator=g))
+
+    send = shard.BlockExchange(world, segs, seg_cap, ov_cap, W, "cpu")
+    recv = shard.BlockExchange(world, segs, seg_cap, ov_cap, W, "cpu")
+    for p in range(world):
+        k, c, ok, oe, oc = stamp(rank, p)
+        send.keys[p], send.counts[p], send.ov_keys[p], send.ov_edges[p], send.ov_counts[p] = k, c, ok, oe, oc[0]
+    send.exchange_into(recv)
+    for p in range(world):
+        k, c, ok, oe, oc = stamp(p, rank)
+        assert torch.equal(recv.keys[p], k) and torch.equal(recv.counts[p], c)
+        assert torch.equal(recv.ov_keys[p], ok) and torch.equal(recv.ov_edges[p], oe)
+        assert int(recv.ov_counts[p]) == int(oc[0])
+    assert not send.overflowed()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_block_exchange_routes_fixed_blocks(mcx, world):
+    mp.spawn(_block_worker, args=(world, _free_port()), nprocs=world, join=True)
