@@ -84,6 +84,8 @@ int mcx_graph_reset(mcx_graph *g);
  *                  occurrence is inserted straight into the HBM table with device atomics.
  *                  Both give the same graph.
  *   "defer_tuples" occurrences buffered per flush (sizes the bin workspace in HBM)
+ *   "flush_regions" table regions split + applied per step of a flush (0 = automatic: 16 K sub-tables
+ *                  per step); bounds the sub-table bin workspace to that share of the table
  *   "profile"      1: time every kernel launch with HIP events (see mcx_graph_profile) */
 int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value);
 /* "kernel calls total_ms" per line for the launches recorded since "profile" was set. */

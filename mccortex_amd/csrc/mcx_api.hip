@@ -79,6 +79,9 @@ struct mcx_graph {
   unsigned long long *l1_cnt = nullptr, *l2_cnt = nullptr;
   uint64_t pending = 0;         // upper bound of tuples sitting in the L1 bins
   uint64_t pending_l2 = 0;      // tuples already split into the sub-table bins (sharded receive path)
+  uint32_t l2_regions = 0;      // regions the L2 (sub-table) bins cover: a flush splits and applies
+                                // the L1 bins in groups of this many regions, reusing the same bins
+  uint32_t flush_regions = 0;   // configured group size (0 = automatic)
   int pending_colour = 0;
   // ---- optional per-kernel timing (mcx_graph_configure("profile", 1)) ----
   bool profile = false;
@@ -217,7 +220,7 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
   if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
-  if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
+  if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->l2_regions * g->subs_per_bin * 8, g->stream));
   g->pending = g->pending_l2 = 0;  // buffered tuples are discarded with the table
   return MCX_OK;
 }
@@ -341,15 +344,15 @@ template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, Tupl
   else launch_bin_tuples_t<W, ONECOL, true, false>(g, in, colour, bs, out);
 }
 
-template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour)
+template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour, uint32_t sub0, uint32_t nsub)
 {
   const size_t lds = kSubSlots * (W + 1) * 8;
   static bool once = false;
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
   BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
   SpanGuard sp(g, "k_lds_insert");
-  hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(g->nsub, (uint64_t)g->grid * 4)),
-                     dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, g->nsub, g->d_ctr);
+  hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nsub, (uint64_t)g->grid * 4)),
+                     dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, sub0, nsub, g->d_ctr);
 }
 
 template <int W, bool ONECOL>
@@ -368,6 +371,48 @@ static void free_defer(mcx_graph *g)
   (void)hipFree(g->l2_keys); (void)hipFree(g->l2_cnt);
   g->l1_keys = g->l2_keys = nullptr; g->l1_cnt = g->l2_cnt = nullptr;
   g->cap1 = g->cap2 = 0;
+  g->l2_regions = 0;
+}
+
+// The sub-table (L2) bins cover `regions` regions at a time.  A flush walks the L1 bins in groups
+// of that many regions: split the group by sub-table, apply it in LDS, reuse the same bins for the
+// next group -- so the bins take a fraction (group / regions) of what bins for the whole table
+// would (80 GB for 8 G occurrences per flush on the bench shape).  Blocks received from other shards are split on arrival
+// (mcx_graph_add_segments_dev), which needs bins for all regions at once.
+static int ensure_l2(mcx_graph *g, uint32_t regions)
+{
+  if (g->l2_keys && g->l2_regions >= regions) return MCX_OK;
+  if (g->pending_l2) return fail(MCX_ERR_ARG, "internal: sub-table bins resized while in use");
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  (void)hipFree(g->l2_keys); (void)hipFree(g->l2_cnt);
+  g->l2_keys = nullptr; g->l2_cnt = nullptr; g->l2_regions = 0;
+  const uint64_t nb = (uint64_t)regions * g->subs_per_bin;
+  if (hipMalloc((void **)&g->l2_keys, nb * g->cap2 * 8 * g->W) != hipSuccess ||
+      hipMalloc((void **)&g->l2_cnt, nb * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(g->l2_keys); g->l2_keys = nullptr;
+    return fail(MCX_ERR_NOMEM, "out of device memory for the sub-table bins (%llu regions)", (unsigned long long)regions);
+  }
+  HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, nb * 8, g->stream));
+  g->l2_regions = regions;
+  return MCX_OK;
+}
+
+// regions per flush group: enough sub-tables for one full wave of LDS-insert workgroups, few
+// enough for the split output to stay cache resident
+static uint32_t flush_group(const mcx_graph *g)
+{
+  uint32_t G = g->flush_regions;
+  if (!G) {
+    const char *e = getenv("MCX_FLUSH_REGIONS");
+    G = e ? (uint32_t)strtoul(e, nullptr, 10) : 0;
+  }
+  // measured on the bench shape (512 regions x 512 sub-tables, profiles/r01g): groups of 32..512
+  // regions run at the same speed (1, 2, 4 regions per step: launch tails dominate, the hoped-for
+  // cache residency of one region's split does not pay); 16 K sub-tables per step = 32 waves of
+  // insert workgroups, and the bins take 1/16 of what bins for the whole table would
+  if (!G) G = std::max<uint32_t>(1u, 16384u / std::max<uint32_t>(1u, g->subs_per_bin));
+  return std::min<uint32_t>(G, g->b1);
 }
 
 static int ensure_defer(mcx_graph *g)
@@ -391,36 +436,40 @@ static int ensure_defer(mcx_graph *g)
     g->cap1 = (uint64_t)((double)tcap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + 8192;
     g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
     if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) continue;
-    const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1, n2 = (uint64_t)g->nsub * g->cap2;
+    const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1;
     const bool ok = hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W) == hipSuccess &&
                     hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * g->rep1 * 8) == hipSuccess &&
-                    hipMalloc((void **)&g->l2_keys, n2 * 8 * g->W) == hipSuccess &&
-                    hipMalloc((void **)&g->l2_cnt, (size_t)g->nsub * 8) == hipSuccess;
+                    ensure_l2(g, flush_group(g)) == MCX_OK;
     if (ok) break;
     free_defer(g);
     (void)hipGetLastError();  // clear the sticky out-of-memory error
   }
   HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
-  HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
   return MCX_OK;
 }
 
-// Split every L1 bin by sub-table, then let one workgroup per sub-table apply its tuples in LDS.
+// Split the L1 bins by sub-table and let one workgroup per sub-table apply its tuples in LDS,
+// one group of regions at a time.
 static int flush_deferred(mcx_graph *g)
 {
   if (!g->pending && !g->pending_l2) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
-  if (g->pending) {
-    TupleIn in{g->l1_keys, nullptr, g->l1_cnt, g->cap1, g->b1 * g->rep1};
-    BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1, 0};
-    BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
-    DISPATCH_WC(g, launch_split_regions, g, in, g->pending_colour, bs, out);
+  // tuples that were split on arrival occupy bins of all regions: everything goes through them
+  const uint32_t G = g->pending_l2 ? g->b1 : std::min(flush_group(g), g->l2_regions);
+  if (g->pending_l2 && g->l2_regions < g->b1) return fail(MCX_ERR_ARG, "internal: split tuples without bins");
+  for (uint32_t r0 = 0; r0 < g->b1; r0 += G) {
+    const uint32_t ng = std::min(G, g->b1 - r0);
+    if (g->pending) {
+      TupleIn in{g->l1_keys + (uint64_t)r0 * g->cap1 * g->W, nullptr, g->l1_cnt + r0, g->cap1, ng * g->rep1, ng, g->b1};
+      BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, ng * g->subs_per_bin, ng, 0, r0};
+      BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
+      DISPATCH_WC(g, launch_split_regions, g, in, g->pending_colour, bs, out);
+      HIP_TRY(hipGetLastError());
+    }
+    DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour, r0 * g->subs_per_bin, ng * g->subs_per_bin);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   }
-  DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->nsub * 8, g->stream));
+  if (g->pending) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   g->pending = 0;
   g->pending_l2 = 0;
   return MCX_OK;
@@ -455,7 +504,7 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     if (rc != MCX_OK) return rc;
     StreamLaunch P = L;
     P.pos_lo = lo; P.pos_hi = hi;
-    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0};
+    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
     BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
     DISPATCH_WC(g, launch_bin_region_stream, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
@@ -481,6 +530,13 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     HIP_TRY(hipStreamSynchronize(g->stream));
     free_defer(g);
     g->defer_tuples = value;
+    return MCX_OK;
+  }
+  if (!strcmp(key, "flush_regions")) {  // regions split + applied per step of a flush (0 = automatic)
+    int rc = flush_deferred(g);
+    if (rc != MCX_OK) return rc;
+    g->flush_regions = (uint32_t)value;
+    if (g->l1_keys) return ensure_l2(g, flush_group(g));
     return MCX_OK;
   }
   if (!strcmp(key, "profile")) {
@@ -539,7 +595,7 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
   if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  BinSpec bs{BIN_OWNER, (uint32_t)nparts, (uint32_t)nparts, 1, (uint32_t)nparts, 1, 0};
+  BinSpec bs{BIN_OWNER, (uint32_t)nparts, (uint32_t)nparts, 1, (uint32_t)nparts, 1, 0, 0};
   BinOut out{(uint64_t *)d_keys, (uint8_t *)d_edges, (unsigned long long *)d_counts, bin_capacity, nullptr, nullptr, nullptr, 0};
   if (g->W == 1) launch_bin_stream_t<1, true, true, 0>(g, L, 0, bs, out);
   else launch_bin_stream_t<2, true, true, 0>(g, L, 0, bs, out);
@@ -563,8 +619,8 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
     const uint64_t cnt = std::min(n - lo, g->defer_tuples);
     int rc = defer_reserve(g, colour, cnt);
     if (rc != MCX_OK) return rc;
-    TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1};
-    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0};
+    TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1, 1, 1};
+    BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
     BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
     DISPATCH_WC(g, launch_bin_received, g, in, colour, bs, out);
     HIP_TRY(hipGetLastError());
@@ -588,8 +644,8 @@ extern "C" int mcx_graph_insert_tuple_segments_dev(mcx_graph *g, int colour, con
   const uint64_t ub = (uint64_t)nseg * seg_cap;  // the fills are only known on the device
   rc = defer_reserve(g, colour, ub);
   if (rc != MCX_OK) return rc;
-  TupleIn in{(const uint64_t *)d_keys, (const uint8_t *)d_edges, (const unsigned long long *)d_counts, seg_cap, nseg};
-  BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0};
+  TupleIn in{(const uint64_t *)d_keys, (const uint8_t *)d_edges, (const unsigned long long *)d_counts, seg_cap, nseg, nseg, nseg};
+  BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
   BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
   DISPATCH_WC(g, launch_bin_received, g, in, colour, bs, out);
   HIP_TRY(hipGetLastError());
@@ -628,7 +684,7 @@ extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint
   HIP_TRY(hipSetDevice(g->device));
   const uint32_t nparts = 1u << g->t.lbo, b1 = 1u << g->t.lb1;
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
-  BinSpec bs{BIN_GLOBAL, nparts, nparts * b1, kShardRep, b1, 1, g->t.lb1};
+  BinSpec bs{BIN_GLOBAL, nparts, nparts * b1, kShardRep, b1, 1, g->t.lb1, 0};
   BinOut out{(uint64_t *)d_keys, nullptr, (unsigned long long *)d_counts, seg_cap,
              (uint64_t *)d_ov_keys, (uint8_t *)d_ov_edges, (unsigned long long *)d_ov_counts, ov_cap};
   if (g->W == 1) launch_bin_stream_t<1, true, false, 2>(g, L, 0, bs, out);
@@ -650,8 +706,10 @@ extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *
   if (nseg % g->b1) return fail(MCX_ERR_ARG, "segments must cover whole sets of %u regions", g->b1);
   rc = defer_reserve(g, colour, ntuples);
   if (rc != MCX_OK) return rc;
-  TupleIn in{(const uint64_t *)d_keys, nullptr, (const unsigned long long *)d_counts, seg_cap, nseg};
-  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1, 0};
+  rc = ensure_l2(g, g->b1);  // split on arrival: bins for every region
+  if (rc != MCX_OK) return rc;
+  TupleIn in{(const uint64_t *)d_keys, nullptr, (const unsigned long long *)d_counts, seg_cap, nseg, nseg, nseg};
+  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1, 0, 0};
   BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
   DISPATCH_WC(g, launch_split_regions, g, in, colour, bs, out);
   HIP_TRY(hipGetLastError());

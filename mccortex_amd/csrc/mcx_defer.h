@@ -42,8 +42,9 @@ struct BinSpec {
   // which merges the 8-tuple runs into full-line write-backs (speed only, never correctness).
   uint32_t rep;
   uint32_t nout;     // output bins per replica
-  uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s holds region s % seg_mod
+  uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s holds region region0 + s % seg_mod
   uint32_t lb1;      // BIN_GLOBAL: log2 regions per owner
+  uint32_t region0;  // BIN_SUBLOCAL: first region of the group being split (output bins are group-local)
 };
 
 // index of the output segment of local bin b
@@ -420,6 +421,9 @@ struct TupleIn {
   const unsigned long long *counts;  // [nseg] or nullptr (every segment holds seg_cap tuples)
   uint64_t seg_cap;
   uint32_t nseg;
+  // segment s sits at physical index (s / seg_group) * seg_stride + s % seg_group: a group of
+  // regions inside the replica-major L1 bins (seg_group == seg_stride: plain [nseg] array)
+  uint32_t seg_group, seg_stride;
 };
 
 template <int W, bool ONECOL, int NB, bool IN_FULL, bool SHARD>
@@ -466,17 +470,19 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
       seg = (uint32_t)(v % nseg_g);  // segment-interleaved
       start = (v / nseg_g) * kTile;
     }
-    uint64_t cnt = in.counts ? (uint64_t)in.counts[seg] : in.seg_cap;
+    const uint64_t pseg = (uint64_t)(seg / in.seg_group) * in.seg_stride + seg % in.seg_group;
+    uint64_t cnt = in.counts ? (uint64_t)in.counts[pseg] : in.seg_cap;
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (start >= cnt) continue;  // uniform across the block
     const uint32_t n = (uint32_t)min((uint64_t)kTile, cnt - start);
-    const uint32_t region = bs.mode == BIN_SUBLOCAL ? seg % bs.seg_mod : 0;  // block-uniform
-    const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? region * isink.t.spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
+    const uint32_t lregion = bs.mode == BIN_SUBLOCAL ? seg % bs.seg_mod : 0;  // block-uniform
+    const uint32_t region = bs.region0 + lregion;
+    const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? lregion * isink.t.spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
     __syncthreads();
     for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
     __syncthreads();
-    const uint64_t *kin = in.keys + ((uint64_t)seg * in.seg_cap + start) * W;
-    const uint8_t *ein = IN_FULL ? in.edges + (uint64_t)seg * in.seg_cap + start : nullptr;
+    const uint64_t *kin = in.keys + (pseg * in.seg_cap + start) * W;
+    const uint8_t *ein = IN_FULL ? in.edges + pseg * in.seg_cap + start : nullptr;
     // each lane keeps its kTile/kThreads tuples in registers: all loads are issued up front
     // (memory-level parallelism) and the placement sweep does not re-read HBM
     constexpr int PER = kTile / kThreads;
@@ -599,7 +605,7 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
 
 template <int W, bool ONECOL>
 __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
-                                                                    uint32_t nsub, Counters *ctr)
+                                                                    uint32_t sub0, uint32_t nsub, Counters *ctr)
 {
   constexpr int kLdsThreads = LdsCfg<W>::kThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -609,13 +615,17 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
   const uint32_t S = ONECOL ? (uint32_t)(W + 1) : t.S;
   uint32_t n_novel = 0, full = 0;
 
-  for (uint32_t sub = blockIdx.x; sub < nsub; sub += gridDim.x) {
-    uint64_t n = bins.counts[sub];
+  // sub-tables sub0 .. sub0 + nsub - 1; bin i of `bins` belongs to sub-table sub0 + i and is handed
+  // back empty (fill reset) for the next group of regions
+  for (uint32_t bi = blockIdx.x; bi < nsub; bi += gridDim.x) {
+    const uint32_t sub = sub0 + bi;
+    uint64_t n = bins.counts[bi];
     if (n == 0) continue;  // uniform
     if (n > bins.cap) n = bins.cap;
     const uint32_t region = sub / t.spb;  // uniform
     uint64_t *slice = t.rec + (uint64_t)sub * kSubSlots * S;
-    __syncthreads();
+    __syncthreads();  // (every thread has read the fill)
+    if (tid == 0) bins.counts[bi] = 0;
     constexpr int PER = (int)(kSubSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
     if (ONECOL) {  // HBM record == LDS slot: straight 16-byte copies, all loads in flight
       const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(slice);
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
     }
     __syncthreads();
 
-    const uint64_t *kin = bins.keys + (uint64_t)sub * bins.cap * W;
+    const uint64_t *kin = bins.keys + (uint64_t)bi * bins.cap * W;
     for (uint64_t i0 = tid; i0 < n; i0 += (uint64_t)kLdsThreads * kLdsBatch) {
       Kmer<W> tk[kLdsBatch];
 #pragma unroll

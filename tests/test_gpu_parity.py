@@ -198,7 +198,9 @@ def test_direct_and_deferred_paths_agree(mcx, orc, k, ncols):
     jobs.append((0, hb, ho))
     og, _ = _oracle(orc, k, ncols, jobs)
     want = og.ctx_bytes(True)[og.header_size():]
-    for cfg in [{"defer": 0}, {"defer": 1}, {"defer": 1, "defer_tuples": 20000}, {"defer": 1, "defer_tuples": 300000}]:
+    for cfg in [{"defer": 0}, {"defer": 1}, {"defer": 1, "defer_tuples": 20000}, {"defer": 1, "defer_tuples": 300000},
+                {"defer": 1, "flush_regions": 1}, {"defer": 1, "defer_tuples": 300000, "flush_regions": 3},
+                {"defer": 1, "flush_regions": 100000}]:
         g = mcx.Graph(k, ncols, 1 << 20)
         for key, v in cfg.items():
             g.configure(key, v)
@@ -216,13 +218,17 @@ def test_deferred_large_table_many_subtables(mcx, orc):
     bases, offs = synth.reads(60000, 150, genome_len=400000, seed=21)
     og, _ = _oracle(orc, 31, 1, [(0, bases, offs)], cap=1 << 22)
     want = og.ctx_bytes(True)[og.header_size():]
-    g = mcx.Graph(31, 1, 3 << 20)  # 768 sub-tables -> 2 L1 bins of 384... plus ragged tail
-    g.configure("profile", 1)
-    g.add_reads(0, bases, offs)
-    assert g.export(True) == want
-    prof = g.profile()
-    assert "k_stream_bin" in prof and "k_tuples_bin" in prof and "k_lds_insert" in prof
-    g.close()
+    for regions in (0, 1, 5, 1 << 20):  # regions split + applied per flush step (0 = automatic)
+        g = mcx.Graph(31, 1, 3 << 20)   # 768 sub-tables in 256 regions of 3
+        g.configure("flush_regions", regions)
+        g.configure("profile", 1)
+        g.add_reads(0, bases, offs)
+        assert g.export(True) == want, regions
+        prof = g.profile()
+        assert "k_stream_bin" in prof and "k_tuples_bin" in prof and "k_lds_insert" in prof
+        if regions == 1:
+            assert prof["k_lds_insert"][0] == 512 and prof["k_tuples_bin"][0] == 512  # one step per region
+        g.close()
 
 
 def test_configure_profile_and_device_memory(mcx):
