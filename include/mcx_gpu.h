@@ -168,6 +168,27 @@ int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *d_keys, con
                                uint32_t nseg, uint64_t seg_cap, uint64_t ntuples);
 uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_words);
 
+/* Bulk load of `.ctx` records: what graph_load() does for `build --graph <in.ctx>`
+ * (src/graph/graphs_load.c:86-214, reader src/graph/graph_file_reader.c:347-420).
+ * `recs` = nrecs records in the .ctx body layout (W x u64 key, file_ncols x u32 coverage,
+ * file_ncols x u8 edges, byte-packed, host memory).  The colour filter is the reference's list of
+ * (from, into) pairs (src/basic/file_filter.c): file colour from_col[i] is added to colour
+ * into_col[i] of this graph (coverage +=, saturating at 2^32-1 on export; edges |=; targets and
+ * sources may repeat).  Records whose loaded colours all have zero coverage are skipped.  MCX_RECORDS_MUST_EXIST: only update k-mers already in the graph
+ * (GraphLoadingPrefs.must_exist_in_graph).  The per-record checks of graph_file_read_raw are
+ * reported through the stats: index (counted from the first record ever passed with this stats
+ * object) of the first record with zero coverage in every file colour / with edges but no coverage
+ * in some colour (the reference warns once for each), or -1; an oversized k-mer fails the call
+ * with MCX_ERR_ARG (the reference dies).  Synchronous. */
+enum { MCX_RECORDS_MUST_EXIST = 1 };
+typedef struct {
+  uint64_t nkmers_read, nkmers_loaded, nkmers_novel;
+  int64_t first_oversized, first_zero_covg, first_edges_no_covg; /* initialise to -1 */
+} mcx_records_stats;
+int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nrecs, int file_ncols,
+                          const int32_t *from_col, const int32_t *into_col, int nmap, uint32_t flags,
+                          mcx_records_stats *stats_accum);
+
 /* Wait for all submitted work; reports MCX_ERR_FULL if any insert ran out of
  * slots (the reference dies with "Hash table is full"). */
 int mcx_graph_sync(mcx_graph *g);

@@ -945,6 +945,75 @@ extern "C" int mcx_graph_device_stats(mcx_graph *g, mcx_load_stats *out)
 }
 
 // ---------------------------------------------------------------------------
+// bulk load of .ctx records (build --graph; graph_load, src/graph/graphs_load.c:86-214)
+// ---------------------------------------------------------------------------
+extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nrecs, int file_ncols,
+                                     const int32_t *from_col, const int32_t *into_col, int nmap, uint32_t flags,
+                                     mcx_records_stats *stats_accum)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (file_ncols < 1 || file_ncols > 10000) return fail(MCX_ERR_ARG, "bad number of file colours: %d", file_ncols);
+  if (nmap < 1 || !from_col || !into_col) return fail(MCX_ERR_ARG, "empty colour filter");
+  for (int m = 0; m < nmap; m++) {
+    if (from_col[m] < 0 || from_col[m] >= file_ncols)
+      return fail(MCX_ERR_ARG, "filter entry %d reads colour %d of a %d colour file", m, from_col[m], file_ncols);
+    if (into_col[m] < 0 || into_col[m] >= g->ncols)
+      return fail(MCX_ERR_ARG, "filter entry %d loads into colour %d of a %d colour graph", m, into_col[m], g->ncols);
+  }
+  if (nrecs && !recs) return fail(MCX_ERR_ARG, "null records");
+  HIP_TRY(hipSetDevice(g->device));
+  int rc = ensure_stage(g);
+  if (rc != MCX_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(g->stream));  // the staging buffers are ours now
+  const uint64_t rec_bytes = 8ull * g->W + 5ull * (uint64_t)file_ncols;
+  int32_t *d_into = nullptr;  // from[nmap] then into[nmap]
+  RecordStats *d_st = nullptr, h_st;
+  HIP_TRY(hipMalloc((void **)&d_into, sizeof(int32_t) * 2 * (size_t)nmap));
+  if (hipMalloc((void **)&d_st, sizeof(RecordStats)) != hipSuccess) { (void)hipFree(d_into); return fail(MCX_ERR_NOMEM, "out of device memory"); }
+  memset(&h_st, 0, sizeof(h_st));
+  h_st.first_oversized = h_st.first_zero_covg = h_st.first_edges_no_covg = ~0ULL;
+  HIP_TRY(hipMemcpyAsync(d_into, from_col, sizeof(int32_t) * (size_t)nmap, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(hipMemcpyAsync(d_into + nmap, into_col, sizeof(int32_t) * (size_t)nmap, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(hipMemcpyAsync(d_st, &h_st, sizeof(h_st), hipMemcpyHostToDevice, g->stream));
+  const uint64_t per_chunk = std::max<uint64_t>(1, kStageBytes / rec_bytes);
+  int cur = 0;
+  for (uint64_t r0 = 0; r0 < nrecs; r0 += per_chunk, cur ^= 1) {
+    const uint64_t n = std::min(per_chunk, nrecs - r0);
+    HIP_TRY(hipEventSynchronize(g->ev[cur]));  // the kernel that last read this staging pair is done
+    memcpy(g->h_stage[cur], (const uint8_t *)recs + r0 * rec_bytes, n * rec_bytes);
+    HIP_TRY(hipMemcpyAsync(g->d_stage[cur], g->h_stage[cur], n * rec_bytes, hipMemcpyHostToDevice, g->stream));
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)g->grid);
+    SpanGuard sp(g, "k_load_records");
+    if (g->W == 1)
+      hipLaunchKernelGGL((k_load_records<1>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
+                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, g->k, g->d_ctr, d_st);
+    else
+      hipLaunchKernelGGL((k_load_records<2>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
+                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, g->k, g->d_ctr, d_st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->ev[cur], g->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(&h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  (void)hipFree(d_into); (void)hipFree(d_st);
+  if (stats_accum) {
+    stats_accum->nkmers_read += nrecs;
+    stats_accum->nkmers_loaded += h_st.loaded;
+    stats_accum->nkmers_novel += h_st.novel;
+    auto first = [](int64_t &dst, unsigned long long v, uint64_t base) {
+      if (v != ~0ULL && dst < 0) dst = (int64_t)(base + v);
+    };
+    const uint64_t base = stats_accum->nkmers_read - nrecs;
+    first(stats_accum->first_oversized, h_st.first_oversized, base);
+    first(stats_accum->first_zero_covg, h_st.first_zero_covg, base);
+    first(stats_accum->first_edges_no_covg, h_st.first_edges_no_covg, base);
+  }
+  if (h_st.first_oversized != ~0ULL)
+    return fail(MCX_ERR_ARG, "oversized kmer in record %llu [kmer: %d]", (unsigned long long)h_st.first_oversized, g->k);
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // export
 // ---------------------------------------------------------------------------
 template <int W>

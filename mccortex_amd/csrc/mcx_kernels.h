@@ -201,6 +201,109 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
   }
 }
 
+// ---------------------------------------------------------------------------
+// Bulk load of .ctx records (graph_load, src/graph/graphs_load.c:86-214)
+// ---------------------------------------------------------------------------
+// find (or, unless must_exist, insert) the record of `key`; nullptr = absent / table full
+template <int W>
+__device__ __forceinline__ uint64_t *find_or_insert_rec(const TableView &t, const Kmer<W> &key, bool must_exist,
+                                                        uint32_t &novel, uint32_t &full)
+{
+  const uint64_t want = key.w[0] | kFlag;
+  uint64_t slot = key_slot<W>(t, key);
+  uint32_t probes = 0;
+  for (;;) {
+    uint64_t *r = t.rec + slot * t.S;
+    uint64_t cur = __hip_atomic_load(r, MCX_RLX, MCX_AGENT);
+    if (cur == 0) {
+      if (must_exist) return nullptr;
+      uint64_t expected = 0;
+      const uint64_t desired = (W == 1) ? want : (want | kPending);
+      if (__hip_atomic_compare_exchange_strong(r, &expected, desired, MCX_RLX, MCX_RLX, MCX_AGENT)) {
+        if (W == 2) {
+          __hip_atomic_store(r + 1, key.w[W - 1], MCX_RLX, MCX_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(r, want, MCX_RLX, MCX_AGENT);
+        }
+        novel++;
+        return r;
+      }
+      cur = expected;
+    }
+    if ((cur & ~kPending) == want) {
+      if (W == 1) return r;
+      if (cur & kPending) {  // owner has not published word 1 yet
+        if (++probes > t.max_probe * 64u) { full = 1; return nullptr; }
+        continue;
+      }
+      if (__hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT) == key.w[W - 1]) return r;
+    }
+    if (++probes > t.max_probe) { full = 1; return nullptr; }
+    slot++;
+    if ((slot & (kSubSlots - 1)) == 0) slot -= kSubSlots;
+  }
+}
+
+struct RecordStats {  // device-resident
+  unsigned long long loaded, novel;
+  unsigned long long first_oversized, first_zero_covg, first_edges_no_covg;  // record index or ~0
+};
+
+// One thread per record of the .ctx body layout: W key words, file_ncols x u32 coverage,
+// file_ncols x u8 edges, byte-packed.  The colour filter is a list of (from, into) pairs
+// (file_filter, src/basic/file_filter.c): file colour from[i] is added to colour into[i] of the
+// graph (coverage +=, edges |=; graph_file_read, graph_file_reader.c:392-412).  Records whose
+// loaded colours all have zero coverage are skipped (graphs_load.c:121-125).  The per-record
+// sanity checks of graph_file_read_raw (graph_file_reader.c:358-386) are reported as the index
+// of the first offending record.
+__device__ __forceinline__ uint32_t load_le32(const uint8_t *p)
+{
+  return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t *recs, uint64_t nrecs, uint64_t rec0,
+                                                      uint32_t file_ncols, const int32_t *from, const int32_t *into,
+                                                      uint32_t nmap, uint32_t must_exist, int kmer_size,
+                                                      Counters *ctr, RecordStats *st)
+{
+  const uint32_t rec_bytes = 8u * W + 5u * file_ncols;
+  uint32_t novel = 0, full = 0, loaded = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrecs; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint8_t *p = recs + i * rec_bytes;
+    Kmer<W> key;
+#pragma unroll
+    for (int w = 0; w < W; w++) key.w[w] = (uint64_t)load_le32(p + 8 * w) | (uint64_t)load_le32(p + 8 * w + 4) << 32;
+    const uint8_t *pc = p + 8 * W, *pe = pc + 4 * file_ncols;
+    const int top_bits = 2 * kmer_size - 64 * (W - 1);
+    if (top_bits < 64 && (key.w[0] >> top_bits)) { atomicMin(&st->first_oversized, (unsigned long long)(rec0 + i)); continue; }
+    uint32_t any_file = 0, any_loaded = 0;
+    bool edges_no_covg = false;
+    for (uint32_t c = 0; c < file_ncols; c++) {
+      const uint32_t cv = load_le32(pc + 4 * c);
+      any_file |= cv;
+      if (pe[c] && !cv) edges_no_covg = true;
+    }
+    for (uint32_t m = 0; m < nmap; m++) any_loaded |= load_le32(pc + 4 * from[m]);
+    if (!any_file) atomicMin(&st->first_zero_covg, (unsigned long long)(rec0 + i));
+    if (edges_no_covg) atomicMin(&st->first_edges_no_covg, (unsigned long long)(rec0 + i));
+    if (!any_loaded) continue;
+    uint64_t *r = find_or_insert_rec<W>(t, key, must_exist != 0, novel, full);
+    if (!r) continue;
+    for (uint32_t m = 0; m < nmap; m++) {
+      const uint32_t cv = load_le32(pc + 4 * from[m]);
+      const uint32_t e = pe[from[m]];
+      uint64_t *val = r + W + into[m];
+      if (cv) __hip_atomic_fetch_add(val, (uint64_t)cv << 8, MCX_RLX, MCX_AGENT);
+      if (e) __hip_atomic_fetch_or(val, (uint64_t)e, MCX_RLX, MCX_AGENT);
+    }
+    loaded++;
+  }
+  if (novel) { atomicAdd(&ctr->novel, (unsigned long long)novel); atomicAdd(&st->novel, (unsigned long long)novel); }
+  if (loaded) atomicAdd(&st->loaded, (unsigned long long)loaded);
+  if (full) ctr->full = 1;
+}
+
 // Sink of the fused kernel: insert straight into the local table.
 template <int W, bool ONECOL> struct InsertSink {
   TableView t;

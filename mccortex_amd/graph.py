@@ -13,7 +13,7 @@ _LIB = None
 SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
-    "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_destroy",
+    "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
@@ -37,6 +37,19 @@ class LoadStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class RecordStats(C.Structure):
+    """mcx_records_stats"""
+    _fields_ = [("nkmers_read", C.c_uint64), ("nkmers_loaded", C.c_uint64), ("nkmers_novel", C.c_uint64),
+                ("first_oversized", C.c_int64), ("first_zero_covg", C.c_int64), ("first_edges_no_covg", C.c_int64)]
+
+    def __init__(self):
+        super().__init__(0, 0, 0, -1, -1, -1)
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+RECORDS_MUST_EXIST = 1
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
@@ -66,6 +79,7 @@ def lib():
     L.mcx_graph_shard_bins_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64]
     L.mcx_graph_add_segments_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]
     L.mcx_graph_insert_tuple_segments_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32, C.c_uint64]
+    L.mcx_graph_add_records.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_int, C.c_uint32, C.POINTER(RecordStats)]
     L.mcx_graph_key_owner.restype = C.c_uint32
     L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
@@ -197,6 +211,19 @@ class Graph:
         st = stats if stats is not None else LoadStats()
         _check(self.L.mcx_graph_add_reads(self.h, colour, _ptr(bases), _ptr(quals), _ptr(offsets),
                                           len(offsets) - 1, fq_cutoff, hp_cutoff, C.byref(st)))
+        return st
+
+    def add_records(self, recs, file_ncols, colour_filter, must_exist=False, stats=None):
+        """recs: .ctx body bytes (W x u64 key, file_ncols x u32 coverage, file_ncols x u8 edges per
+        record); colour_filter: [(from file colour, into graph colour)]"""
+        recs = np.frombuffer(recs, dtype=np.uint8) if isinstance(recs, (bytes, bytearray, memoryview)) else np.ascontiguousarray(recs, dtype=np.uint8)
+        rs = 8 * self.W + 5 * file_ncols
+        assert recs.size % rs == 0
+        frm = np.array([f for f, _ in colour_filter], dtype=np.int32)
+        into = np.array([t for _, t in colour_filter], dtype=np.int32)
+        st = stats if stats is not None else RecordStats()
+        _check(self.L.mcx_graph_add_records(self.h, _ptr(recs), recs.size // rs, file_ncols, _ptr(frm), _ptr(into),
+                                            len(frm), RECORDS_MUST_EXIST if must_exist else 0, C.byref(st)))
         return st
 
     def add_stream_dev(self, colour, d_stream, nbytes):

@@ -53,8 +53,8 @@ static const char build_usage[] =
 "  Note: Argument must come before input file\n"
 "  --sample <name> is required before sequence input can be loaded.\n"
 "  Consecutive sequence options are loaded into the same colour.\n"
-"  This build runs the graph construction on an MI355X: --remove-pcr, --graph and\n"
-"  --intersect and SAM/BAM/CRAM input are not available; -m/-n size the table in HBM.\n"
+"  This build runs the graph construction on an MI355X: --remove-pcr, --intersect\n"
+"  and SAM/BAM/CRAM input are not available; -m/-n size the table in HBM.\n"
 "\n";
 
 static struct option longopts[] = {
@@ -81,7 +81,10 @@ typedef struct {
 static build_task *tasks = NULL;
 static size_t ntasks = 0, tasks_cap = 0;
 static char **sample_names = NULL;
+static int *sample_cols = NULL;   /* SampleName.colour: ctx_build.c:83-86,159-164 */
 static size_t nsamples = 0;
+static ctx_reader *gfiles = NULL; /* --graph inputs, in command-line order (gfilebuf) */
+static size_t ngfiles = 0;
 
 #define usage_die(...) print_usage(build_usage, __VA_ARGS__)
 
@@ -151,6 +154,74 @@ static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
                                 sc->fq_abs, sc->bt->hp_cutoff, &sc->bt->stats), "add reads");
 }
 
+/* file_filter_status: file_filter.c:170-192 */
+static void filter_status(const ctx_reader *r)
+{
+  char line[1024];
+  int n = snprintf(line, sizeof(line), "[FileFilter] Reading file %s [%u src colour%s]", r->path, r->num_cols, r->num_cols == 1 ? "" : "s");
+  bool direct = true;
+  for (size_t i = 0; i < r->nfilter; i++) direct &= (r->filter[i].from == i && r->filter[i].into == i);
+  if (!direct) {
+    for (size_t i = 0; i < r->nfilter && n < (int)sizeof(line) - 32; i++)
+      n += snprintf(line + n, sizeof(line) - (size_t)n, "%s%u->%u", i ? "," : " with filter: ", r->filter[i].from, r->filter[i].into);
+  }
+  status("%s", line);
+}
+
+/* graph_load (graphs_load.c:86-214) with the hash table on the GPU: merge the header's GraphInfo
+ * into the colours it loads into, then stream the records through mcx_graph_add_records */
+static void load_graph_file(mcx_graph *g, ctx_reader *r, col_info *cols, size_t ncols)
+{
+  char a[64], b[64];
+  filter_status(r);
+  if (r->file_size >= 0)
+    status("[GReader] %s kmers, %s filesize", ulong_to_str((uint64_t)r->num_kmers, a), bytes_to_str((uint64_t)r->file_size, 1, b));
+  else status("  reading from a stream.");
+  /* graph_load_ginfo: graphs_load.c:48-77 */
+  if (r->into_ncols > ncols)
+    die("Program has not assigned enough colours! [colours in graph: %zu vs file: %zu; path: %s]", ncols, r->into_ncols, r->path);
+  for (size_t i = 0; i < r->nfilter; i++) col_info_merge(&cols[r->filter[i].into], &r->ginfo[r->filter[i].from]);
+
+  const size_t rec_bytes = 8 * (size_t)r->num_words + 5 * (size_t)r->num_cols;
+  const size_t chunk_recs = (64u << 20) / rec_bytes;
+  unsigned char *buf = malloc(chunk_recs * rec_bytes);
+  int32_t *from = malloc(r->nfilter * sizeof(int32_t)), *into = malloc(r->nfilter * sizeof(int32_t));
+  if (!buf || !from || !into) die("Out of memory");
+  for (size_t i = 0; i < r->nfilter; i++) { from[i] = (int32_t)r->filter[i].from; into[i] = (int32_t)r->filter[i].into; }
+  mcx_records_stats st = {0, 0, 0, -1, -1, -1};
+  bool warned_zero = false, warned_edges = false;
+  for (;;) {
+    const size_t got = fread(buf, 1, chunk_recs * rec_bytes, r->fh);
+    if (got == 0) break;
+    if (got % rec_bytes) {
+      /* graph_file_read_raw: a partial key is "Unexpected end of file", a partial tail an _gfread error */
+      die("Unexpected end of file: %s", r->path);
+    }
+    const uint64_t base = st.nkmers_read;
+    int rc = mcx_graph_add_records(g, buf, got / rec_bytes, (int)r->num_cols, from, into, (int)r->nfilter, 0, &st);
+    if (rc != MCX_OK && st.first_oversized >= 0) die("Oversized kmer in path [kmer: %u]: %s", r->kmer_size, r->path);
+    mcx_check(rc, "load graph records");
+    if (st.first_zero_covg >= 0 && !warned_zero) {
+      char kstr[2 * MAX_KMER_SIZE + 8];
+      kmer_words_to_str(buf + ((uint64_t)st.first_zero_covg - base) * rec_bytes, r->kmer_size, kstr);
+      warn("Kmer has zero covg in all colours [kmer: %s; path: %s]", kstr, r->path);
+      warned_zero = true;
+    }
+    if (st.first_edges_no_covg >= 0 && !warned_edges) {
+      char kstr[2 * MAX_KMER_SIZE + 8];
+      kmer_words_to_str(buf + ((uint64_t)st.first_edges_no_covg - base) * rec_bytes, r->kmer_size, kstr);
+      warn("Kmer has edges but no coverage [kmer: %s; path: %s]", kstr, r->path);
+      warned_edges = true;
+    }
+  }
+  if (r->num_kmers >= 0 && st.nkmers_read != (uint64_t)r->num_kmers)
+    warn("%s kmers in the graph file than expected [exp: %zu; act: %zu; path: %s]",
+         st.nkmers_read > (uint64_t)r->num_kmers ? "More" : "Fewer", (size_t)r->num_kmers, (size_t)st.nkmers_read, r->path);
+  status("[GReader] Loaded %s / %s (%.2f%%) of kmers parsed", ulong_to_str(st.nkmers_loaded, a), ulong_to_str(st.nkmers_read, b),
+         st.nkmers_read ? 100.0 * (double)st.nkmers_loaded / (double)st.nkmers_read : 0.0);
+  free(buf); free(from); free(into);
+}
+
 int ctx_build(int argc, char **argv)
 {
   size_t nthreads = 0, kmer_size = 0, mem_to_use = DEFAULT_MEM, num_kmers = 0;
@@ -194,6 +265,8 @@ int ctx_build(int argc, char **argv)
         intocolour++;
         check_sample_name(optarg);
         sample_names = realloc(sample_names, (nsamples + 1) * sizeof(char *));
+        sample_cols = realloc(sample_cols, (nsamples + 1) * sizeof(int));
+        sample_cols[nsamples] = intocolour;
         sample_names[nsamples++] = optarg;
         sample_named = true; break;
       case 'S': if (sort_kmers) usage_die("%s given twice", cmd); sort_kmers = true; break;
@@ -224,7 +297,13 @@ int ctx_build(int argc, char **argv)
         hp_cutoff = (uint8_t)u; pref_unused = true; break;
       case 'p': remove_pcr = true; pref_unused = true; break;
       case 'P': remove_pcr = false; pref_unused = true; break;
-      case 'g': die("--graph is not available in this build (loads an existing .ctx; SURVEY.md 8f)");
+      case 'g': /* ctx_build.c:189-196 */
+        if (intocolour == -1) intocolour = 0;
+        gfiles = realloc(gfiles, (ngfiles + 1) * sizeof(ctx_reader));
+        ctx_reader_open(&gfiles[ngfiles], optarg, (size_t)intocolour, MIN_KMER_SIZE, MAX_KMER_SIZE);
+        if ((int)gfiles[ngfiles].into_ncols - 1 > intocolour) intocolour = (int)gfiles[ngfiles].into_ncols - 1;
+        ngfiles++;
+        sample_named = false; break;
       case 'I': die("--intersect is not available in this build (SURVEY.md 8f)");
       case 'D': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int x >= 0: %s", cmd, optarg);
         device = (int)u; break;
@@ -241,14 +320,21 @@ int ctx_build(int argc, char **argv)
   if (nsamples == 0) usage_die("No inputs given");
   if (pref_unused) usage_die("Arguments not given BEFORE sequence file");
   if (!kmer_size) die("kmer size not set with -k <K>");
+  for (size_t i = 0; i < ngfiles; i++) /* ctx_build.c:231-239 */
+    if (gfiles[i].kmer_size != kmer_size)
+      usage_die("Input graph kmer_size doesn't match [%u vs %zu]: %s", gfiles[i].kmer_size, kmer_size, gfiles[i].input);
   const size_t ncols = (size_t)intocolour + (sample_named ? 1 : 0);
 
   /* print inputs in sample/task order (ctx_build.c:270-279) and estimate k-mers from file
    * sizes (asyncio_input_nkmers: bytes, halved for FASTQ, times 5; async_read_io.c:313-334) */
   size_t max_kmers = 0;
   bool size_unknown = false;
+  for (size_t i = 0; i < ngfiles; i++) { /* ctx_build.c:268-272 (a stream counts as -1 there too) */
+    filter_status(&gfiles[i]);
+    max_kmers += (size_t)gfiles[i].num_kmers;
+  }
   for (size_t s = 0, t = 0; s < nsamples || t < ntasks;) {
-    if (t == ntasks || (s < nsamples && (int)s <= tasks[t].colour)) { status("[sample] %zu: %s", s, sample_names[s]); s++; }
+    if (t == ntasks || (s < nsamples && sample_cols[s] <= tasks[t].colour)) { status("[sample] %zu: %s", s, sample_names[s]); s++; }
     else {
       build_task *bt = &tasks[t];
       bt->fmt = SEQ_FMT_UNKNOWN;
@@ -317,12 +403,21 @@ int ctx_build(int argc, char **argv)
 
   col_info *cols = calloc(ncols, sizeof(col_info));
   for (size_t i = 0; i < ncols; i++) col_info_init(&cols[i]);
-  for (size_t i = 0; i < nsamples; i++) strcpy(cols[i].name, sample_names[i]);
+
+  /* ---- load graphs (graph_load: graphs_load.c:86-214), then name the samples (ctx_build.c:365-382) ---- */
+  for (size_t i = 0; i < ngfiles; i++) {
+    load_graph_file(g, &gfiles[i], cols, ncols);
+    uint64_t nk0 = 0;
+    mcx_check(mcx_graph_nkmers(g, &nk0), "nkmers");
+    status("[hash] occupancy: %s / %s (%.2f%%)", ulong_to_str(nk0, s1), ulong_to_str(slots, s2), 100.0 * (double)nk0 / (double)slots);
+    ctx_reader_close(&gfiles[i]);
+  }
+  for (size_t i = 0; i < nsamples; i++) col_info_set_name(&cols[sample_cols[i]], sample_names[i]);
 
   /* ---- load every input in task order (build_graph(): build_graph.c:257-300) ---- */
   read_batch batch;
   mcx_load_stats prev;
-  memset(&prev, 0, sizeof(prev));
+  mcx_check(mcx_graph_device_stats(g, &prev), "device stats"); /* k-mers created by --graph are not a file's */
   for (size_t t = 0; t < ntasks; t++) {
     build_task *bt = &tasks[t];
     /* -t threads parse an uncompressed regular file in parallel; gzip, stdin and files the fast
@@ -384,6 +479,7 @@ int ctx_build(int argc, char **argv)
   if (fout != stdout) fclose(fout);
   mcx_graph_destroy(g);
   for (size_t t = 0; t < ntasks; t++) free(tasks[t].path);
-  free(tasks); free(cols); free(sample_names);
+  for (size_t i = 0; i < ncols; i++) col_info_free(&cols[i]);
+  free(tasks); free(cols); free(sample_names); free(sample_cols); free(gfiles);
   return EXIT_SUCCESS;
 }

@@ -35,6 +35,8 @@ bool parse_entire_uint(const char *s, unsigned *out);
 bool mem_to_integer(const char *s, size_t *bytes);
 char *ulong_to_str(unsigned long n, char *out);
 char *bytes_to_str(unsigned long n, int decimals, char *out);
+/* binary_kmer_to_str (binary_kmer.c:190-210) for the key of a .ctx record: word 0 (most significant) first */
+void kmer_words_to_str(const unsigned char *rec, unsigned kmer_size, char *out);
 
 /* ---- table sizing (src/basic/hash_mem.c:5-51, src/graph/cmd_mem.c:38-130) ---- */
 uint64_t hash_table_cap(uint64_t nkmers, uint64_t *nbuckets, uint8_t *bucket_size);
@@ -69,15 +71,42 @@ int seq_in_guess_fq_offset(const seq_in *s);
 int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, size_t batch_bases,
                void (*submit)(void *arg, read_batch *b, int fq_offset_guess), void *arg);
 
-/* ---- .ctx v6 header (src/graph/graph_writer.c:11-110, src/basic/graph_info.c:116-175) ---- */
-typedef struct {
+/* ---- .ctx header: GraphInfo arithmetic, writer, reader
+ * (src/basic/graph_info.c, src/graph/graph_writer.c:11-110, src/graph/graph_file_reader.c:78-340,
+ *  colour filters src/basic/file_filter.c) ---- */
+typedef struct { /* ErrorCleaning, graph_info.h */
+  uint8_t cleaned_tips, cleaned_unitigs, cleaned_kmers, is_graph_intersection;
+  uint32_t clean_unitigs_thresh, clean_kmers_thresh;
+  char *intersection_name;
+} err_cleaning;
+typedef struct { /* GraphInfo */
   uint32_t mean_read_length;
   uint64_t total_sequence;
-  char name[256];
+  long double seq_err;
+  char *name;
+  err_cleaning cleaning;
 } col_info;
 void col_info_init(col_info *c);
+void col_info_free(col_info *c);
+void col_info_set_name(col_info *c, const char *name);
 void col_info_update(col_info *c, uint64_t bases_loaded, uint64_t contigs);
+void col_info_merge(col_info *dst, const col_info *src); /* graph_info_merge */
 size_t ctx_write_header(FILE *fh, uint32_t kmer_size, uint32_t ncols, const col_info *cols);
+
+typedef struct { uint32_t from, into; } col_filter;
+typedef struct {
+  char *input, *path;        /* "0,1:in.ctx:2-3" and "in.ctx" */
+  FILE *fh;
+  uint32_t version, kmer_size, num_words, num_cols;
+  col_info *ginfo;           /* [num_cols] */
+  size_t hdr_size;
+  long long file_size, num_kmers; /* -1 when reading a stream */
+  col_filter *filter;        /* sorted by `into` */
+  size_t nfilter, into_ncols;
+} ctx_reader;
+/* graph_file_open2: parse "<into>:path:<from>", read and check the header; dies on error */
+void ctx_reader_open(ctx_reader *r, const char *input, size_t into_offset, size_t min_k, size_t max_k);
+void ctx_reader_close(ctx_reader *r);
 
 /* ---- commands ---- */
 int ctx_build(int argc, char **argv);

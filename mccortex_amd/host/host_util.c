@@ -184,3 +184,17 @@ size_t hash_table_mem_limit(size_t memlimit, size_t entrybits, uint64_t *nkmers_
   if (nkmers_out) *nkmers_out = nb * bs;
   return ht_mem(bs, nb, entrybits);
 }
+
+void kmer_words_to_str(const unsigned char *rec, unsigned kmer_size, char *out)
+{
+  const unsigned W = (2 * kmer_size + 63) / 64;
+  for (unsigned i = 0; i < kmer_size; i++) {
+    /* base i (first base = most significant): bit offset from the low end of the W-word integer */
+    const unsigned bit = 2 * (kmer_size - 1 - i);
+    const unsigned word = W - 1 - bit / 64, sh = bit % 64;
+    uint64_t w;
+    memcpy(&w, rec + 8 * word, 8);
+    out[i] = "ACGT"[(w >> sh) & 3];
+  }
+  out[kmer_size] = '\0';
+}

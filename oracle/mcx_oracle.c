@@ -595,6 +595,45 @@ static void hdr_ginfo(const orc_graph *g, int c, uint32_t *mean, uint64_t *total
   *mean = dmean; *total = dtotal; *seq_err = derr;
 }
 
+/* graph_load's per-record body (src/graph/graphs_load.c:117-186) once graph_file_read_reset
+ * (graph_file_reader.c:392-420) has mapped the file's colours onto the graph's: covgs/edges hold
+ * g->ncols entries.  Returns 1 = loaded, 0 = skipped (no coverage / absent with must_exist),
+ * -1 = hash table full. */
+int orc_graph_add_record(orc_graph *g, const uint64_t *key_words, const uint32_t *covgs, const uint8_t *edges,
+                         int must_exist)
+{
+  int c, found = 0;
+  uint32_t keep = 0;
+  for(c = 0; c < g->ncols; c++) keep |= covgs[c];
+  if(keep == 0) return 0; /* "If kmer has no covg -> don't load" */
+  orc_bkmer key;
+  memset(&key, 0, sizeof(key));
+  for(c = 0; c < g->W; c++) key.b[c] = key_words[c];
+  uint64_t hkey;
+  if(must_exist) {
+    /* hash_table_find: probe the same bucket sequence without inserting */
+    const uint64_t before = g->num_kmers;
+    hkey = find_or_insert(g, &key, &found);
+    if(hkey == ORC_NOT_FOUND) return 0;
+    if(!found) { /* undo: the restatement has no find-only entry; the slot was appended last in its bucket */
+      uint64_t h = hkey / g->bucket_size;
+      memset(g->table + hkey * (uint64_t)g->W, 0, sizeof(uint64_t) * (size_t)g->W);
+      g->bsize[h]--;
+      g->num_kmers = before;
+      return 0;
+    }
+  } else {
+    hkey = find_or_insert(g, &key, &found);
+    if(hkey == ORC_NOT_FOUND) { g->full = 1; return -1; }
+  }
+  for(c = 0; c < g->ncols; c++) { /* db_node_add_col_covg: SAFE_SUM_COVG, cortex_types.h:10-11 */
+    uint32_t *cv = &g->covgs[hkey * (uint64_t)g->ncols + (uint64_t)c];
+    *cv = ((uint64_t)*cv + covgs[c] > UINT32_MAX) ? UINT32_MAX : *cv + covgs[c];
+    g->edges[hkey * (uint64_t)g->ncols + (uint64_t)c] |= edges[c]; /* edge_mask = 0xff */
+  }
+  return 1;
+}
+
 size_t orc_graph_header_size(const orc_graph *g)
 {
   size_t n = 6 + 16, c;

@@ -72,6 +72,9 @@ void orc_graph_update_stats(orc_graph *g, int colour, const orc_stats *stats);
 
 /* .ctx v6 image (row H): graph_writer.c:11-30,62-127,182-268.
  * sorted!=0 -> records ordered by key (hash_table.c:362-374). */
+/* one record of graph_load (graphs_load.c:117-186), colours already mapped onto the graph's */
+int orc_graph_add_record(orc_graph *g, const uint64_t *key_words, const uint32_t *covgs, const uint8_t *edges,
+                         int must_exist);
 size_t orc_graph_ctx_size(const orc_graph *g);
 size_t orc_graph_write_ctx(const orc_graph *g, int sorted, uint8_t *out);
 size_t orc_graph_header_size(const orc_graph *g);

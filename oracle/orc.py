@@ -86,6 +86,8 @@ def lib():
     L.orc_graph_write_ctx.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.orc_graph_lookup.restype = C.c_int
     L.orc_graph_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]
+    L.orc_graph_add_record.restype = C.c_int
+    L.orc_graph_add_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_tuples.restype = C.c_uint64
     L.orc_tuples.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                              C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p]
@@ -152,6 +154,20 @@ class Graph:
         if rc != 0:
             raise RuntimeError("Hash table is full" if rc == -1 else "oracle error %d" % rc)
         return st
+
+    def add_record(self, key_words, covgs, edges, must_exist=False):
+        """graph_load's per-record body: colours already mapped onto this graph's (ncols entries)"""
+        kw = np.ascontiguousarray(key_words, dtype=np.uint64)
+        cv = np.ascontiguousarray(covgs, dtype=np.uint32)
+        ed = np.ascontiguousarray(edges, dtype=np.uint8)
+        assert len(kw) == self.W and len(cv) == self.ncols and len(ed) == self.ncols
+        rc = self.L.orc_graph_add_record(self.h, _ptr(kw), _ptr(cv), _ptr(ed), 1 if must_exist else 0)
+        if rc < 0:
+            raise RuntimeError("Hash table is full")
+        return rc
+
+    def body_bytes(self, sorted_=True):
+        return self.ctx_bytes(sorted_)[self.header_size():]
 
     def update_stats(self, colour, st):
         self.L.orc_graph_update_stats(self.h, colour, C.byref(st))

@@ -1,0 +1,288 @@
+"""`.ctx` reading, colour filters, GraphInfo merging and `build --graph`.
+
+CPU: the Python restatement (oracle/ctxio.py) is pinned to the C oracle's header writer (itself
+pinned in tests/test_oracle.py) and to the golden files; the host program's argument handling.
+GPU: mcx_graph_add_records against the oracle's graph_load restatement, and the command line."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import ctxio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mccortex_amd", "bin")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run(maxk, *args, stdin=None):
+    exe = os.path.join(BIN, "mccortex%d" % maxk)
+    p = subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, input=stdin)
+    return p.returncode, p.stdout, p.stderr.decode(errors="replace")
+
+
+def _reads_graph(orc, k, ncols, jobs, names):
+    """C oracle graph + the GraphInfo the reference would hold after build_graph()"""
+    og = orc.Graph(k, ncols, 1 << 20)
+    gi = [ctxio.GraphInfo() for _ in range(ncols)]
+    for c, n in enumerate(names):
+        og.set_sample(c, n)
+        gi[c].sample_name = n
+    for col, b, o in jobs:
+        st = og.add_reads(col, b, o)
+        og.update_stats(col, st)
+        gi[col].update_contigs(st.total_bases_loaded, st.contigs_parsed)
+    return og, gi
+
+
+@pytest.mark.parametrize("k", [31, 63, 5])
+def test_python_header_equals_c_oracle_header(orc, k):
+    g = synth.genome(8000, 4)
+    jobs = [(0, *synth.reads(500, 90, seed=1, g=g, n_frac=0.1)), (1, *synth.reads(300, 120, seed=2, g=g, var_len=True)),
+            (0, *synth.reads(200, 70, seed=3, g=g))]
+    og, gi = _reads_graph(orc, k, 3, jobs, ["alice", "bob"])   # colour 2 stays empty / "undefined"
+    want = og.ctx_bytes(True)
+    hs = og.header_size()
+    assert ctxio.header_bytes(k, gi) == want[:hs]
+    hdr, n = ctxio.read_header(want)
+    assert n == hs and hdr["kmer_size"] == k and hdr["num_cols"] == 3
+    assert [x.sample_name for x in hdr["ginfo"]] == ["alice", "bob", "undefined"]
+    # (writing the parsed header again is NOT a fixed point: graph_info_merge re-derives the mean
+    # read length from total / round(total / mean) every time a header passes through it)
+    keys, covgs, edges = ctxio.records(want, hdr, hs)
+    assert len(keys) == og.nkmers and covgs.shape == (og.nkmers, 3)
+
+
+@pytest.mark.parametrize("name", ["tiny_k31", "tiny_k63", "tiny_k5"])
+def test_golden_files_parse(name):
+    buf = open(os.path.join(GOLD, name + ".ctx"), "rb").read()
+    hdr, hs = ctxio.read_header(buf)
+    keys, covgs, edges = ctxio.records(buf, hdr, hs)
+    assert hs + len(keys) * (8 * hdr["num_words"] + 5 * hdr["num_cols"]) == len(buf)
+    assert (covgs.sum(axis=1) > 0).all()
+    k = keys.astype(object)  # sorted by key, most significant word first
+    as_int = [sum(int(w) << (64 * (hdr["num_words"] - 1 - i)) for i, w in enumerate(row)) for row in k]
+    assert as_int == sorted(as_int)
+
+
+def test_filter_parsing():
+    pf = ctxio.parse_filter
+    assert pf("in.ctx", 3, 0) == ("in.ctx", [(0, 0), (1, 1), (2, 2)])
+    assert pf("in.ctx", 2, 4) == ("in.ctx", [(0, 4), (1, 5)])
+    assert pf("in.ctx:0,6-8", 9, 1) == ("in.ctx", [(0, 1), (6, 2), (7, 3), (8, 4)])
+    assert pf("2:in.ctx:1", 3, 0) == ("in.ctx", [(1, 2)])
+    assert pf("0:in.ctx", 3, 7) == ("in.ctx", [(0, 0), (1, 0), (2, 0)])      # flatten into colour 0
+    assert pf("3,1:dir/in.ctx:0-1", 2, 0) == ("dir/in.ctx", [(1, 1), (0, 3)])
+    assert pf("in.ctx:2-0", 3, 0) == ("in.ctx", [(2, 0), (1, 1), (0, 2)])
+    assert pf("a:b.ctx", 1, 0) == ("a:b.ctx", [(0, 0)])                      # not a range: part of the path
+    for bad in ["in.ctx:3", "in.ctx:0,", "0,1,2:in.ctx:0-1"]:
+        with pytest.raises(ctxio.CtxError):
+            pf(bad, 3, 0)
+
+
+def test_graphinfo_merge_arithmetic():
+    a, b = ctxio.GraphInfo(), ctxio.GraphInfo()
+    a.sample_name, a.total_sequence, a.mean_read_length = "x", 1000, 100
+    b.sample_name, b.total_sequence, b.mean_read_length = "y", 3000, 150
+    b.seq_err = ctxio.LD(0.02)
+    b.cleaning.cleaned_kmers, b.cleaning.clean_kmers_thresh = 1, 5
+    b.cleaning.is_graph_intersection, b.cleaning.intersection_name = 1, "ref"
+    a.merge(b)
+    assert a.sample_name == "x,y" and a.total_sequence == 4000
+    assert a.mean_read_length == 4000 // (10 + 20)
+    assert abs(float(a.seq_err) - (0.01 * 1000 + 0.02 * 3000) / 4000) < 1e-15
+    assert a.cleaning.cleaned_kmers == 1 and a.cleaning.clean_kmers_thresh == 5
+    assert a.cleaning.is_graph_intersection == 1 and a.cleaning.intersection_name == "ref"
+    c = ctxio.GraphInfo()
+    c.cleaning.is_graph_intersection, c.cleaning.intersection_name = 1, "other"
+    a.merge(c)
+    assert a.cleaning.intersection_name == "ref,other" and a.sample_name == "x,y"
+    # header fields survive a write/read round trip
+    hdr, _ = ctxio.read_header(ctxio.header_bytes(31, [a]))
+    g = hdr["ginfo"][0]
+    assert (g.sample_name, g.total_sequence, g.cleaning.clean_kmers_thresh, g.cleaning.intersection_name) == \
+        ("x,y", 4000, 5, "ref,other")
+    assert g.seq_err == a.seq_err
+
+
+def test_oracle_add_record_semantics(orc):
+    og = orc.Graph(31, 2, 1 << 12)
+    key = [0x06f939390b58c9c9]
+    assert og.add_record(key, [0, 0], [3, 0]) == 0 and og.nkmers == 0          # no coverage: not loaded
+    assert og.add_record(key, [5, 0], [0x11, 0], must_exist=True) == 0 and og.nkmers == 0
+    assert og.add_record(key, [5, 0], [0x11, 0]) == 1 and og.nkmers == 1
+    assert og.add_record(key, [0xFFFFFFFF, 2], [0x02, 0x80], must_exist=True) == 1 and og.nkmers == 1
+    body = og.body_bytes()
+    assert body == struct.pack("<QIIBB", key[0], 0xFFFFFFFF, 2, 0x13, 0x80)     # saturating sum, edges OR
+
+
+def test_graph_option_argument_errors(mcx, tmp_path):
+    fa = tmp_path / "a.fa"
+    fa.write_text(">r\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    good = os.path.join(GOLD, "tiny_k31.ctx")
+    bad = tmp_path / "bad.ctx"
+    bad.write_bytes(b"CORTEY" + open(good, "rb").read()[6:])
+    trunc = tmp_path / "trunc.ctx"
+    trunc.write_bytes(open(good, "rb").read()[:40])
+    cases = [
+        (["build", "-k", "31", "-g", good, "o.ctx"], "No inputs given"),
+        (["build", "-k", "31", "-g", str(tmp_path / "none.ctx"), "-s", "a", "--seq", str(fa), "o.ctx"], "Cannot open file"),
+        (["build", "-k", "31", "-g", str(bad), "-s", "a", "--seq", str(fa), "o.ctx"], "Magic word doesn't match"),
+        (["build", "-k", "31", "-g", str(trunc), "-s", "a", "--seq", str(fa), "o.ctx"], "Unexpected end of file"),
+        (["build", "-k", "21", "-g", good, "-s", "a", "--seq", str(fa), "o.ctx"], "Input graph kmer_size doesn't match"),
+        (["build", "-k", "31", "-g", good + ":7", "-s", "a", "--seq", str(fa), "o.ctx"], "Invalid filter path"),
+        (["build", "-k", "31", "-g", os.path.join(GOLD, "tiny_k63.ctx"), "-s", "a", "--seq", str(fa), "o.ctx"], "Cannot handle kmer size 63"),
+    ]
+    for args, msg in cases:
+        rc, _, err = run(31, *args)
+        assert rc == 1, (args, err)
+        assert msg in err, (args, err)
+
+
+# ------------------------------------------------------------------------------------------
+def _random_records(rng, k, file_ncols, n, W):
+    keys = np.zeros((n, W), dtype=np.uint64)
+    top_bits = 2 * k - 64 * (W - 1)
+    keys[:, 0] = rng.integers(0, 1 << min(top_bits, 62), n, dtype=np.uint64)
+    if top_bits > 62:
+        keys[:, 0] |= rng.integers(0, 1 << (top_bits - 62), n, dtype=np.uint64) << np.uint64(62)
+    for w in range(1, W):
+        keys[:, w] = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    keys[n // 2:] = keys[:n - n // 2]          # duplicates: coverage sums, edges OR
+    keys[0] = 0                                # the all-A k-mer
+    covgs = rng.integers(0, 4, (n, file_ncols), dtype=np.uint32) * rng.integers(0, 1 << 30, (n, file_ncols), dtype=np.uint32)
+    covgs[1::7] = 0xFFFFFFFF                   # saturation
+    edges = rng.integers(0, 256, (n, file_ncols), dtype=np.uint8)
+    edges[covgs == 0] = 0                      # well-formed: no edges without coverage
+    rec = np.concatenate([keys.view(np.uint8).reshape(n, 8 * W), covgs.view(np.uint8).reshape(n, 4 * file_ncols), edges], axis=1)
+    return keys, covgs, edges, rec.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,file_ncols,ncols,filt", [
+    (31, 1, 1, [(0, 0)]),
+    (31, 3, 2, [(0, 1), (2, 1), (1, 0)]),
+    (63, 2, 3, [(1, 0), (1, 2)]),
+    (45, 4, 2, [(3, 1)]),
+])
+def test_add_records_matches_oracle(mcx, orc, k, file_ncols, ncols, filt):
+    rng = np.random.default_rng(k * 10 + file_ncols)
+    og = orc.Graph(k, ncols, 1 << 20)
+    g = mcx.Graph(k, ncols, 1 << 20)
+    # some reads first (both insert strategies meet the loaded records), then records, then reads
+    b, o = synth.reads(2000, 100, seed=5, genome_len=20000)
+    og.add_reads(0, b, o); g.add_reads(0, b, o)
+    keys, covgs, edges, rec = _random_records(rng, k, file_ncols, 30000, og.W)
+    # records of k-mers the reads created: take some keys back from the graph
+    kk, _, _ = g.records(True)
+    nk = min(len(kk), 5000)
+    keys[100:100 + nk] = kk[:nk]
+    rec = np.concatenate([keys.view(np.uint8).reshape(len(keys), 8 * og.W), covgs.view(np.uint8).reshape(len(keys), 4 * file_ncols),
+                          edges], axis=1).tobytes()
+    loaded = 0
+    for i in range(len(keys)):
+        cv, ed = [0] * ncols, [0] * ncols
+        for f, t in filt:
+            cv[t] = min(0xFFFFFFFF, cv[t] + int(covgs[i, f])); ed[t] |= int(edges[i, f])
+        loaded += og.add_record(keys[i], cv, ed) == 1
+    st = g.add_records(rec, file_ncols, filt)
+    assert (st.nkmers_read, st.nkmers_loaded) == (len(keys), loaded)
+    assert st.first_oversized == -1 and st.first_edges_no_covg == -1
+    b2, o2 = synth.reads(1500, 80, seed=6, genome_len=20000)
+    og.add_reads(ncols - 1, b2, o2); g.add_reads(ncols - 1, b2, o2)
+    assert g.nkmers == og.nkmers
+    assert g.export(True) == og.body_bytes(True)
+    # must_exist: nothing new appears, existing records are updated
+    st2 = g.add_records(rec, file_ncols, filt, must_exist=True)
+    for i in range(len(keys)):
+        cv, ed = [0] * ncols, [0] * ncols
+        for f, t in filt:
+            cv[t] = min(0xFFFFFFFF, cv[t] + int(covgs[i, f])); ed[t] |= int(edges[i, f])
+        og.add_record(keys[i], cv, ed, must_exist=True)
+    assert st2.nkmers_novel == 0 and g.nkmers == og.nkmers
+    assert g.export(True) == og.body_bytes(True)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_add_records_reports_dirty_records(mcx):
+    g = mcx.Graph(31, 1, 1 << 12)
+    rec = struct.pack("<QIB", 5, 0, 0) + struct.pack("<QIB", 6, 0, 4) + struct.pack("<QIB", 7, 2, 1)
+    st = g.add_records(rec, 1, [(0, 0)])
+    assert (st.nkmers_read, st.nkmers_loaded, st.first_zero_covg, st.first_edges_no_covg) == (3, 1, 0, 1)
+    with pytest.raises(mcx.McxError):
+        g.add_records(struct.pack("<QIB", 1 << 62, 1, 0), 1, [(0, 0)])   # oversized for k=31
+    with pytest.raises(mcx.McxError):
+        g.add_records(rec, 1, [(1, 0)])
+    g.close()
+
+
+def _fasta(path, bases, offs):
+    with open(path, "w") as f:
+        for i in range(len(offs) - 1):
+            f.write(">r%d\n%s\n" % (i, bytes(bases[int(offs[i]):int(offs[i + 1])]).decode()))
+    return str(path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxk,k", [(31, 31), (63, 47)])
+def test_build_graph_option_matches_oracle(mcx, orc, tmp_path, maxk, k):
+    g0 = synth.genome(30000, 8)
+    r = [synth.reads(1500, 100, seed=20 + i, g=g0, n_frac=0.05) for i in range(4)]
+    f = [_fasta(tmp_path / ("r%d.fa" % i), *r[i]) for i in range(4)]
+    # A: 2 colours from reads (this command line is covered by tests/test_cli.py)
+    A = str(tmp_path / "A.ctx")
+    rc, _, err = run(maxk, "build", "-q", "-k", str(k), "-n", "1M", "--sort", "-s", "a0", "--seq", f[0], "-s", "a1", "--seq", f[1], A)
+    assert rc == 0, err
+    ogA, giA = _reads_graph(orc, k, 2, [(0, *r[0]), (1, *r[1])], ["a0", "a1"])
+    bufA = open(A, "rb").read()
+    assert bufA == ctxio.header_bytes(k, giA) + ogA.body_bytes(True)
+
+    def expect(ncols, loads, names, jobs):
+        """loads: [(buf, input spec, into_offset)] in command-line order; names {colour: name};
+        jobs: [(colour, bases, offs)] -> expected file bytes (ctx_build.c:365-425)"""
+        og = orc.Graph(k, ncols, 1 << 20)
+        gi = [ctxio.GraphInfo() for _ in range(ncols)]
+        for buf, spec, off in loads:
+            hdr, _ = ctxio.read_header(buf)
+            _, filt = ctxio.parse_filter(spec, hdr["num_cols"], off)
+            ctxio.load_into(og, gi, buf, filt)
+        for c, n in names.items():
+            gi[c].sample_name = n        # strbuf_set: overrides what the graph files merged in
+        for col, b, o in jobs:
+            st = og.add_reads(col, b, o)
+            gi[col].update_contigs(st.total_bases_loaded, st.contigs_parsed)
+        return ctxio.header_bytes(k, gi) + og.body_bytes(True)
+
+    # 1. graph into colours 0-1, new sample in colour 2
+    out = str(tmp_path / "o1.ctx")
+    rc, _, err = run(maxk, "build", "-k", str(k), "-n", "1M", "--sort", "-g", A, "-s", "new", "--seq", f[2], out)
+    assert rc == 0, err
+    assert "[GReader] Loaded" in err and "kmers parsed" in err
+    assert open(out, "rb").read() == expect(3, [(bufA, A, 0)], {2: "new"}, [(2, *r[2])])
+
+    # 2. sample first, then a filtered graph (colour 1 of A) after it, then another sample; via stdin too
+    out = str(tmp_path / "o2.ctx")
+    rc, _, err = run(maxk, "build", "-q", "-k", str(k), "-n", "1M", "--sort", "-s", "s0", "--seq", f[2], "-g", A + ":1",
+                     "-s", "s1", "--seq", f[3], out)
+    assert rc == 0, err
+    # -s s0 -> colour 0; -g with into_offset 0 loads A:1 into colour 0 as well; -s s1 -> colour 1
+    assert open(out, "rb").read() == expect(2, [(bufA, A + ":1", 0)], {0: "s0", 1: "s1"}, [(0, *r[2]), (1, *r[3])])
+
+    # 3. explicit into-colours, both file colours flattened into colour 1; graph read from stdin
+    out = str(tmp_path / "o3.ctx")
+    rc, _, err = run(maxk, "build", "-q", "-k", str(k), "-n", "1M", "--sort", "-g", "1:-", "-s", "x", "--seq", f[3], out, stdin=bufA)
+    assert rc == 0, err
+    assert open(out, "rb").read() == expect(3, [(bufA, "1:-", 0)], {2: "x"}, [(2, *r[3])])
+
+    # 4. two graph files: the second lands after the first's colours; loading our own output again
+    out4 = str(tmp_path / "o4.ctx")
+    o1 = open(str(tmp_path / "o1.ctx"), "rb").read()
+    rc, _, err = run(maxk, "build", "-q", "-k", str(k), "-n", "1M", "--sort", "-g", A, "-g", str(tmp_path / "o1.ctx") + ":2,0",
+                     "-s", "z", "--seq", f[0], out4)
+    assert rc == 0, err
+    # first -g: intocolour 0 -> 1; second -g is opened with into_offset 1 (colours 1, 2); -s z -> colour 3
+    assert open(out4, "rb").read() == expect(4, [(bufA, A, 0), (o1, "o1.ctx:2,0", 1)], {3: "z"}, [(3, *r[0])])
