@@ -189,6 +189,24 @@ int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nrecs, int fi
                           const int32_t *from_col, const int32_t *into_col, int nmap, uint32_t flags,
                           mcx_records_stats *stats_accum);
 
+/* Table scans (imply a sync).
+ * mcx_graph_kmer_covg       db_graph_get_kmer_covg (src/graph/db_graph.c:490-534): per colour, the
+ *                           number of k-mers with coverage and their summed coverage (ncols entries)
+ * mcx_graph_covg_histogram  the k-mer coverage histogram of `clean`'s first pass
+ *                           (src/tools/clean_graph.c:365-377): hist[min(c, nbins-1)]++ for every
+ *                           k-mer, c = its coverage summed over colours (saturating, db_node.h:302) */
+int mcx_graph_kmer_covg(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov);
+int mcx_graph_covg_histogram(mcx_graph *g, uint64_t *hist, uint32_t nbins);
+
+/* `.ctx` records on the device without a graph handle (host buffers, .ctx body layout).
+ * mcx_sort_records    sort in place by k-mer, most significant word first -- what `sort` does with
+ *                     qsort (src/commands/ctx_sort.c:133-152; binary_kmers_qcmp_unaligned_ptrs)
+ * mcx_records_sorted  *first_unsorted = index of the first record whose k-mer is not greater than
+ *                     its predecessor's, or -1 (the check `index` makes, src/commands/ctx_index.c:136) */
+int mcx_sort_records(void *recs, uint64_t nrecs, int kmer_size, int ncols, int device);
+int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_size, int ncols, int device,
+                       int64_t *first_unsorted);
+
 /* Wait for all submitted work; reports MCX_ERR_FULL if any insert ran out of
  * slots (the reference dies with "Hash table is full"). */
 int mcx_graph_sync(mcx_graph *g);

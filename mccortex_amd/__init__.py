@@ -6,9 +6,11 @@ that ABI used by the tests and by bench.py.  There is no CPU path: without the
 HIP extension or without a GPU every graph operation raises.
 """
 from .graph import (Graph, LoadStats, McxError, MCX_ERR_FULL, device_count, lib, kmer_from_str,
-                    kmer_canonical, kmer_hash, key_owner, stream_from_reads)
+                    kmer_canonical, kmer_hash, key_owner, stream_from_reads, RecordStats, sort_records,
+                    records_sorted)
 from .ctx import CtxHeader, ctx_header_bytes, graph_info_update, write_ctx
 
 __all__ = ["Graph", "LoadStats", "McxError", "MCX_ERR_FULL", "device_count", "lib", "kmer_from_str",
-           "kmer_canonical", "kmer_hash", "key_owner", "stream_from_reads", "CtxHeader",
+           "kmer_canonical", "kmer_hash", "key_owner", "stream_from_reads", "RecordStats", "sort_records",
+           "records_sorted", "CtxHeader",
            "ctx_header_bytes", "graph_info_update", "write_ctx"]

@@ -1098,6 +1098,159 @@ extern "C" int mcx_graph_export(mcx_graph *g, int sorted, mcx_sink_fn sink, void
 }
 
 // ---------------------------------------------------------------------------
+// table scans: per-colour k-mer / coverage totals and the k-mer coverage histogram
+// ---------------------------------------------------------------------------
+static int covg_scan(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov, uint64_t *hist, uint32_t nbins)
+{
+  HIP_TRY(hipSetDevice(g->device));
+  int rc = flush_deferred(g);
+  if (rc != MCX_OK) return rc;
+  const uint32_t nc = (uint32_t)g->ncols;
+  const uint32_t lbins = hist ? std::min<uint32_t>(nbins, 4096u) : 0;
+  unsigned long long *d_out = nullptr, *d_hist = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_out, 2 * nc * 8));
+  HIP_TRY(hipMemsetAsync(d_out, 0, 2 * nc * 8, g->stream));
+  if (hist) {
+    if (hipMalloc((void **)&d_hist, (size_t)nbins * 8) != hipSuccess) { (void)hipFree(d_out); return fail(MCX_ERR_NOMEM, "out of device memory"); }
+    HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)nbins * 8, g->stream));
+  }
+  {
+    SpanGuard sp(g, "k_covg_scan");
+    hipLaunchKernelGGL(k_covg_scan, dim3(g->grid), dim3(256), (2 * nc + lbins) * 8, g->stream, g->t, nc, d_out, d_hist, nbins, lbins);
+  }
+  HIP_TRY(hipGetLastError());
+  std::vector<unsigned long long> h(2 * nc);
+  HIP_TRY(hipMemcpyAsync(h.data(), d_out, 2 * nc * 8, hipMemcpyDeviceToHost, g->stream));
+  if (hist) HIP_TRY(hipMemcpyAsync(hist, d_hist, (size_t)nbins * 8, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  (void)hipFree(d_out); (void)hipFree(d_hist);
+  for (uint32_t c = 0; c < nc; c++) {
+    if (nkmers) nkmers[c] = h[c];
+    if (sumcov) sumcov[c] = h[nc + c];
+  }
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_kmer_covg(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (g->ncols > 2048) return fail(MCX_ERR_ARG, "too many colours for the scan");
+  return covg_scan(g, nkmers, sumcov, nullptr, 0);
+}
+
+extern "C" int mcx_graph_covg_histogram(mcx_graph *g, uint64_t *hist, uint32_t nbins)
+{
+  if (!g || !hist) return fail(MCX_ERR_ARG, "null argument");
+  if (nbins < 2) return fail(MCX_ERR_ARG, "the histogram needs at least two bins");
+  if (g->ncols > 2048) return fail(MCX_ERR_ARG, "too many colours for the scan");
+  return covg_scan(g, nullptr, nullptr, hist, nbins);
+}
+
+// ---------------------------------------------------------------------------
+// sort / sortedness check of .ctx records on the device (src/commands/ctx_sort.c:133-152,
+// src/commands/ctx_index.c:136-137)
+// ---------------------------------------------------------------------------
+template <int W>
+static int sort_records_t(uint8_t *recs, uint64_t n, uint32_t rec_bytes, int device, bool check_only, int64_t *first_unsorted)
+{
+  hipStream_t st = nullptr;
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  uint64_t *d_k0 = nullptr, *d_k1 = nullptr, *d_ks = nullptr, *d_ks2 = nullptr, *d_idx = nullptr, *d_idx2 = nullptr;
+  unsigned long long *d_bad = nullptr;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  auto cleanup = [&]() {
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_k0); (void)hipFree(d_k1); (void)hipFree(d_ks); (void)hipFree(d_ks2);
+    (void)hipFree(d_idx); (void)hipFree(d_idx2); (void)hipFree(d_bad); (void)hipFree(d_tmp);
+    if (st) (void)hipStreamDestroy(st);
+  };
+#define SRT_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      cleanup();                                                                          \
+      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    }                                                                                     \
+  } while (0)
+  SRT_TRY(hipSetDevice(device));
+  SRT_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  const uint64_t bytes = n * rec_bytes;
+  SRT_TRY(hipMalloc((void **)&d_in, bytes));
+  SRT_TRY(hipMalloc((void **)&d_k0, n * 8));
+  if (W == 2) SRT_TRY(hipMalloc((void **)&d_k1, n * 8));
+  SRT_TRY(hipMemcpyAsync(d_in, recs, bytes, hipMemcpyHostToDevice, st));
+  const unsigned gb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL((k_record_keys<W>), dim3(gb), dim3(256), 0, st, d_in, n, rec_bytes, d_k0, d_k1);
+  SRT_TRY(hipGetLastError());
+  if (check_only) {
+    unsigned long long bad = ~0ULL;
+    SRT_TRY(hipMalloc((void **)&d_bad, 8));
+    SRT_TRY(hipMemcpyAsync(d_bad, &bad, 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_check_sorted<W>), dim3(gb), dim3(256), 0, st, d_k0, d_k1, n, d_bad);
+    SRT_TRY(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, st));
+    SRT_TRY(hipStreamSynchronize(st));
+    *first_unsorted = bad == ~0ULL ? -1 : (int64_t)bad;
+    cleanup();
+    return MCX_OK;
+  }
+  SRT_TRY(hipMalloc((void **)&d_idx, n * 8));
+  SRT_TRY(hipMalloc((void **)&d_idx2, n * 8));
+  SRT_TRY(hipMalloc((void **)&d_ks, n * 8));
+  hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, n);
+  const uint64_t *first_key = W == 2 ? d_k1 : d_k0;
+  SRT_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, first_key, d_ks, d_idx, d_idx2, n, 0, 64, st));
+  SRT_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  SRT_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, first_key, d_ks, d_idx, d_idx2, n, 0, 64, st));
+  uint64_t *perm = d_idx2;
+  if (W == 2) {  // LSD: stable second pass on the most significant word
+    SRT_TRY(hipMalloc((void **)&d_ks2, n * 8));
+    hipLaunchKernelGGL(k_gather_u64, dim3(gb), dim3(256), 0, st, (const uint64_t *)d_k0, (const uint64_t *)d_idx2, d_ks2, n);
+    SRT_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, d_idx2, d_idx, n, 0, 64, st));
+    perm = d_idx;
+  }
+  (void)hipFree(d_ks); d_ks = nullptr;
+  SRT_TRY(hipMalloc((void **)&d_out, bytes));
+  hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, st, d_in, (const uint64_t *)perm, n, rec_bytes, d_out);
+  SRT_TRY(hipGetLastError());
+  SRT_TRY(hipMemcpyAsync(recs, d_out, bytes, hipMemcpyDeviceToHost, st));
+  SRT_TRY(hipStreamSynchronize(st));
+#undef SRT_TRY
+  cleanup();
+  return MCX_OK;
+}
+
+static int sort_args(const void *recs, uint64_t nrecs, int kmer_size, int ncols, uint32_t *rec_bytes)
+{
+  if (kmer_size < 3 || kmer_size > 63 || !(kmer_size & 1)) return fail(MCX_ERR_ARG, "kmer size must be odd and within 3..63 (got %d)", kmer_size);
+  if (ncols < 1 || ncols > 10000) return fail(MCX_ERR_ARG, "bad number of colours: %d", ncols);
+  if (nrecs && !recs) return fail(MCX_ERR_ARG, "null records");
+  if (nrecs >= (1ull << 32) * 16) return fail(MCX_ERR_ARG, "too many records for one call");
+  *rec_bytes = 8u * (uint32_t)words_for_k(kmer_size) + 5u * (uint32_t)ncols;
+  return MCX_OK;
+}
+
+extern "C" int mcx_sort_records(void *recs, uint64_t nrecs, int kmer_size, int ncols, int device)
+{
+  uint32_t rb;
+  int rc = sort_args(recs, nrecs, kmer_size, ncols, &rb);
+  if (rc != MCX_OK || nrecs < 2) return rc;
+  int64_t dummy;
+  return words_for_k(kmer_size) == 1 ? sort_records_t<1>((uint8_t *)recs, nrecs, rb, device, false, &dummy)
+                                     : sort_records_t<2>((uint8_t *)recs, nrecs, rb, device, false, &dummy);
+}
+
+extern "C" int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_size, int ncols, int device, int64_t *first_unsorted)
+{
+  uint32_t rb;
+  if (!first_unsorted) return fail(MCX_ERR_ARG, "null argument");
+  *first_unsorted = -1;
+  int rc = sort_args(recs, nrecs, kmer_size, ncols, &rb);
+  if (rc != MCX_OK || nrecs < 2) return rc;
+  return words_for_k(kmer_size) == 1 ? sort_records_t<1>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted)
+                                     : sort_records_t<2>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted);
+}
+
+// ---------------------------------------------------------------------------
 // host-side primitives (rows A-C), same templates the kernels use
 // ---------------------------------------------------------------------------
 extern "C" void mcx_kmer_from_str(const char *seq, int k, uint64_t *out)

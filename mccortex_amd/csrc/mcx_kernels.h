@@ -304,6 +304,81 @@ __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t
   if (full) ctr->full = 1;
 }
 
+// ---------------------------------------------------------------------------
+// `sort` (src/commands/ctx_sort.c:133-152): keys of byte-packed .ctx records, record gather
+// ---------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_record_keys(const uint8_t *recs, uint64_t n, uint32_t rec_bytes, uint64_t *k0, uint64_t *k1)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *p = recs + i * rec_bytes;
+  k0[i] = (uint64_t)load_le32(p) | (uint64_t)load_le32(p + 4) << 32;
+  if (W == 2) k1[i] = (uint64_t)load_le32(p + 8) | (uint64_t)load_le32(p + 12) << 32;
+}
+
+// out record i = in record perm[i]; 16 lanes copy one record (coalesced over its bytes)
+__global__ __launch_bounds__(256) void k_gather_records(const uint8_t *in, const uint64_t *perm, uint64_t n, uint32_t rec_bytes, uint8_t *out)
+{
+  const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const uint32_t l = threadIdx.x & 15u;
+  if (i >= n) return;
+  const uint8_t *src = in + perm[i] * rec_bytes;
+  uint8_t *dst = out + i * rec_bytes;
+  for (uint32_t b = l; b < rec_bytes; b += 16) dst[b] = src[b];
+}
+
+// strictly increasing keys? (ctx_index.c:136-137 requires it); flags the first violation
+template <int W>
+__global__ __launch_bounds__(256) void k_check_sorted(const uint64_t *k0, const uint64_t *k1, uint64_t n, unsigned long long *first_bad)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 >= n) return;
+  bool lt = k0[i] < k0[i + 1];
+  if (W == 2 && k0[i] == k0[i + 1]) lt = k1[i] < k1[i + 1];
+  if (!lt) atomicMin(first_bad, (unsigned long long)(i + 1));
+}
+
+// ---------------------------------------------------------------------------
+// Table scans: db_graph_get_kmer_covg (src/graph/db_graph.c:490-534) and the k-mer coverage
+// histogram of clean's pre-pass (src/tools/clean_graph.c:365-377)
+// ---------------------------------------------------------------------------
+// out[c] = nodes with coverage in colour c, out[ncols + c] = their summed coverage (clamped per
+// node to 2^32-1 like the exported value); hist[min(sum over colours (saturating), nbins-1)]++
+__global__ __launch_bounds__(256) void k_covg_scan(TableView t, uint32_t ncols, unsigned long long *out,
+                                                   unsigned long long *hist, uint32_t nbins, uint32_t lbins)
+{
+  // LDS: 2 * ncols accumulators, then a block-local copy of the first `lbins` histogram bins
+  // (nearly every node lands in the low bins: global atomics on them would serialise)
+  extern __shared__ unsigned long long s_acc[];
+  unsigned long long *s_hist = s_acc + 2 * ncols;
+  for (uint32_t c = threadIdx.x; c < 2 * ncols + lbins; c += blockDim.x) s_acc[c] = 0;
+  __syncthreads();
+  for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < t.nslots; slot += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t *r = t.rec + slot * t.S;
+    if (!(r[0] & kFlag)) continue;
+    const uint32_t W = t.S - ncols;
+    uint64_t sum = 0;
+    for (uint32_t c = 0; c < ncols; c++) {
+      uint64_t cv = r[W + c] >> 8;
+      if (cv > 0xFFFFFFFFull) cv = 0xFFFFFFFFull;
+      if (cv) { atomicAdd(&s_acc[c], 1ULL); atomicAdd(&s_acc[ncols + c], (unsigned long long)cv); }
+      sum += cv;
+    }
+    if (sum > 0xFFFFFFFFull) sum = 0xFFFFFFFFull;  // db_node_sum_covg saturates (db_node.h:302-309)
+    if (hist) {
+      const uint64_t bin = sum < nbins ? sum : nbins - 1;
+      if (bin < lbins) atomicAdd(&s_hist[bin], 1ULL);
+      else atomicAdd(&hist[bin], 1ULL);
+    }
+  }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < 2 * ncols; c += blockDim.x)
+    if (s_acc[c]) atomicAdd(&out[c], s_acc[c]);
+  for (uint32_t c = threadIdx.x; c < lbins; c += blockDim.x)
+    if (s_hist[c]) atomicAdd(&hist[c], s_hist[c]);
+}
+
 // Sink of the fused kernel: insert straight into the local table.
 template <int W, bool ONECOL> struct InsertSink {
   TableView t;

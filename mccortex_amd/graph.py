@@ -13,7 +13,8 @@ _LIB = None
 SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
-    "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_destroy",
+    "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_kmer_covg", "mcx_graph_covg_histogram", "mcx_sort_records",
+    "mcx_records_sorted", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
@@ -80,6 +81,10 @@ def lib():
     L.mcx_graph_add_segments_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]
     L.mcx_graph_insert_tuple_segments_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32, C.c_uint64]
     L.mcx_graph_add_records.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_int, C.c_uint32, C.POINTER(RecordStats)]
+    L.mcx_graph_kmer_covg.argtypes = [vp, u64p, u64p]
+    L.mcx_graph_covg_histogram.argtypes = [vp, u64p, C.c_uint32]
+    L.mcx_sort_records.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    L.mcx_records_sorted.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.mcx_graph_key_owner.restype = C.c_uint32
     L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
@@ -226,6 +231,18 @@ class Graph:
                                             len(frm), RECORDS_MUST_EXIST if must_exist else 0, C.byref(st)))
         return st
 
+    def kmer_covg(self):
+        """per colour: (k-mers with coverage, summed coverage) -- db_graph_get_kmer_covg"""
+        nk = np.zeros(self.ncols, dtype=np.uint64)
+        sc = np.zeros(self.ncols, dtype=np.uint64)
+        _check(self.L.mcx_graph_kmer_covg(self.h, nk.ctypes.data_as(C.POINTER(C.c_uint64)), sc.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return nk, sc
+
+    def covg_histogram(self, nbins):
+        h = np.zeros(nbins, dtype=np.uint64)
+        _check(self.L.mcx_graph_covg_histogram(self.h, h.ctypes.data_as(C.POINTER(C.c_uint64)), nbins))
+        return h
+
     def add_stream_dev(self, colour, d_stream, nbytes):
         _check(self.L.mcx_graph_add_stream_dev(self.h, colour, _ptr(d_stream), nbytes))
 
@@ -296,3 +313,21 @@ class Graph:
         cov = rec[:, 8 * self.W:8 * self.W + 4 * self.ncols].copy().view(np.uint32).reshape(-1, self.ncols)
         edg = rec[:, 8 * self.W + 4 * self.ncols:].copy()
         return keys, cov, edg
+
+
+def sort_records(recs, kmer_size, ncols, device=0):
+    """sort .ctx body bytes by k-mer on the device; returns the sorted bytes"""
+    a = np.frombuffer(bytes(recs), dtype=np.uint8).copy()
+    rs = 8 * _words(kmer_size) + 5 * ncols
+    assert a.size % rs == 0
+    _check(lib().mcx_sort_records(_ptr(a), a.size // rs, kmer_size, ncols, device))
+    return a.tobytes()
+
+
+def records_sorted(recs, kmer_size, ncols, device=0):
+    """index of the first record that is not greater than its predecessor, or -1"""
+    a = np.frombuffer(bytes(recs), dtype=np.uint8)
+    rs = 8 * _words(kmer_size) + 5 * ncols
+    bad = C.c_int64(-1)
+    _check(lib().mcx_records_sorted(_ptr(a), a.size // rs, kmer_size, ncols, device, C.byref(bad)))
+    return int(bad.value)

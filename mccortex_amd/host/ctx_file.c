@@ -104,6 +104,18 @@ void col_info_merge(col_info *dst, const col_info *src)
 
 static size_t put(FILE *fh, const void *p, size_t n) { return fwrite(p, 1, n, fh); }
 
+static size_t put_cleaning(FILE *fh, const err_cleaning *ec)
+{ /* write_error_cleaning_object: graph_writer.c:33-60 */
+  size_t n = 0;
+  n += put(fh, &ec->cleaned_tips, 1); n += put(fh, &ec->cleaned_unitigs, 1);
+  n += put(fh, &ec->cleaned_kmers, 1); n += put(fh, &ec->is_graph_intersection, 1);
+  const uint32_t tu = ec->cleaned_unitigs ? ec->clean_unitigs_thresh : 0, tk = ec->cleaned_kmers ? ec->clean_kmers_thresh : 0;
+  n += put(fh, &tu, 4); n += put(fh, &tk, 4);
+  const uint32_t len = (uint32_t)strlen(ec->intersection_name);
+  n += put(fh, &len, 4); n += put(fh, ec->intersection_name, len);
+  return n;
+}
+
 size_t ctx_write_header(FILE *fh, uint32_t kmer_size, uint32_t ncols, const col_info *cols)
 {
   _Static_assert(sizeof(long double) == 16, "x87 long double layout expected");
@@ -127,15 +139,7 @@ size_t ctx_write_header(FILE *fh, uint32_t kmer_size, uint32_t ncols, const col_
     memcpy(b, &h[c].seq_err, 10);
     n += put(fh, b, 16);
   }
-  for (uint32_t c = 0; c < ncols; c++) { /* write_error_cleaning_object: graph_writer.c:33-60 */
-    const err_cleaning *ec = &h[c].cleaning;
-    n += put(fh, &ec->cleaned_tips, 1); n += put(fh, &ec->cleaned_unitigs, 1);
-    n += put(fh, &ec->cleaned_kmers, 1); n += put(fh, &ec->is_graph_intersection, 1);
-    const uint32_t tu = ec->cleaned_unitigs ? ec->clean_unitigs_thresh : 0, tk = ec->cleaned_kmers ? ec->clean_kmers_thresh : 0;
-    n += put(fh, &tu, 4); n += put(fh, &tk, 4);
-    const uint32_t len = (uint32_t)strlen(ec->intersection_name);
-    n += put(fh, &len, 4); n += put(fh, ec->intersection_name, len);
-  }
+  for (uint32_t c = 0; c < ncols; c++) n += put_cleaning(fh, &h[c].cleaning);
   n += put(fh, "CORTEX", 6);
   for (uint32_t c = 0; c < ncols; c++) col_info_free(&h[c]);
   free(h);
@@ -358,6 +362,38 @@ static size_t read_header(ctx_reader *r)
 
 void ctx_reader_open(ctx_reader *r, const char *input, size_t into_offset, size_t min_k, size_t max_k)
 {
+  ctx_reader_open_mode(r, input, "r", into_offset, min_k, max_k);
+}
+
+bool ctx_reader_from_direct(const ctx_reader *r)
+{
+  for (size_t i = 0; i < r->nfilter; i++)
+    if (r->filter[i].from != i || r->filter[i].into != i) return false;
+  return r->nfilter == r->num_cols;
+}
+
+size_t ctx_write_header_raw(FILE *fh, const ctx_reader *r)
+{
+  size_t n = 0;
+  n += fwrite("CORTEX", 1, 6, fh);
+  n += fwrite(&r->version, 1, 4, fh); n += fwrite(&r->kmer_size, 1, 4, fh);
+  n += fwrite(&r->num_words, 1, 4, fh); n += fwrite(&r->num_cols, 1, 4, fh);
+  for (uint32_t c = 0; c < r->num_cols; c++) n += fwrite(&r->ginfo[c].mean_read_length, 1, 4, fh);
+  for (uint32_t c = 0; c < r->num_cols; c++) n += fwrite(&r->ginfo[c].total_sequence, 1, 8, fh);
+  if (r->version >= 6) {
+    for (uint32_t c = 0; c < r->num_cols; c++) {
+      const uint32_t len = (uint32_t)strlen(r->ginfo[c].name);
+      n += fwrite(&len, 1, 4, fh); n += fwrite(r->ginfo[c].name, 1, len, fh);
+    }
+    for (uint32_t c = 0; c < r->num_cols; c++) n += fwrite(&r->ginfo[c].seq_err, 1, 16, fh);
+    for (uint32_t c = 0; c < r->num_cols; c++) n += put_cleaning(fh, &r->ginfo[c].cleaning);
+  }
+  n += fwrite("CORTEX", 1, 6, fh);
+  return n;
+}
+
+void ctx_reader_open_mode(ctx_reader *r, const char *input, const char *mode, size_t into_offset, size_t min_k, size_t max_k)
+{
   memset(r, 0, sizeof(*r));
   r->input = dupstr(input);
   const char *ps, *pe;
@@ -370,8 +406,10 @@ void ctx_reader_open(ctx_reader *r, const char *input, size_t into_offset, size_
     if (stat(r->path, &st) == 0) r->file_size = (long long)st.st_size;
     else warn("Couldn't get file size: %s", r->path);
   }
-  if (!strcmp(r->path, "-")) r->fh = stdin;
-  else if (!(r->fh = fopen(r->path, "r"))) die("Cannot open file: %s [%s]", r->path, strerror(errno));
+  if (!strcmp(r->path, "-")) {
+    if (strcmp(mode, "r") != 0) die("Cannot open pipe with mode: %s", mode);
+    r->fh = stdin;
+  } else if (!(r->fh = fopen(r->path, mode))) die("Cannot open file: %s [%s]", r->path, strerror(errno));
   setvbuf(r->fh, NULL, _IOFBF, 1 << 20);
   r->hdr_size = read_header(r);
   filter_set_cols(r, r->num_cols, into_offset);

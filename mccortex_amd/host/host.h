@@ -106,9 +106,15 @@ typedef struct {
 } ctx_reader;
 /* graph_file_open2: parse "<into>:path:<from>", read and check the header; dies on error */
 void ctx_reader_open(ctx_reader *r, const char *input, size_t into_offset, size_t min_k, size_t max_k);
+void ctx_reader_open_mode(ctx_reader *r, const char *input, const char *mode, size_t into_offset, size_t min_k, size_t max_k);
+bool ctx_reader_from_direct(const ctx_reader *r); /* file_filter_from_direct: no colour filter in the path */
+/* graph_write_header (graph_writer.c:62-110): the parsed header as it is, no merging */
+size_t ctx_write_header_raw(FILE *fh, const ctx_reader *r);
 void ctx_reader_close(ctx_reader *r);
 
 /* ---- commands ---- */
 int ctx_build(int argc, char **argv);
+int ctx_sort(int argc, char **argv);
+int ctx_index(int argc, char **argv);
 
 #endif

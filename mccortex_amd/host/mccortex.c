@@ -1,5 +1,6 @@
 /* mccortex.c -- `mccortex<K> <command>` dispatcher (src/main/mccortex.c:15-28,279-332).
- * Only `build` is implemented: this repository replaces that one command's hot path. */
+ * `build` (the hot path this repository replaces) and the two commands next to it that run on the
+ * same device code: `sort` and `index`. */
 #include "host.h"
 
 #include <stdlib.h>
@@ -11,6 +12,8 @@ static const char usage[] =
 "version: mccortex_amd (MI355X build backend) k=" MCX_STR(MIN_KMER_SIZE) ".." MCX_STR(MAX_KMER_SIZE) "\n"
 "\n"
 "Commands:   build       construct cortex graph from FASTA/FASTQ\n"
+"            sort        sort the kmers in a graph file\n"
+"            index       index a sorted cortex graph file\n"
 "\n"
 "  Type a command with no arguments to see help.\n"
 "\n"
@@ -40,12 +43,16 @@ int main(int argc, char **argv)
     }
   }
   if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { fputs(usage, stderr); return EXIT_FAILURE; }
-  if (strcmp(argv[1], "build") != 0) {
-    fprintf(stderr, "%s: command '%s' is not part of this build (only `build` is)\n\n", CMD_NAME, argv[1]);
+  int (*func)(int, char **) = NULL;
+  if (!strcmp(argv[1], "build")) func = ctx_build;
+  else if (!strcmp(argv[1], "sort")) func = ctx_sort;
+  else if (!strcmp(argv[1], "index")) func = ctx_index;
+  if (!func) {
+    fprintf(stderr, "%s: command '%s' is not part of this build (build, sort and index are)\n\n", CMD_NAME, argv[1]);
     fputs(usage, stderr);
     return EXIT_FAILURE;
   }
-  int rc = ctx_build(argc - 1, argv + 1);
+  int rc = func(argc - 1, argv + 1);
   gettimeofday(&t1, NULL);
   double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_usec - t0.tv_usec);
   if (rc == 0) status("[time] %.2f seconds", secs);

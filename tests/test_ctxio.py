@@ -286,3 +286,129 @@ def test_build_graph_option_matches_oracle(mcx, orc, tmp_path, maxk, k):
     assert rc == 0, err
     # first -g: intocolour 0 -> 1; second -g is opened with into_offset 1 (colours 1, 2); -s z -> colour 3
     assert open(out4, "rb").read() == expect(4, [(bufA, A, 0), (o1, "o1.ctx:2,0", 1)], {3: "z"}, [(3, *r[0])])
+
+
+# ---- sort / index / table scans ---------------------------------------
+def _np_sorted(rec, W, rs):
+    a = np.frombuffer(rec, np.uint8).reshape(-1, rs)
+    keys = a[:, :8 * W].copy().view("<u8").reshape(-1, W)
+    order = np.lexsort([keys[:, w] for w in range(W - 1, -1, -1)])
+    return a[order].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,ncols", [(31, 1), (63, 2), (33, 3), (5, 1)])
+def test_sort_records_and_sorted_check(mcx, k, ncols):
+    rng = np.random.default_rng(k + ncols)
+    W = (2 * k + 63) // 64
+    n = 50000
+    keys, covgs, edges, rec = _random_records(rng, k, ncols, n, W)
+    # distinct keys (sort has no tie rule): de-duplicate
+    rs = 8 * W + 5 * ncols
+    a = np.frombuffer(rec, np.uint8).reshape(-1, rs)
+    _, first = np.unique(a[:, :8 * W].copy().view("<u8").reshape(-1, W), axis=0, return_index=True)
+    rec = a[np.sort(first)].tobytes()
+    want = _np_sorted(rec, W, rs)
+    got = mcx.sort_records(rec, k, ncols)
+    assert got == want
+    assert mcx.records_sorted(got, k, ncols) == -1
+    nrec = len(rec) // rs
+    swapped = bytearray(got)
+    i = nrec // 2
+    swapped[i * rs:(i + 1) * rs], swapped[(i + 1) * rs:(i + 2) * rs] = got[(i + 1) * rs:(i + 2) * rs], got[i * rs:(i + 1) * rs]
+    assert mcx.records_sorted(bytes(swapped), k, ncols) == i + 1
+    dup = got[:rs] + got[:rs]
+    assert mcx.records_sorted(dup, k, ncols) == 1          # equal keys are "not sorted" (binary_kmer_ge)
+    assert mcx.sort_records(b"", k, ncols) == b"" and mcx.sort_records(got[:rs], k, ncols) == got[:rs]
+
+
+@pytest.mark.gpu
+def test_kmer_covg_and_histogram(mcx, orc):
+    k, ncols = 31, 3
+    g0 = synth.genome(20000, 12)
+    og = orc.Graph(k, ncols, 1 << 20)
+    g = mcx.Graph(k, ncols, 1 << 20)
+    for c in range(ncols - 1):
+        b, o = synth.reads(3000 * (c + 1), 100, seed=40 + c, g=g0, n_frac=0.02)
+        og.add_reads(c, b, o); g.add_reads(c, b, o)
+    body = og.body_bytes(True)
+    rs = 8 + 5 * ncols
+    a = np.frombuffer(body, np.uint8).reshape(-1, rs)
+    cov = a[:, 8:8 + 4 * ncols].copy().view("<u4").reshape(-1, ncols).astype(np.uint64)
+    nk, sc = g.kmer_covg()
+    assert nk.tolist() == (cov > 0).sum(axis=0).tolist()
+    assert sc.tolist() == cov.sum(axis=0).tolist()
+    for nbins in (2, 16, 5000):
+        want = np.bincount(np.minimum(cov.sum(axis=1), nbins - 1).astype(np.int64), minlength=nbins)
+        assert g.covg_histogram(nbins).tolist() == want.tolist()
+    g.close()
+
+
+def _index_expected(buf, block_kmers):
+    """ctx_index.c:117-158 restated (with its block arithmetic)"""
+    hdr, hs = ctxio.read_header(buf)
+    k, W = hdr["kmer_size"], hdr["num_words"]
+    km = 8 * W + 5 * hdr["num_cols"]
+    bs = block_kmers * km
+    lines = ["#block_start\tnext_block\tfirst_kmer\tkmer_idx\tnext_kmer_idx"]
+    off, koff, p = hs, 0, hs
+    while p + km <= len(buf):
+        words = struct.unpack("<%dQ" % W, buf[p:p + 8 * W])
+        v = 0
+        for w in words:
+            v = (v << 64) | w
+        kstr = "".join("ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+        bl_bytes = km + min(bs - km, len(buf) - (p + km))
+        bl_kmers = 1 + bl_bytes // km
+        lines.append("%d\t%d\t%s\t%d\t%d" % (off, off + bl_bytes, kstr, koff, koff + bl_kmers))
+        off += bl_bytes; koff += bl_kmers; p += bl_bytes
+        if bl_kmers < block_kmers:
+            break
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.gpu
+def test_sort_and_index_commands(mcx, orc, tmp_path):
+    k = 31
+    g0 = synth.genome(20000, 3)
+    r = synth.reads(2000, 100, seed=9, g=g0, n_frac=0.05)
+    f = _fasta(tmp_path / "r.fa", *r)
+    unsorted = str(tmp_path / "u.ctx")
+    rc, _, err = run(31, "build", "-q", "-k", str(k), "-n", "1M", "-s", "a", "--seq", f, "-s", "b", "--seq", f, unsorted)
+    assert rc == 0, err
+    og, gi = _reads_graph(orc, k, 2, [(0, *r), (1, *r)], ["a", "b"])
+    want = ctxio.header_bytes(k, gi) + og.body_bytes(True)
+    ubuf = open(unsorted, "rb").read()
+    assert ubuf != want and len(ubuf) == len(want)
+    # index refuses an unsorted file
+    rc, _, err = run(31, "index", unsorted)
+    assert rc == 1 and "File is not sorted" in err
+    # sort to a new file (header passed through unchanged), refuse to overwrite, then in place
+    s1 = str(tmp_path / "s1.ctx")
+    rc, _, err = run(31, "sort", "-o", s1, unsorted)
+    assert rc == 0, err
+    assert open(s1, "rb").read() == want
+    rc, _, err = run(31, "sort", "-o", s1, unsorted)
+    assert rc == 1 and "File already exists" in err
+    rc, _, err = run(31, "sort", "-q", unsorted)
+    assert rc == 0 and err == ""
+    assert open(unsorted, "rb").read() == want
+    # from a stream: -n required
+    rc, _, err = run(31, "sort", "-o", str(tmp_path / "s2.ctx"), "-", stdin=ubuf)
+    assert rc == 1 and "must give -n" in err
+    rc, out, err = run(31, "sort", "-q", "-n", str(og.nkmers), "-o", "-", "-", stdin=ubuf)
+    assert rc == 0 and out == want
+    rc, _, err = run(31, "sort", "-m", "1K", unsorted)
+    assert rc == 1 and "Require at least" in err
+    rc, _, err = run(31, "sort", unsorted + ":0")
+    assert rc == 1 and "Cannot open graph file with a filter" in err
+    # index: default block size (one block) and small blocks
+    rc, out, err = run(31, "index", s1)
+    assert rc == 0 and out.decode() == _index_expected(want, (4 << 20) // 18)
+    idx = str(tmp_path / "s1.idx")
+    rc, out, err = run(31, "index", "-b", "100", "-o", idx, s1)
+    assert rc == 0 and out == b"" and open(idx).read() == _index_expected(want, 100)
+    rc, out, err = run(31, "index", "-s", "1800", s1)
+    assert rc == 0 and out.decode() == _index_expected(want, 100)
+    rc, _, err = run(31, "index", "-s", "1800", "-b", "100", s1)
+    assert rc == 1 and "Cannot use --block-kmers and --block-size together" in err
