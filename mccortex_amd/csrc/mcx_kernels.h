@@ -356,11 +356,18 @@ __global__ __launch_bounds__(256) void k_covg_scan(TableView t, uint32_t ncols, 
   __syncthreads();
   for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < t.nslots; slot += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t *r = t.rec + slot * t.S;
-    if (!(r[0] & kFlag)) continue;
+    uint64_t w0, v1 = 0;
+    if (t.S == 2) {  // one 16-byte load per record (k <= 31, one colour)
+      const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(r);
+      w0 = kv.x; v1 = kv.y;
+    } else {
+      w0 = r[0];
+    }
+    if (!(w0 & kFlag)) continue;
     const uint32_t W = t.S - ncols;
     uint64_t sum = 0;
     for (uint32_t c = 0; c < ncols; c++) {
-      uint64_t cv = r[W + c] >> 8;
+      uint64_t cv = (t.S == 2 ? v1 : r[W + c]) >> 8;
       if (cv > 0xFFFFFFFFull) cv = 0xFFFFFFFFull;
       if (cv) { atomicAdd(&s_acc[c], 1ULL); atomicAdd(&s_acc[ncols + c], (unsigned long long)cv); }
       sum += cv;

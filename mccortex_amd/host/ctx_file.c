@@ -186,6 +186,8 @@ static int range_parse_array(const char *str, size_t *arr, size_t range_max)
     p += bytes;
     if (*p == ',') p++;
     if (start <= end) for (size_t j = start; j <= end; j++) arr[num++] = j;
+    /* descending range a-b = a, a-1, .. b.  (The reference's loop, range.c:71-72, has no lower
+     * bound: it runs on to 0 and past the array range_get_num() sized.) */
     else for (size_t j = start; j <= start; j--) { arr[num++] = j; if (j == end) break; }
   }
   if (p > str && *(p - 1) == ',') return -1;
