@@ -559,22 +559,48 @@ template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? 512 : 
 #endif
 constexpr int kLdsBatch = MCX_LDS_BATCH;
 
-// find-or-insert one occurrence in the LDS-resident sub-table
+// find-or-insert one occurrence in the LDS-resident sub-table.  A whole bucket (kBucket slots) is
+// examined per step: the four key words are loaded together and compared in registers, so nearly
+// every lane is done after one step (walking slot by slot made the wave run as many iterations as
+// its unluckiest lane).  Slots fill in probe order and never empty, so "first empty slot of the
+// snapshot" + CAS keeps a key from ever being stored twice: a failed CAS re-reads the bucket.
 template <int W>
 __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W> &key, uint32_t bucket, uint32_t e,
                                           uint32_t &n_novel, uint32_t &full)
 {
   constexpr int R = W + 1;
-  uint32_t slot = bucket * kBucket;
   const unsigned long long want = key.w[0] | kFlag;
-  uint32_t probes = 0;
+  uint32_t b = bucket, steps = 0;
   for (;;) {
-    unsigned long long *r = lds + slot * R;
-    unsigned long long cur = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (cur == 0) {
+    unsigned long long *bp = lds + (size_t)b * (kBucket * R);
+    unsigned long long k[kBucket];
+#pragma unroll
+    for (int j = 0; j < kBucket; j++) k[j] = __hip_atomic_load(bp + j * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int hit = -1, empty = -1;
+    bool retry = false;
+#pragma unroll
+    for (int j = kBucket - 1; j >= 0; j--) {
+      if (k[j] == 0) empty = j;
+      if ((k[j] & ~kPending) == want) {
+        if (W == 1) hit = j;
+        else if (k[j] & kPending) retry = true;  // its owner has not published word 1 yet
+        else if (__hip_atomic_load(bp + j * R + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1]) hit = j;
+      }
+    }
+    if (hit >= 0) {
+      unsigned long long *val = bp + hit * R + W;
+      const unsigned long long old = atomicAdd(val, 256ULL);
+      if (e & ~(uint32_t)old) atomicOr(val, (unsigned long long)e);
+      return;
+    }
+    if (retry) {
+      if (++steps > (1u << 22)) { full = 1; return; }
+      continue;
+    }
+    if (empty >= 0) {
+      unsigned long long *r = bp + empty * R;
       const unsigned long long desired = (W == 1) ? want : (want | kPending);
-      cur = atomicCAS(r, 0ULL, desired);
-      if (cur == 0) {
+      if (atomicCAS(r, 0ULL, desired) == 0) {
         if (W == 2) {
           __hip_atomic_store(r + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_store(r, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -584,22 +610,13 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
         if (e) atomicOr(r + W, (unsigned long long)e);
         return;
       }
+      if (++steps > (1u << 22)) { full = 1; return; }
+      continue;  // somebody took the slot: look at the bucket again
     }
-    if ((cur & ~kPending) == want) {
-      bool match = true;
-      if (W == 2) {
-        if (cur & kPending) { if (++probes > (1u << 22)) { full = 1; return; } continue; }
-        match = __hip_atomic_load(r + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1];
-      }
-      if (match) {
-        atomicAdd(r + W, 256ULL);
-        if (e & ~(uint32_t)__hip_atomic_load(r + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-          atomicOr(r + W, (unsigned long long)e);
-        return;
-      }
-    }
-    if (++probes > kSubSlots) { full = 1; return; }
-    slot = (slot + 1) & (uint32_t)(kSubSlots - 1);
+    if (++steps > (uint32_t)kSubBuckets + (1u << 22)) { full = 1; return; }
+    b = (b + 1) & (uint32_t)(kSubBuckets - 1);
+    // a full sub-table: every bucket seen without a hit or a free slot
+    if (b == bucket) { full = 1; return; }
   }
 }
 
