@@ -72,6 +72,22 @@ def make_batch(genome, nreads, seed, device, err_rate=0.001):
     return out.reshape(-1)
 
 
+def pmc_traffic(kernel, occurrences_per_launch):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json,
+    written by tools/prof.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's launch size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        t = json.load(open(files[-1]))["kernels"][kernel]
+        per_occ = (t["read_bytes"] + t["written_bytes"]) / t["occurrences"]
+        return per_occ * occurrences_per_launch, os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError, ZeroDivisionError):
+        return None, None
+
+
 def cpu_baseline(stream_dev, rank):
     """Time the CPU oracle (port of the reference algorithm, pthreads) on a bounded sample."""
     from oracle import orc
@@ -283,8 +299,9 @@ def main():
         alg_bytes = KERNEL_ALG_BYTES[dom] * kmers_local / calls
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         pipe_bytes = ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel
+        traffic, traffic_src = pmc_traffic(dom, kmers_local / calls)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_kernel_ms": avg_ms, "launches": calls, "alg_bytes_per_launch": alg_bytes,
                            "kernels": {n: {"launches": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4)}
                                        for n, (c, t) in prof.items()},

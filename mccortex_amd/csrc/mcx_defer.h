@@ -553,7 +553,10 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
 // colours' value words stay untouched in HBM.  find-or-insert / coverage / edges are the same
 // protocol as probe_insert, with LDS atomics.
 // threads of the LDS-insert workgroup: W=2 slices are 96 KiB (one workgroup per CU), so that one is larger
-template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? 512 : 1024; };
+#ifndef MCX_LDS_THREADS1
+#define MCX_LDS_THREADS1 512
+#endif
+template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : 1024; };
 #ifndef MCX_LDS_BATCH
 #define MCX_LDS_BATCH 4
 #endif
