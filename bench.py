@@ -72,6 +72,20 @@ def make_batch(genome, nreads, seed, device, err_rate=0.001):
     return out.reshape(-1)
 
 
+def make_batch_iid(nreads, seed, device):
+    """C2-stress: iid random reads, (nearly) every k-mer novel."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty((nreads, READ_LEN + 1), dtype=torch.uint8, device=device)
+    sub = 500_000
+    for lo in range(0, nreads, sub):
+        n = min(sub, nreads - lo)
+        out[lo:lo + n, :READ_LEN] = acgt[torch.randint(0, 4, (n, READ_LEN), generator=g, device=device)]
+    out[:, READ_LEN] = ord("\n")
+    return out.reshape(-1)
+
+
 def pmc_traffic(kernel, occurrences_per_launch):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json,
     written by tools/prof.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
@@ -131,6 +145,7 @@ def main():
     ap.add_argument("--table-slots", type=int, default=TABLE_SLOTS, help="experiments only")
     ap.add_argument("--genome", type=int, default=GENOME_PER_GPU, help="experiments only")
     ap.add_argument("--err", type=float, default=0.001, help="experiments only")
+    ap.add_argument("--iid", action="store_true", help="experiments only: C2-stress, iid random reads (every k-mer novel)")
     ap.add_argument("--direct", action="store_true", help="insert with HBM atomics instead of partition + LDS insert")
     ap.add_argument("--defer-tuples", type=int, default=DEFER_TUPLES)
     args = ap.parse_args()
@@ -168,10 +183,13 @@ def main():
 
     B = args.batch_reads
     nsteps, nwarm = args.steps, args.warmup
-    genome = make_genome(args.genome * world, device, seed=42)
-    batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device, err_rate=args.err)
-               for i in range(nsteps + nwarm)]
-    del genome
+    if args.iid:
+        batches = [make_batch_iid(B, seed=1000 * (rank + 1) + i, device=device) for i in range(nsteps + nwarm)]
+    else:
+        genome = make_genome(args.genome * world, device, seed=42)
+        batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device, err_rate=args.err)
+                   for i in range(nsteps + nwarm)]
+        del genome
     torch.cuda.synchronize()
     torch.cuda.empty_cache()  # hand the generator's temporaries back before the graph allocates
 
@@ -282,7 +300,9 @@ def main():
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": nsteps, "warmup": nwarm,
             "ms_per_step": 1e3 * dt / nsteps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
+            "config": {"workload": ("C2-stress: k=31, 1 colour, %d iid random reads x %d bp per step per GPU, table %d slots per GPU"
+                                    % (B, READ_LEN, args.table_slots)) if args.iid else
+                                   "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
                                    "table %d slots per GPU" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots),
                        "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
                        "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else "hash-prefix x%d, all-to-all" % world,

@@ -411,7 +411,9 @@ static uint32_t flush_group(const mcx_graph *g)
   // regions run at the same speed (1, 2, 4 regions per step: launch tails dominate, the hoped-for
   // cache residency of one region's split does not pay); 16 K sub-tables per step = 32 waves of
   // insert workgroups, and the bins take 1/16 of what bins for the whole table would
-  if (!G) G = std::max<uint32_t>(1u, 16384u / std::max<uint32_t>(1u, g->subs_per_bin));
+  // ... and never fewer than 32 regions: with 8 the XCD-aware chunk order of the split leaves one
+  // region per XCD and its blocks all reserve from the same counters (4x slower, C2-stress)
+  if (!G) G = std::max<uint32_t>(32u, 16384u / std::max<uint32_t>(1u, g->subs_per_bin));
   return std::min<uint32_t>(G, g->b1);
 }
 

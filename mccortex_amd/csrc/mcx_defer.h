@@ -624,7 +624,7 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
 }
 
 template <int W, bool ONECOL>
-__global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
+__global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
                                                                     uint32_t sub0, uint32_t nsub, Counters *ctr)
 {
   constexpr int kLdsThreads = LdsCfg<W>::kThreads;
@@ -636,25 +636,40 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
   uint32_t n_novel = 0, full = 0;
 
   // sub-tables sub0 .. sub0 + nsub - 1; bin i of `bins` belongs to sub-table sub0 + i and is handed
-  // back empty (fill reset) for the next group of regions
-  for (uint32_t bi = blockIdx.x; bi < nsub; bi += gridDim.x) {
+  // back empty (fill reset) for the next group of regions.
+  // The slice of the NEXT sub-table this block will own is fetched into registers while the
+  // current one is being updated (ONECOL): load -> apply -> store of one workgroup would otherwise
+  // run back to back, and with two workgroups per CU the HBM pipe idles through the apply phases
+  // (C2-stress, 2.9 K occurrences per 64 KiB slice: 1.1 TB/s before).
+  constexpr int PER = (int)(kSubSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
+  auto next_bin = [&](uint32_t from) {
+    while (from < nsub && bins.counts[from] == 0) from += gridDim.x;
+    return from;
+  };
+  uint32_t bi = next_bin(blockIdx.x);
+  // the prefetched slice: named scalars, not an array -- an array that lives across the loop is
+  // left in scratch memory by the compiler (144 B per lane), which defeats the purpose
+  static_assert(PER <= 8, "slice prefetch registers");
+  ulonglong2 v0{}, v1{}, v2{}, v3{}, v4{}, v5{}, v6{}, v7{};
+#define MCX_SLICE_EACH(OP) OP(0, v0) OP(1, v1) OP(2, v2) OP(3, v3) OP(4, v4) OP(5, v5) OP(6, v6) OP(7, v7)
+#define MCX_SLICE_LOAD(q, r) if (q < PER) r = src[q * kLdsThreads + tid];
+#define MCX_SLICE_PUT(q, r) if (q < PER) dst[q * kLdsThreads + tid] = r;
+  if (ONECOL && bi < nsub) {
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + bi) * kSubSlots * S);
+    MCX_SLICE_EACH(MCX_SLICE_LOAD)
+  }
+  while (bi < nsub) {
     const uint32_t sub = sub0 + bi;
     uint64_t n = bins.counts[bi];
-    if (n == 0) continue;  // uniform
     if (n > bins.cap) n = bins.cap;
     const uint32_t region = sub / t.spb;  // uniform
     uint64_t *slice = t.rec + (uint64_t)sub * kSubSlots * S;
-    __syncthreads();  // (every thread has read the fill)
+    const uint32_t nb = next_bin(bi + gridDim.x);
+    __syncthreads();  // every thread has read the fills; the previous slice has left LDS
     if (tid == 0) bins.counts[bi] = 0;
-    constexpr int PER = (int)(kSubSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
-    if (ONECOL) {  // HBM record == LDS slot: straight 16-byte copies, all loads in flight
-      const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(slice);
+    if (ONECOL) {  // HBM record == LDS slot: straight 16-byte copies
       ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
-      ulonglong2 v[PER];
-#pragma unroll
-      for (int q = 0; q < PER; q++) v[q] = src[q * kLdsThreads + tid];
-#pragma unroll
-      for (int q = 0; q < PER; q++) dst[q * kLdsThreads + tid] = v[q];
+      MCX_SLICE_EACH(MCX_SLICE_PUT)
     } else {
 #pragma unroll 4
       for (uint32_t i = tid; i < kSubSlots; i += kLdsThreads) {
@@ -667,8 +682,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
     __syncthreads();
 
     const uint64_t *kin = bins.keys + (uint64_t)bi * bins.cap * W;
-    for (uint64_t i0 = tid; i0 < n; i0 += (uint64_t)kLdsThreads * kLdsBatch) {
-      Kmer<W> tk[kLdsBatch];
+    auto load_batch = [&](uint64_t i0, Kmer<W> (&tk)[kLdsBatch]) {
 #pragma unroll
       for (int q = 0; q < kLdsBatch; q++) {
         const uint64_t i = i0 + (uint64_t)q * kLdsThreads;
@@ -677,6 +691,8 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
           if (W == 2) tk[q].w[W - 1] = kin[i * W + 1];
         }
       }
+    };
+    auto apply_batch = [&](uint64_t i0, const Kmer<W> (&tk)[kLdsBatch]) {
 #pragma unroll
       for (int q = 0; q < kLdsBatch; q++)
         if (i0 + (uint64_t)q * kLdsThreads < n) {  // packed tuple + region -> full key, start bucket
@@ -687,6 +703,21 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
           const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), r_of(t, region, c));
           lds_apply<W>(lds, key, (c >> lbq_of(t)) & (kSubBuckets - 1), e, n_novel, full);
         }
+    };
+    {  // first batch of tuple loads, THEN the next slice: loads return in order, so the first
+       // batch does not wait for the 64 KiB behind it
+      Kmer<W> tk[kLdsBatch];
+      load_batch(tid, tk);
+      if (ONECOL && nb < nsub) {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + nb) * kSubSlots * S);
+        MCX_SLICE_EACH(MCX_SLICE_LOAD)
+      }
+      apply_batch(tid, tk);
+    }
+    for (uint64_t i0 = (uint64_t)tid + (uint64_t)kLdsThreads * kLdsBatch; i0 < n; i0 += (uint64_t)kLdsThreads * kLdsBatch) {
+      Kmer<W> tk[kLdsBatch];
+      load_batch(i0, tk);
+      apply_batch(i0, tk);
     }
     __syncthreads();
 
@@ -704,7 +735,11 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads) void k_lds_insert(TableView t,
         r[W + col] = lds[i * R + W];
       }
     }
+    bi = nb;
   }
+#undef MCX_SLICE_EACH
+#undef MCX_SLICE_LOAD
+#undef MCX_SLICE_PUT
   if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
   if (full) ctr->full = 1;
 }
