@@ -300,13 +300,18 @@ static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour,
   static bool once = false;
   if (!once) {
     allow_lds(k_stream_bin<W, ONECOL, 512, FULL, SH>, sizeof(BinLds<W, 512, FULL>));
+    allow_lds(k_stream_bin<W, ONECOL, 1024, FULL, SH>, sizeof(BinLds<W, 1024, FULL>));
     allow_lds(k_stream_bin<W, ONECOL, kMaxBins, FULL, SH>, sizeof(BinLds<W, kMaxBins, FULL>));
     once = true;
   }
   SpanGuard sp(g, "k_stream_bin");
   const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
+  // the histogram capacity sets the LDS footprint and with it the blocks per CU: 512 and 1024 bins
+  // leave room for 4 blocks (W=1), 2048 for 2
   if (bs.nlocal <= 512)
     hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, 512, FULL>), g->stream, a, bs, out, is);
+  else if (bs.nlocal <= 1024)
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 1024, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, 1024, FULL>), g->stream, a, bs, out, is);
   else
     hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, FULL>), g->stream, a, bs, out, is);
 }
