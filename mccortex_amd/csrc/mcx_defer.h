@@ -97,7 +97,10 @@ constexpr int kStage = kTile / kRounds;
 // LDS working set of one binning block (NB = histogram capacity)
 template <int W, int NB, bool FULL> struct BinLds {
   uint64_t skey[kStage * W];
-  unsigned long long gbase[NB];  // where this tile's run of every bin starts in its segment
+  // per bin, for the write-out: bits 0..47 = (output tuple index of the bin's first tuple of this
+  // tile) - (its sorted position in the tile), mod 2^48; bits 48..63 = sorted positions below this
+  // value still fit the bin's segment (the rest overflows)
+  unsigned long long gbase[NB];
   uint32_t cnt[NB];
   uint32_t off[NB + 4];
   uint16_t sbin[kStage];
@@ -145,13 +148,22 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
   __syncthreads();
 }
 
+constexpr unsigned long long kDstMask = (1ULL << 48) - 1;
+
 template <class LDS, int NB>
-__device__ __forceinline__ void bin_commit(LDS &L, const BinSpec &bs, const BinRes<NB> &res)
+__device__ __forceinline__ void bin_commit(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, const BinRes<NB> &res)
 {
 #pragma unroll
   for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
     const uint32_t b = (uint32_t)q * kThreads + threadIdx.x;
-    if (b < bs.nlocal) L.gbase[b] = res.g0[q];
+    if (b < bs.nlocal) {
+      const uint32_t o0 = L.off[b], o1 = L.off[b + 1];
+      const unsigned long long g0 = res.g0[q];                       // start of the run in its segment
+      const unsigned long long room = out.cap > g0 ? out.cap - g0 : 0;  // tuples that still fit
+      const uint32_t lim = o0 + (uint32_t)min((unsigned long long)(o1 - o0), room);
+      const unsigned long long dst = ((unsigned long long)out_seg(bs, ob0, b) * out.cap + g0 - o0) & kDstMask;
+      L.gbase[b] = dst | ((unsigned long long)lim << 48);
+    }
   }
 }
 
@@ -187,9 +199,9 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
   const uint32_t cnt = n > lo ? min(n - lo, (uint32_t)kStage) : 0;
   for (uint32_t q = threadIdx.x; q < cnt; q += kThreads) {
     const uint32_t b = L.sbin[q];
-    const uint64_t gpos = L.gbase[b] + ((lo + q) - L.off[b]);
-    if (gpos < out.cap) {
-      const uint64_t at = (uint64_t)out_seg(bs, ob0, b) * out.cap + gpos;
+    const unsigned long long gb = L.gbase[b];
+    if (lo + q < (uint32_t)(gb >> 48)) {
+      const uint64_t at = (gb + (lo + q)) & kDstMask;
       uint64_t *kd = out.keys + at * W;
       kd[0] = L.skey[q * W];
       if (W == 2) kd[1] = L.skey[q * W + 1];
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
 #pragma unroll
     for (int j = 0; j < kPosPerLane; j++)  // sorted position goes into bits 19..30 of tle
       if (vmask & (1u << j)) tle[j] |= bin_rank<LDS>(L, (tle[j] >> 8) & 0x7ffu) << 19;
-    bin_commit<LDS, NB>(L, bs, res);
+    bin_commit<LDS, NB>(L, bs, out, ob0, res);
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
     for (int q = 0; q < PER; q++) {  // sorted position goes into the high half of loc
       if (okm >> q & 1u) loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
     }
-    bin_commit<LDS, NB>(L, bs, res);
+    bin_commit<LDS, NB>(L, bs, out, ob0, res);
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int q = 0; q < PER; q++) {
