@@ -319,11 +319,30 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
     const uint64_t P0 = tile * kTile + 16ull * (uint64_t)tid;
     const int j_lo = a.pos_lo > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_lo - P0) : 0;
     const int j_hi = a.pos_hi > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_hi - P0) : 0;
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < kPosPerLane; j++) {
-      const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
-      any |= ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
+    // The lane's 16 positions as 16-bit masks, position j at bit 15 - j (base i of the lane's
+    // window = bit 63 - i of Vh, then Vl):
+    //   ok16   a whole k-mer of valid bases starts at j, and j is owned by this launch
+    //   nok16  the base after that k-mer is valid (there is a successor)
+    //   pok16  the base before j is valid (there is a predecessor)
+    // "any invalid base in [j, j+k)" for all j at once = OR of k left-shifted copies of the
+    // invalid flags, built by doubling.
+    uint32_t ok16, nok16, pok16;
+    {
+      uint64_t Mh = Vh, Ml = Vl;
+      for (int c = 1; c < k;) {  // uniform
+        const int s = min(c, k - c);
+        if (W == 2) Mh |= (Mh << s) | (Ml >> (64 - s));
+        else Mh |= Mh << s;
+        if (W == 2) Ml |= Ml << s;
+        c += s;
+      }
+      const uint32_t range = ((0x10000u >> j_lo) - 1u) & ~((0x10000u >> j_hi) - 1u);
+      ok16 = ~(uint32_t)(Mh >> 48) & range;
+      // base j + k: bit 127 - k - j of Vh:Vl -> field of 16 starting at bit 112 - k
+      const int sh = 112 - k;  // 49..109
+      const uint64_t nx = sh >= 64 ? (Vh >> (sh - 64)) : ((Vh << (64 - sh)) | (W == 2 ? (Vl >> sh) : 0));
+      nok16 = ~(uint32_t)nx & 0xFFFFu;
+      pok16 = ~((prev_chunk_inv << 15) | (uint32_t)(Vh >> 49)) & 0xFFFFu;
     }
 
     // One pass over the lane's 16 positions: the tuples stay in registers (static indices
@@ -331,7 +350,9 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
     Kmer<W> tk[kPosPerLane];    // FULL: canonical key; packed: quotient | edges << 56
     uint32_t tle[kPosPerLane];  // edge byte (FULL) | local bin << 8 | sorted position << 19
     uint32_t vmask = 0;
-    if (any) {
+    if (ok16) {
+      n_kmers += __popc(ok16);
+      n_contigs += __popc(ok16 & ~pok16);
       Kmer<W> fw, rc;
       if (W == 1) {
         fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
@@ -346,10 +367,10 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
       uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++) {
-        const uint64_t Th = (W == 2 && j) ? ((Vh << j) | (Vl >> (64 - j))) : (Vh << j);
-        const bool valid = ((Th >> (64 - k)) == 0) & (j >= j_lo) & (j < j_hi);
-        const bool next_ok = ((Th >> (63 - k)) & 1ULL) == 0;
-        const bool prev_ok = (j == 0) ? (prev_chunk_inv == 0) : (((Vh >> (64 - j)) & 1ULL) == 0);
+        const uint32_t bit = 0x8000u >> j;
+        const bool valid = (ok16 & bit) != 0;
+        const bool next_ok = (nok16 & bit) != 0;
+        const bool prev_ok = (pok16 & bit) != 0;
         const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
         tle[j] = 0;
         tk[j] = fw;
@@ -379,8 +400,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
               local = kMaxBins;  // not binned
             }
           }
-          n_kmers++;
-          n_contigs += prev_ok ? 0u : 1u;
           if (local < (uint32_t)kMaxBins) {
             vmask |= 1u << j;
             atomicAdd(&L.cnt[local], 1u);
