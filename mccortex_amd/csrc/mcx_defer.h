@@ -364,17 +364,19 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
       }
       rc = revcomp<W>(fw, k);
       const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
-      uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
+      // base before position j: the last base of the previous chunk, then the lane's own codes
+      // (s_code[pl >> 4] holds the 16 bases of the lane, first base on top): constant shifts
+      const uint32_t own = s_code[pl >> 4];
+      const uint32_t before = s_code[(pl - 1) >> 4] & 3u;
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++) {
+        const uint32_t prev_nuc = j == 0 ? before : ((own >> (32 - 2 * j)) & 3u);
         const uint32_t bit = 0x8000u >> j;
         const bool valid = (ok16 & bit) != 0;
         const bool next_ok = (nok16 & bit) != 0;
         const bool prev_ok = (pok16 & bit) != 0;
         const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
-        tle[j] = 0;
-        tk[j] = fw;
-        if (valid) {
+        if (valid) {  // tk[j] / tle[j] are only read for positions that were binned (vmask)
           uint32_t o, local;
           const Kmer<W> key = canonical<W>(fw, rc, o);
           uint32_t e = 0;
@@ -405,7 +407,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
             atomicAdd(&L.cnt[local], 1u);
           }
         }
-        prev_nuc = (uint32_t)(fw.w[0] >> first_shift) & 3u;
         if (W == 1) {
           fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
           rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
