@@ -147,8 +147,9 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   g->W = words_for_k(kmer_size);
   g->ncols = ncols;
   g->device = device;
-  // geometry of the quotient-hashed table: 2^lb1 regions x spb sub-tables x 4096 slots
-  uint64_t nsub = (std::max<uint64_t>(capacity_kmers, 1024) + kSubSlots - 1) / kSubSlots;
+  // geometry of the quotient-hashed table: 2^lb1 regions x spb sub-tables x 4096 (W=2: 2048) slots
+  const uint64_t sub_slots = 1ull << sub_shift_for_words(g->W);
+  uint64_t nsub = (std::max<uint64_t>(capacity_kmers, 1024) + sub_slots - 1) / sub_slots;
   uint32_t lbo = 0;
   while ((1 << lbo) < nparts) lbo++;
   uint32_t lb1 = 0;
@@ -158,14 +159,14 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   const uint64_t spb = (nsub + (1ull << lb1) - 1) >> lb1;
   nsub = spb << lb1;
   if (nsub >= (1ull << 31)) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }
-  const uint64_t slots = nsub * kSubSlots;
+  const uint64_t slots = nsub * sub_slots;
   g->t.nslots = slots;
   g->t.lb1 = lb1;
   g->t.lbo = lbo;
   g->t.part = (uint32_t)part;
   g->t.spb = (uint32_t)spb;
   g->t.S = (uint32_t)(g->W + ncols);
-  g->t.max_probe = (uint32_t)kSubSlots;  // a probe sequence never leaves its sub-table
+  g->t.max_probe = (uint32_t)sub_slots;  // a probe sequence never leaves its sub-table
   { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
   g->table_bytes = slots * g->t.S * 8;
 
@@ -325,6 +326,7 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   static bool once = false;
   if (!once) {
     allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>, sizeof(BinLds<W, 512, false>));
+    allow_lds(k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD>, sizeof(BinLds<W, 1024, false>));
     allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD>, sizeof(BinLds<W, kMaxBins, false>));
     once = true;
   }
@@ -332,6 +334,8 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   const dim3 grid((unsigned)std::min<uint64_t>(nchunks, (uint64_t)g->grid * 4));
   if (bs.nlocal <= 512)
     hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>), grid, dim3(kThreads), sizeof(BinLds<W, 512, false>), g->stream, in, bs, out, is, g->d_ctr);
+  else if (bs.nlocal <= 1024)
+    hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD>), grid, dim3(kThreads), sizeof(BinLds<W, 1024, false>), g->stream, in, bs, out, is, g->d_ctr);
   else
     hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, false>), g->stream, in, bs, out, is, g->d_ctr);
 }
@@ -351,7 +355,7 @@ template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, Tupl
 
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour, uint32_t sub0, uint32_t nsub)
 {
-  const size_t lds = kSubSlots * (W + 1) * 8;
+  const size_t lds = Sub<W>::kSlots * (W + 1) * 8;
   static bool once = false;
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
   BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
@@ -425,7 +429,7 @@ static uint32_t flush_group(const mcx_graph *g)
 static int ensure_defer(mcx_graph *g)
 {
   if (g->l1_keys) return MCX_OK;
-  g->nsub = (uint32_t)(g->t.nslots >> kSubShift);
+  g->nsub = (uint32_t)(g->t.nslots >> sub_shift_for_words(g->W));
   g->b1 = 1u << g->t.lb1;        // L1 bins = regions of the quotient hash
   g->subs_per_bin = g->t.spb;
   // packed tuples need 2k - lb1 <= 56 quotient bits in the top word, and the histograms must fit

@@ -581,14 +581,14 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
 // ---------------------------------------------------------------------------
 // 3. LDS insert: one workgroup owns one sub-table
 // ---------------------------------------------------------------------------
-// The slice is held in LDS as kSubSlots x (W key words + this colour's value word); other
+// The slice is held in LDS as Sub<W>::kSlots x (W key words + this colour's value word); other
 // colours' value words stay untouched in HBM.  find-or-insert / coverage / edges are the same
 // protocol as probe_insert, with LDS atomics.
 // threads of the LDS-insert workgroup: W=2 slices are 96 KiB (one workgroup per CU), so that one is larger
 #ifndef MCX_LDS_THREADS1
 #define MCX_LDS_THREADS1 512
 #endif
-template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : 1024; };
+template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : 512; };
 #ifndef MCX_LDS_BATCH
 #define MCX_LDS_BATCH 4
 #endif
@@ -648,15 +648,15 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
       if (++steps > (1u << 22)) { full = 1; return; }
       continue;  // somebody took the slot: look at the bucket again
     }
-    if (++steps > (uint32_t)kSubBuckets + (1u << 22)) { full = 1; return; }
-    b = (b + 1) & (uint32_t)(kSubBuckets - 1);
+    if (++steps > Sub<W>::kBuckets + (1u << 22)) { full = 1; return; }
+    b = (b + 1) & (Sub<W>::kBuckets - 1);
     // a full sub-table: every bucket seen without a hit or a free slot
     if (b == bucket) { full = 1; return; }
   }
 }
 
 template <int W, bool ONECOL>
-__global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
+__global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
                                                                     uint32_t sub0, uint32_t nsub, Counters *ctr)
 {
   constexpr int kLdsThreads = LdsCfg<W>::kThreads;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_i
   // current one is being updated (ONECOL): load -> apply -> store of one workgroup would otherwise
   // run back to back, and with two workgroups per CU the HBM pipe idles through the apply phases
   // (C2-stress, 2.9 K occurrences per 64 KiB slice: 1.1 TB/s before).
-  constexpr int PER = (int)(kSubSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
+  constexpr int PER = (int)(Sub<W>::kSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
   auto next_bin = [&](uint32_t from) {
     while (from < nsub && bins.counts[from] == 0) from += gridDim.x;
     return from;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_i
 #define MCX_SLICE_LOAD(q, r) if (q < PER) r = src[q * kLdsThreads + tid];
 #define MCX_SLICE_PUT(q, r) if (q < PER) dst[q * kLdsThreads + tid] = r;
   if (ONECOL && bi < nsub) {
-    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + bi) * kSubSlots * S);
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + bi) * Sub<W>::kSlots * S);
     MCX_SLICE_EACH(MCX_SLICE_LOAD)
   }
   while (bi < nsub) {
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_i
     uint64_t n = bins.counts[bi];
     if (n > bins.cap) n = bins.cap;
     const uint32_t region = sub / t.spb;  // uniform
-    uint64_t *slice = t.rec + (uint64_t)sub * kSubSlots * S;
+    uint64_t *slice = t.rec + (uint64_t)sub * Sub<W>::kSlots * S;
     const uint32_t nb = next_bin(bi + gridDim.x);
     __syncthreads();  // every thread has read the fills; the previous slice has left LDS
     if (tid == 0) bins.counts[bi] = 0;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_i
       MCX_SLICE_EACH(MCX_SLICE_PUT)
     } else {
 #pragma unroll 4
-      for (uint32_t i = tid; i < kSubSlots; i += kLdsThreads) {
+      for (uint32_t i = tid; i < Sub<W>::kSlots; i += kLdsThreads) {
         const uint64_t *r = slice + (uint64_t)i * S;
         lds[i * R] = r[0];
         if (W == 2) lds[i * R + 1] = r[1];
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_i
           uint32_t hb;
           const uint32_t c = kmer_hash<W>(qq, 0, &hb);
           const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), r_of(t, region, c));
-          lds_apply<W>(lds, key, (c >> lbq_of(t)) & (kSubBuckets - 1), e, n_novel, full);
+          lds_apply<W>(lds, key, (c >> lbq_of(t)) & (Sub<W>::kBuckets - 1), e, n_novel, full);
         }
     };
     {  // first batch of tuple loads, THEN the next slice: loads return in order, so the first
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_i
       Kmer<W> tk[kLdsBatch];
       load_batch(tid, tk);
       if (ONECOL && nb < nsub) {
-        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + nb) * kSubSlots * S);
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + nb) * Sub<W>::kSlots * S);
         MCX_SLICE_EACH(MCX_SLICE_LOAD)
       }
       apply_batch(tid, tk);
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, (W == 1 ? 4 : 2)) void k_lds_i
       for (int q = 0; q < PER; q++) dst[q * kLdsThreads + tid] = src[q * kLdsThreads + tid];
     } else {
 #pragma unroll 4
-      for (uint32_t i = tid; i < kSubSlots; i += kLdsThreads) {
+      for (uint32_t i = tid; i < Sub<W>::kSlots; i += kLdsThreads) {
         uint64_t *r = slice + (uint64_t)i * S;
         r[0] = lds[i * R];
         if (W == 2) r[1] = lds[i * R + 1];

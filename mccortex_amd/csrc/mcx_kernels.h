@@ -26,17 +26,21 @@ namespace mcx {
 // and edges of a node share one 64-byte sector, so an occurrence costs one
 // random sector instead of the reference's three arrays.
 constexpr int kBucket = 4;  // slots per hash bucket (64 B when S == 2)
-// The table is an array of independent sub-tables of kSubSlots slots: a key's probe sequence
-// starts at its hash bucket and wraps inside its sub-table, so one sub-table (64 KiB at S == 2)
-// can be staged in LDS and owned by a single workgroup (mcx_defer.h).
-constexpr int kSubShift = 12;
-constexpr uint64_t kSubSlots = 1ull << kSubShift;
-
-constexpr uint32_t kSubBuckets = (uint32_t)(kSubSlots / kBucket);  // 1024 buckets per sub-table
+// The table is an array of independent sub-tables: a key's probe sequence starts at its hash
+// bucket and wraps inside its sub-table, so one sub-table can be staged in LDS and owned by a
+// single workgroup (mcx_defer.h).  One-word keys: 4096 slots (64 KiB of key + value words, two
+// workgroups per CU); two-word keys: 2048 slots (48 KiB, so that two or three workgroups share a
+// CU instead of one 96 KiB slice monopolising it).
+template <int W> struct Sub {
+  static constexpr int kShift = W == 1 ? 12 : 11;
+  static constexpr uint64_t kSlots = 1ull << kShift;
+  static constexpr uint32_t kBuckets = (uint32_t)(kSlots / kBucket);
+};
+__host__ __device__ constexpr int sub_shift_for_words(int W) { return W == 1 ? 12 : 11; }
 
 struct TableView {
   uint64_t *rec;
-  uint64_t nslots;   // = (spb << lb1) sub-tables of kSubSlots slots
+  uint64_t nslots;   // = (spb << lb1) sub-tables of Sub<W>::kSlots slots
   uint32_t lb1;      // log2 of the number of top-level regions ("L1 bins") of the table
   uint32_t lbo;      // log2 of the number of shards (GPUs) the global table is split over
   uint32_t part;     // which shard this table is (0 when lbo == 0)
@@ -92,7 +96,7 @@ template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t
   a.G = r ^ (c & ((1u << lbq) - 1u));
   a.region = a.G & ((1u << t.lb1) - 1u);
   a.sub = a.region * t.spb + __umulhi(b, t.spb);
-  a.bucket = (c >> lbq) & (kSubBuckets - 1);
+  a.bucket = (c >> lbq) & (Sub<W>::kBuckets - 1);
   return a;
 }
 // remainder of a key of THIS shard from its quotient hash word c and its region
@@ -105,7 +109,7 @@ template <int W> __device__ __forceinline__ uint64_t key_slot(const TableView &t
   uint32_t r;
   const Kmer<W> q = key_quot<W>(key, lbq_of(t), r);
   const TableAddr a = addr_of<W>(t, q, r);
-  return ((uint64_t)a.sub << kSubShift) + (uint64_t)a.bucket * kBucket;
+  return ((uint64_t)a.sub << Sub<W>::kShift) + (uint64_t)a.bucket * kBucket;
 }
 
 struct Counters {  // device-resident, 64-bit each
@@ -197,7 +201,7 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
     }
     if (++probes > t.max_probe) { full = 1; return; }
     slot++;
-    if ((slot & (kSubSlots - 1)) == 0) slot -= kSubSlots;  // wrap inside the sub-table
+    if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots;  // wrap inside the sub-table
   }
 }
 
@@ -240,7 +244,7 @@ __device__ __forceinline__ uint64_t *find_or_insert_rec(const TableView &t, cons
     }
     if (++probes > t.max_probe) { full = 1; return nullptr; }
     slot++;
-    if ((slot & (kSubSlots - 1)) == 0) slot -= kSubSlots;
+    if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots;
   }
 }
 
