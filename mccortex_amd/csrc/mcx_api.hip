@@ -166,6 +166,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   g->t.part = (uint32_t)part;
   g->t.spb = (uint32_t)spb;
   g->t.S = (uint32_t)(g->W + ncols);
+  // one colour: records [key words, value]; several: key array, then one value array per colour
   g->t.max_probe = (uint32_t)sub_slots;  // a probe sequence never leaves its sub-table
   { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
   g->table_bytes = slots * g->t.S * 8;
@@ -185,6 +186,16 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc((void **)&g->t.rec, g->table_bytes));
+  if (ncols == 1) {
+    g->t.KS = g->t.VS = (uint32_t)(g->W + 1);
+    g->t.val = g->t.rec + g->W;
+    g->t.VC = 0;
+  } else {
+    g->t.KS = (uint32_t)g->W;
+    g->t.VS = 1;
+    g->t.val = g->t.rec + g->t.nslots * (uint64_t)g->W;
+    g->t.VC = g->t.nslots;
+  }
   CREATE_TRY(hipMalloc((void **)&g->d_ctr, sizeof(Counters)));
   CREATE_TRY(hipHostMalloc((void **)&g->h_ctr, sizeof(Counters), hipHostMallocDefault));
   CREATE_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));

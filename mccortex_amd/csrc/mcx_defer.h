@@ -233,8 +233,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
         const uint32_t region = bs.mode == BIN_GROUP ? b : region_of_seg;
         const Kmer<W> key = key_unquot<W>(qq, lbq, r_of(isink.t, region, c));
         const uint64_t slot = key_slot<W>(isink.t, key);
-        const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
-        const uint64_t cur = isink.t.rec[slot * S];
+        const uint64_t cur = *key_ptr_t<W, ONECOL>(isink.t, slot);
         probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
       }
     }
@@ -249,8 +248,7 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
                                             uint32_t &novel, uint32_t &full)
 {
   const uint64_t slot = key_slot<W>(isink.t, key);
-  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : isink.t.S;
-  const uint64_t cur = isink.t.rec[slot * S];
+  const uint64_t cur = *key_ptr_t<W, ONECOL>(isink.t, slot);
   probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
 }
 
@@ -664,7 +662,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
   unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
   constexpr int R = W + 1;  // words per slot in LDS
   const int tid = threadIdx.x;
-  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : t.S;
+  constexpr uint32_t S = W + 1;  // words per record of the one-colour table
   uint32_t n_novel = 0, full = 0;
 
   // sub-tables sub0 .. sub0 + nsub - 1; bin i of `bins` belongs to sub-table sub0 + i and is handed
@@ -703,12 +701,14 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
       ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
       MCX_SLICE_EACH(MCX_SLICE_PUT)
     } else {
+      // several colours: key words and this colour's values are separate contiguous arrays
+      const uint64_t s0 = (uint64_t)sub * Sub<W>::kSlots;
+      const uint64_t *kp = t.rec + s0 * W, *vp = t.val + (uint64_t)col * t.VC + s0;
 #pragma unroll 4
       for (uint32_t i = tid; i < Sub<W>::kSlots; i += kLdsThreads) {
-        const uint64_t *r = slice + (uint64_t)i * S;
-        lds[i * R] = r[0];
-        if (W == 2) lds[i * R + 1] = r[1];
-        lds[i * R + W] = r[W + col];
+        lds[i * R] = kp[(uint64_t)i * W];
+        if (W == 2) lds[i * R + 1] = kp[(uint64_t)i * W + 1];
+        lds[i * R + W] = vp[i];
       }
     }
     __syncthreads();
@@ -759,12 +759,13 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
 #pragma unroll
       for (int q = 0; q < PER; q++) dst[q * kLdsThreads + tid] = src[q * kLdsThreads + tid];
     } else {
+      const uint64_t s0 = (uint64_t)sub * Sub<W>::kSlots;
+      uint64_t *kp = t.rec + s0 * W, *vp = t.val + (uint64_t)col * t.VC + s0;
 #pragma unroll 4
       for (uint32_t i = tid; i < Sub<W>::kSlots; i += kLdsThreads) {
-        uint64_t *r = slice + (uint64_t)i * S;
-        r[0] = lds[i * R];
-        if (W == 2) r[1] = lds[i * R + 1];
-        r[W + col] = lds[i * R + W];
+        kp[(uint64_t)i * W] = lds[i * R];
+        if (W == 2) kp[(uint64_t)i * W + 1] = lds[i * R + 1];
+        vp[i] = lds[i * R + W];
       }
     }
     bi = nb;

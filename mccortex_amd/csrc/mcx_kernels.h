@@ -45,9 +45,32 @@ struct TableView {
   uint32_t lbo;      // log2 of the number of shards (GPUs) the global table is split over
   uint32_t part;     // which shard this table is (0 when lbo == 0)
   uint32_t spb;      // sub-tables per region
-  uint32_t S;        // words per record
+  uint32_t S;        // words per slot in total (key words + colours)
   uint32_t max_probe;
+  // Layout.  One colour: array of records [key words, value] (key and value share a 16-byte /
+  // 24-byte record, one sector per occurrence).  Several colours: the key words of all slots
+  // first, then one value array per colour -- a flush of one colour then touches the keys and
+  // that colour's values only, not every colour's (records of 8 * (W + ncols) bytes made a
+  // 4-colour flush move 2.5x the bytes, a 10-colour one 5.5x).
+  uint32_t KS;       // words between the keys of consecutive slots (W + 1, or W)
+  uint32_t VS;       // words between the values of consecutive slots (W + 1, or 1)
+  uint64_t *val;     // value word of (slot 0, colour 0)
+  uint64_t VC;       // words between the value arrays of consecutive colours (0, or nslots)
 };
+__device__ __forceinline__ uint64_t *key_ptr(const TableView &t, uint64_t slot) { return t.rec + slot * t.KS; }
+__device__ __forceinline__ uint64_t *val_ptr(const TableView &t, uint64_t slot, uint32_t col)
+{
+  return t.val + slot * t.VS + (uint64_t)col * t.VC;
+}
+// the same with the layout known at compile time (ONECOL == one colour == records)
+template <int W, bool ONECOL> __device__ __forceinline__ uint64_t *key_ptr_t(const TableView &t, uint64_t slot)
+{
+  return t.rec + slot * (ONECOL ? (uint64_t)(W + 1) : (uint64_t)W);
+}
+template <int W, bool ONECOL> __device__ __forceinline__ uint64_t *val_ptr_t(const TableView &t, uint64_t slot, uint32_t col)
+{
+  return ONECOL ? t.rec + slot * (uint64_t)(W + 1) + W : t.val + (uint64_t)col * t.VC + slot;
+}
 
 // ---------------------------------------------------------------------------
 // Table addressing: a quotient hash built on Lookup3
@@ -152,11 +175,11 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
                                              uint32_t &novel, uint32_t &full)
 {
   const uint64_t want = key.w[0] | kFlag;
-  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : t.S;
   uint32_t probes = 0;
   bool fresh = true;  // `cur`/`hint` were preloaded for this slot
   for (;;) {
-    uint64_t *r = t.rec + slot * S;
+    uint64_t *r = key_ptr_t<W, ONECOL>(t, slot);
+    uint64_t *v = val_ptr_t<W, ONECOL>(t, slot, col);
     if (!fresh) {
       if (W == 1 && ONECOL) {
         const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(r);
@@ -177,7 +200,7 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
           __hip_atomic_store(r, want, MCX_RLX, MCX_AGENT);
         }
         novel++;
-        update_value<W>(r + W + col, 0, e);
+        update_value<W>(v, 0, e);
         return;
       }
       cur = expected;  // somebody else took the slot: look at what is there now
@@ -192,10 +215,10 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
           continue;
         }
         const uint64_t w1 = __hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT);
-        if (w1 == key.w[W - 1]) { update_value<W>(r + W + col, r[W + col], e); return; }
+        if (w1 == key.w[W - 1]) { update_value<W>(v, *v, e); return; }
       } else {
-        if (!ONECOL) hint = r[W + col];
-        update_value<W>(r + W + col, hint, e);
+        if (!ONECOL) hint = *v;
+        update_value<W>(v, hint, e);
         return;
       }
     }
@@ -208,19 +231,20 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
 // ---------------------------------------------------------------------------
 // Bulk load of .ctx records (graph_load, src/graph/graphs_load.c:86-214)
 // ---------------------------------------------------------------------------
-// find (or, unless must_exist, insert) the record of `key`; nullptr = absent / table full
+// find (or, unless must_exist, insert) the slot of `key`; kNoSlot = absent / table full
+constexpr uint64_t kNoSlot = ~0ULL;
 template <int W>
-__device__ __forceinline__ uint64_t *find_or_insert_rec(const TableView &t, const Kmer<W> &key, bool must_exist,
-                                                        uint32_t &novel, uint32_t &full)
+__device__ __forceinline__ uint64_t find_or_insert_rec(const TableView &t, const Kmer<W> &key, bool must_exist,
+                                                       uint32_t &novel, uint32_t &full)
 {
   const uint64_t want = key.w[0] | kFlag;
   uint64_t slot = key_slot<W>(t, key);
   uint32_t probes = 0;
   for (;;) {
-    uint64_t *r = t.rec + slot * t.S;
+    uint64_t *r = key_ptr(t, slot);
     uint64_t cur = __hip_atomic_load(r, MCX_RLX, MCX_AGENT);
     if (cur == 0) {
-      if (must_exist) return nullptr;
+      if (must_exist) return kNoSlot;
       uint64_t expected = 0;
       const uint64_t desired = (W == 1) ? want : (want | kPending);
       if (__hip_atomic_compare_exchange_strong(r, &expected, desired, MCX_RLX, MCX_RLX, MCX_AGENT)) {
@@ -230,19 +254,19 @@ __device__ __forceinline__ uint64_t *find_or_insert_rec(const TableView &t, cons
           __hip_atomic_store(r, want, MCX_RLX, MCX_AGENT);
         }
         novel++;
-        return r;
+        return slot;
       }
       cur = expected;
     }
     if ((cur & ~kPending) == want) {
-      if (W == 1) return r;
+      if (W == 1) return slot;
       if (cur & kPending) {  // owner has not published word 1 yet
-        if (++probes > t.max_probe * 64u) { full = 1; return nullptr; }
+        if (++probes > t.max_probe * 64u) { full = 1; return kNoSlot; }
         continue;
       }
-      if (__hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT) == key.w[W - 1]) return r;
+      if (__hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT) == key.w[W - 1]) return slot;
     }
-    if (++probes > t.max_probe) { full = 1; return nullptr; }
+    if (++probes > t.max_probe) { full = 1; return kNoSlot; }
     slot++;
     if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots;
   }
@@ -292,12 +316,12 @@ __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t
     if (!any_file) atomicMin(&st->first_zero_covg, (unsigned long long)(rec0 + i));
     if (edges_no_covg) atomicMin(&st->first_edges_no_covg, (unsigned long long)(rec0 + i));
     if (!any_loaded) continue;
-    uint64_t *r = find_or_insert_rec<W>(t, key, must_exist != 0, novel, full);
-    if (!r) continue;
+    const uint64_t slot = find_or_insert_rec<W>(t, key, must_exist != 0, novel, full);
+    if (slot == kNoSlot) continue;
     for (uint32_t m = 0; m < nmap; m++) {
       const uint32_t cv = load_le32(pc + 4 * from[m]);
       const uint32_t e = pe[from[m]];
-      uint64_t *val = r + W + into[m];
+      uint64_t *val = val_ptr(t, slot, (uint32_t)into[m]);
       if (cv) __hip_atomic_fetch_add(val, (uint64_t)cv << 8, MCX_RLX, MCX_AGENT);
       if (e) __hip_atomic_fetch_or(val, (uint64_t)e, MCX_RLX, MCX_AGENT);
     }
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(256) void k_covg_scan(TableView t, uint32_t ncols, 
   for (uint32_t c = threadIdx.x; c < 2 * ncols + lbins; c += blockDim.x) s_acc[c] = 0;
   __syncthreads();
   for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < t.nslots; slot += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t *r = t.rec + slot * t.S;
+    const uint64_t *r = key_ptr(t, slot);
     uint64_t w0, v1 = 0;
     if (t.S == 2) {  // one 16-byte load per record (k <= 31, one colour)
       const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(r);
@@ -368,10 +392,9 @@ __global__ __launch_bounds__(256) void k_covg_scan(TableView t, uint32_t ncols, 
       w0 = r[0];
     }
     if (!(w0 & kFlag)) continue;
-    const uint32_t W = t.S - ncols;
     uint64_t sum = 0;
     for (uint32_t c = 0; c < ncols; c++) {
-      uint64_t cv = (t.S == 2 ? v1 : r[W + c]) >> 8;
+      uint64_t cv = (t.S == 2 ? v1 : *val_ptr(t, slot, c)) >> 8;
       if (cv > 0xFFFFFFFFull) cv = 0xFFFFFFFFull;
       if (cv) { atomicAdd(&s_acc[c], 1ULL); atomicAdd(&s_acc[ncols + c], (unsigned long long)cv); }
       sum += cv;
@@ -490,13 +513,12 @@ __device__ __forceinline__ void flush_batch(const InsertSink<W, ONECOL> &sink, c
                                             const bool (&ov)[kBatch], uint32_t &novel, uint32_t &full)
 {
   uint64_t slot[kBatch], cur[kBatch], hint[kBatch];
-  const uint32_t S = ONECOL ? (uint32_t)(W + 1) : sink.t.S;
 #pragma unroll
   for (int i = 0; i < kBatch; i++) {  // issue all first probes before looking at any
     cur[i] = 0; hint[i] = 0; slot[i] = 0;
     if (ov[i]) {
       slot[i] = key_slot<W>(sink.t, occ[i].key);
-      const uint64_t *r = sink.t.rec + slot[i] * S;
+      const uint64_t *r = key_ptr_t<W, ONECOL>(sink.t, slot[i]);
       if (W == 1 && ONECOL) {
         const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(r);
         cur[i] = kv.x; hint[i] = kv.y;
@@ -773,12 +795,12 @@ __global__ __launch_bounds__(kThreads) void k_compact(TableView t, uint64_t *key
 {
   const uint64_t stride = (uint64_t)gridDim.x * kThreads;
   for (uint64_t s = (uint64_t)blockIdx.x * kThreads + threadIdx.x; s < t.nslots; s += stride) {
-    const uint64_t w0 = t.rec[s * t.S];
+    const uint64_t w0 = *key_ptr(t, s);
     if (w0 & kFlag) {
       const unsigned long long pos = atomicAdd(cursor, 1ULL);
       if (pos < cap_out) {
         key0[pos] = w0 & kKeyMask;  // hash_table_fetch masks the top two bits (hash_table.h:41-46)
-        if (W == 2) key1[pos] = t.rec[s * t.S + 1];
+        if (W == 2) key1[pos] = key_ptr(t, s)[1];
         slot_out[pos] = s;
       }
     }
@@ -806,7 +828,7 @@ __global__ void k_emit_records(TableView t, const uint64_t *slot_of, const uint6
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const uint64_t s = slot_of[perm ? perm[first + i] : first + i];
-  const uint64_t *r = t.rec + s * t.S;
+  const uint64_t *r = key_ptr(t, s);
   const uint32_t recsz = 8u * W + 5u * ncols;
   uint8_t *o = out + i * recsz;
   uint64_t kw[2];
@@ -815,7 +837,7 @@ __global__ void k_emit_records(TableView t, const uint64_t *slot_of, const uint6
   for (int w = 0; w < W; w++)
     for (int b = 0; b < 8; b++) o[w * 8 + b] = (uint8_t)(kw[w] >> (8 * b));
   for (uint32_t c = 0; c < ncols; c++) {
-    const uint64_t v = r[W + c];
+    const uint64_t v = *val_ptr(t, s, c);
     const uint64_t cv = v >> 8;
     const uint32_t covg = cv > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)cv;  // COVG_MAX saturation
     for (int b = 0; b < 4; b++) o[8 * W + 4 * c + b] = (uint8_t)(covg >> (8 * b));
