@@ -653,64 +653,133 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
   }
 }
 
+// The slice of one sub-table in flight between HBM and LDS: up to 8 16-byte vectors per thread,
+// as named members (an indexed array that lives across the sub-table loop is left in scratch
+// memory by the compiler, which defeats the purpose of prefetching into registers).
+struct SliceRegs { ulonglong2 a, b, c, d, e, f, g, h; };
+
+// HBM -> registers.  One colour: the slice is one contiguous block of [key words, value] records,
+// identical to the LDS image.  Several colours: key words and this colour's values are separate
+// contiguous arrays; a thread fetches whole 16-byte vectors of both and pairs them up for LDS.
+template <int W, bool ONECOL, int T>
+__device__ __forceinline__ void slice_load(const TableView &t, uint32_t sub, uint32_t col, int tid, SliceRegs &v)
+{
+  const uint64_t s0 = (uint64_t)sub * Sub<W>::kSlots;
+  if (ONECOL) {
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + s0 * (W + 1));
+    static_assert(Sub<W>::kSlots * (W + 1) * 8 / 16 / T == (W == 1 ? 8 : 6), "vectors per thread");
+    // (element-wise: whole-member copies become memcpys of the struct, which then stays in memory)
+#define MCX_LD(m, q) { const ulonglong2 x = src[q * T + tid]; v.m.x = x.x; v.m.y = x.y; }
+    MCX_LD(a, 0) MCX_LD(b, 1) MCX_LD(c, 2) MCX_LD(d, 3) MCX_LD(e, 4) MCX_LD(f, 5)
+    if (W == 1) { MCX_LD(g, 6) MCX_LD(h, 7) }
+#undef MCX_LD
+  } else if (W == 1) {  // pair p = q * T + tid covers slots 2p, 2p + 1: one key vector, one value vector
+    static_assert(W != 1 || Sub<W>::kSlots / 2 == 4 * (uint64_t)T, "4 slot pairs per thread");
+    const ulonglong2 *K = reinterpret_cast<const ulonglong2 *>(t.rec + s0);
+    const ulonglong2 *V = reinterpret_cast<const ulonglong2 *>(t.val + (uint64_t)col * t.VC + s0);
+#define MCX_LD(m, p) { const ulonglong2 x = p; v.m.x = x.x; v.m.y = x.y; }
+    MCX_LD(a, K[0 * T + tid]) MCX_LD(b, K[1 * T + tid]) MCX_LD(c, K[2 * T + tid]) MCX_LD(d, K[3 * T + tid])
+    MCX_LD(e, V[0 * T + tid]) MCX_LD(f, V[1 * T + tid]) MCX_LD(g, V[2 * T + tid]) MCX_LD(h, V[3 * T + tid])
+#undef MCX_LD
+  } else {              // pair p = j * T + tid: two key vectors (one per slot), one value vector
+    static_assert(W != 2 || Sub<W>::kSlots / 2 == 2 * (uint64_t)T, "2 slot pairs per thread");
+    const ulonglong2 *K = reinterpret_cast<const ulonglong2 *>(t.rec + s0 * 2);
+    const ulonglong2 *V = reinterpret_cast<const ulonglong2 *>(t.val + (uint64_t)col * t.VC + s0);
+#define MCX_LD(m, p) { const ulonglong2 x = p; v.m.x = x.x; v.m.y = x.y; }
+    MCX_LD(a, K[2 * (0 * T + tid)]) MCX_LD(b, K[2 * (0 * T + tid) + 1]) MCX_LD(c, V[0 * T + tid])
+    MCX_LD(d, K[2 * (1 * T + tid)]) MCX_LD(e, K[2 * (1 * T + tid) + 1]) MCX_LD(f, V[1 * T + tid])
+#undef MCX_LD
+  }
+}
+
+// registers -> LDS image: slots of W key words + this colour's value word
+template <int W, bool ONECOL, int T>
+__device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, const SliceRegs &v)
+{
+  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
+  if (ONECOL) {
+#define MCX_ST(m, q) dst[q * T + tid] = make_ulonglong2(v.m.x, v.m.y);
+    MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5)
+    if (W == 1) { MCX_ST(g, 6) MCX_ST(h, 7) }
+#undef MCX_ST
+  } else if (W == 1) {  // slots 2p, 2p + 1 = vectors 2p, 2p + 1: {key, value}
+#define MCX_PUT1(q, kv, vv) { const int p = q * T + tid; dst[2 * p] = make_ulonglong2(kv.x, vv.x); dst[2 * p + 1] = make_ulonglong2(kv.y, vv.y); }
+    MCX_PUT1(0, v.a, v.e) MCX_PUT1(1, v.b, v.f) MCX_PUT1(2, v.c, v.g) MCX_PUT1(3, v.d, v.h)
+#undef MCX_PUT1
+  } else {              // slots 2p, 2p + 1 = 6 words = vectors 3p .. 3p + 2: k0a k0b | v0 k1a | k1b v1
+#define MCX_PUT2(j, k0, k1, vv) { const int p = j * T + tid; dst[3 * p] = make_ulonglong2(k0.x, k0.y); dst[3 * p + 1] = make_ulonglong2(vv.x, k1.x); dst[3 * p + 2] = make_ulonglong2(k1.y, vv.y); }
+    MCX_PUT2(0, v.a, v.b, v.c) MCX_PUT2(1, v.d, v.e, v.f)
+#undef MCX_PUT2
+  }
+}
+
+// LDS image -> HBM
+template <int W, bool ONECOL, int T>
+__device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, uint32_t col, int tid, const unsigned long long *lds)
+{
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(lds);
+  const uint64_t s0 = (uint64_t)sub * Sub<W>::kSlots;
+  if (ONECOL) {
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(t.rec + s0 * (W + 1));
+    constexpr int PER = (int)(Sub<W>::kSlots * (W + 1) * 8 / 16 / T);
+#pragma unroll
+    for (int q = 0; q < PER; q++) dst[q * T + tid] = src[q * T + tid];
+  } else if (W == 1) {
+    ulonglong2 *K = reinterpret_cast<ulonglong2 *>(t.rec + s0);
+    ulonglong2 *V = reinterpret_cast<ulonglong2 *>(t.val + (uint64_t)col * t.VC + s0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int p = q * T + tid;
+      const ulonglong2 x = src[2 * p], y = src[2 * p + 1];
+      K[p] = make_ulonglong2(x.x, y.x);
+      V[p] = make_ulonglong2(x.y, y.y);
+    }
+  } else {
+    ulonglong2 *K = reinterpret_cast<ulonglong2 *>(t.rec + s0 * 2);
+    ulonglong2 *V = reinterpret_cast<ulonglong2 *>(t.val + (uint64_t)col * t.VC + s0);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int p = j * T + tid;
+      const ulonglong2 x = src[3 * p], y = src[3 * p + 1], z = src[3 * p + 2];
+      K[2 * p] = x;
+      K[2 * p + 1] = make_ulonglong2(y.y, z.x);
+      V[p] = make_ulonglong2(y.x, z.y);
+    }
+  }
+}
+
 template <int W, bool ONECOL>
 __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
-                                                                    uint32_t sub0, uint32_t nsub, Counters *ctr)
+                                                                       uint32_t sub0, uint32_t nsub, Counters *ctr)
 {
   constexpr int kLdsThreads = LdsCfg<W>::kThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
-  constexpr int R = W + 1;  // words per slot in LDS
   const int tid = threadIdx.x;
-  constexpr uint32_t S = W + 1;  // words per record of the one-colour table
   uint32_t n_novel = 0, full = 0;
 
   // sub-tables sub0 .. sub0 + nsub - 1; bin i of `bins` belongs to sub-table sub0 + i and is handed
   // back empty (fill reset) for the next group of regions.
   // The slice of the NEXT sub-table this block will own is fetched into registers while the
-  // current one is being updated (ONECOL): load -> apply -> store of one workgroup would otherwise
-  // run back to back, and with two workgroups per CU the HBM pipe idles through the apply phases
+  // current one is being updated: load -> apply -> store of one workgroup would otherwise run back
+  // to back, and with two workgroups per CU the HBM pipe idles through the apply phases
   // (C2-stress, 2.9 K occurrences per 64 KiB slice: 1.1 TB/s before).
-  constexpr int PER = (int)(Sub<W>::kSlots * R * 8 / 16 / kLdsThreads);  // 16-byte vectors per thread
   auto next_bin = [&](uint32_t from) {
     while (from < nsub && bins.counts[from] == 0) from += gridDim.x;
     return from;
   };
   uint32_t bi = next_bin(blockIdx.x);
-  // the prefetched slice: named scalars, not an array -- an array that lives across the loop is
-  // left in scratch memory by the compiler (144 B per lane), which defeats the purpose
-  static_assert(PER <= 8, "slice prefetch registers");
-  ulonglong2 v0{}, v1{}, v2{}, v3{}, v4{}, v5{}, v6{}, v7{};
-#define MCX_SLICE_EACH(OP) OP(0, v0) OP(1, v1) OP(2, v2) OP(3, v3) OP(4, v4) OP(5, v5) OP(6, v6) OP(7, v7)
-#define MCX_SLICE_LOAD(q, r) if (q < PER) r = src[q * kLdsThreads + tid];
-#define MCX_SLICE_PUT(q, r) if (q < PER) dst[q * kLdsThreads + tid] = r;
-  if (ONECOL && bi < nsub) {
-    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + bi) * Sub<W>::kSlots * S);
-    MCX_SLICE_EACH(MCX_SLICE_LOAD)
-  }
+  SliceRegs v{};
+  if (bi < nsub) slice_load<W, ONECOL, kLdsThreads>(t, sub0 + bi, col, tid, v);
   while (bi < nsub) {
     const uint32_t sub = sub0 + bi;
     uint64_t n = bins.counts[bi];
     if (n > bins.cap) n = bins.cap;
     const uint32_t region = sub / t.spb;  // uniform
-    uint64_t *slice = t.rec + (uint64_t)sub * Sub<W>::kSlots * S;
     const uint32_t nb = next_bin(bi + gridDim.x);
     __syncthreads();  // every thread has read the fills; the previous slice has left LDS
     if (tid == 0) bins.counts[bi] = 0;
-    if (ONECOL) {  // HBM record == LDS slot: straight 16-byte copies
-      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
-      MCX_SLICE_EACH(MCX_SLICE_PUT)
-    } else {
-      // several colours: key words and this colour's values are separate contiguous arrays
-      const uint64_t s0 = (uint64_t)sub * Sub<W>::kSlots;
-      const uint64_t *kp = t.rec + s0 * W, *vp = t.val + (uint64_t)col * t.VC + s0;
-#pragma unroll 4
-      for (uint32_t i = tid; i < Sub<W>::kSlots; i += kLdsThreads) {
-        lds[i * R] = kp[(uint64_t)i * W];
-        if (W == 2) lds[i * R + 1] = kp[(uint64_t)i * W + 1];
-        lds[i * R + W] = vp[i];
-      }
-    }
+    slice_to_lds<W, ONECOL, kLdsThreads>(lds, tid, v);
     __syncthreads();
 
     const uint64_t *kin = bins.keys + (uint64_t)bi * bins.cap * W;
@@ -740,10 +809,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
        // batch does not wait for the 64 KiB behind it
       Kmer<W> tk[kLdsBatch];
       load_batch(tid, tk);
-      if (ONECOL && nb < nsub) {
-        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t.rec + (uint64_t)(sub0 + nb) * Sub<W>::kSlots * S);
-        MCX_SLICE_EACH(MCX_SLICE_LOAD)
-      }
+      if (nb < nsub) slice_load<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v);
       apply_batch(tid, tk);
     }
     for (uint64_t i0 = (uint64_t)tid + (uint64_t)kLdsThreads * kLdsBatch; i0 < n; i0 += (uint64_t)kLdsThreads * kLdsBatch) {
@@ -752,27 +818,9 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
       apply_batch(i0, tk);
     }
     __syncthreads();
-
-    if (ONECOL) {
-      const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(lds);
-      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(slice);
-#pragma unroll
-      for (int q = 0; q < PER; q++) dst[q * kLdsThreads + tid] = src[q * kLdsThreads + tid];
-    } else {
-      const uint64_t s0 = (uint64_t)sub * Sub<W>::kSlots;
-      uint64_t *kp = t.rec + s0 * W, *vp = t.val + (uint64_t)col * t.VC + s0;
-#pragma unroll 4
-      for (uint32_t i = tid; i < Sub<W>::kSlots; i += kLdsThreads) {
-        kp[(uint64_t)i * W] = lds[i * R];
-        if (W == 2) kp[(uint64_t)i * W + 1] = lds[i * R + 1];
-        vp[i] = lds[i * R + W];
-      }
-    }
+    slice_store<W, ONECOL, kLdsThreads>(t, sub, col, tid, lds);
     bi = nb;
   }
-#undef MCX_SLICE_EACH
-#undef MCX_SLICE_LOAD
-#undef MCX_SLICE_PUT
   if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
   if (full) ctr->full = 1;
 }
