@@ -3,6 +3,7 @@
  * MI355X backend through include/mcx_gpu.h instead of build_graph() / graph_writer. */
 #define _GNU_SOURCE
 #include "host.h"
+#include <time.h>
 
 #include <ctype.h>
 #include <errno.h>
@@ -19,6 +20,8 @@
 #define IDEAL_OCCUPANCY 0.75f
 #define WARN_OCCUPANCY 0.9f
 #define BATCH_BASES (48u << 20)
+/* batches of the parallel parser: small enough that submitting (one thread) overlaps with parsing */
+#define PAR_BATCH_BASES (8u << 20)
 
 static const char build_usage[] =
 "usage: " CMD_NAME " build [options] <out.ctx>\n"
@@ -133,6 +136,19 @@ static int write_sink(void *ctx, const void *recs, size_t n)
   return fwrite(recs, 1, n, (FILE *)ctx) == n ? 0 : 1;
 }
 
+/* MCX_TIMING=1: elapsed milliseconds at every stage (stderr), for the end-to-end breakdown */
+#include <time.h>
+static void stage_time(const char *what)
+{
+  static int on = -1;
+  static struct timespec t0;
+  if (on < 0) { on = getenv("MCX_TIMING") != NULL; clock_gettime(CLOCK_MONOTONIC, &t0); }
+  if (!on) return;
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  fprintf(stderr, "[timing] %8.1f ms  %s\n", (t.tv_sec - t0.tv_sec) * 1e3 + (t.tv_nsec - t0.tv_nsec) * 1e-6, what);
+}
+
 static void mcx_check(int rc, const char *what)
 {
   if (rc == MCX_ERR_FULL) die("Hash table is full");
@@ -141,6 +157,8 @@ static void mcx_check(int rc, const char *what)
 
 /* one batch of parsed reads -> the GPU (callback of the parallel parser and body of the sequential loop) */
 typedef struct { mcx_graph *g; build_task *bt; bool use_q; uint8_t fq_abs; } submit_ctx;
+static double submit_ms = 0; /* time inside mcx_graph_add_reads (MCX_TIMING) */
+static unsigned long submit_calls = 0;
 static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
 {
   submit_ctx *sc = arg;
@@ -150,8 +168,13 @@ static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
     if (!off) off = 33;
     sc->fq_abs = (uint8_t)(sc->bt->fq_cutoff + off);
   }
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
   mcx_check(mcx_graph_add_reads(sc->g, sc->bt->colour, b->bases, sc->use_q ? b->quals : NULL, b->offsets, b->nreads,
                                 sc->fq_abs, sc->bt->hp_cutoff, &sc->bt->stats), "add reads");
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  submit_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+  submit_calls++;
 }
 
 /* file_filter_status: file_filter.c:170-192 */
@@ -377,7 +400,9 @@ int ctx_build(int argc, char **argv)
         bytes_to_str(graph_mem, 1, s1), bytes_to_str(mem_to_use, 1, s2));
   status("[memory] graph: %s", bytes_to_str(graph_mem, 1, s1));
 
+  stage_time("arguments parsed");
   if (mcx_device_count() < 1) die("No MI355X / HIP device found: %s has no CPU build path", CMD_NAME);
+  stage_time("HIP runtime up");
   uint64_t hbm_free = 0, hbm_total = 0;
   mcx_check(mcx_device_memory(device, &hbm_free, &hbm_total), "device query");
   const uint64_t dev_bytes = kmers_in_hash * 8 * (W + ncols);
@@ -400,6 +425,7 @@ int ctx_build(int argc, char **argv)
   uint64_t slots = 0, tbytes = 0;
   mcx_graph_capacity(g, &slots, &tbytes);
   status("[hasht] Allocated table in HBM with %s entries, using %s", ulong_to_str(slots, s1), bytes_to_str(tbytes, 1, s2));
+  stage_time("table allocated");
 
   col_info *cols = calloc(ncols, sizeof(col_info));
   for (size_t i = 0; i < ncols; i++) col_info_init(&cols[i]);
@@ -425,7 +451,7 @@ int ctx_build(int argc, char **argv)
     submit_ctx sc = {g, bt, bt->fq_cutoff > 0 && bt->fmt == SEQ_FMT_FASTQ, 0};
     int prc = 1;
     if (nthreads > 1 && strcmp(bt->path, "-") != 0)
-      prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, BATCH_BASES, submit_batch, &sc);
+      prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, PAR_BATCH_BASES, submit_batch, &sc);
     if (prc == 2) die("Irregular %s record in %s (multi-line FASTQ?): rerun with -t 1", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
     if (prc == 1) {
       seq_in *in = seq_in_open(bt->path);
@@ -451,7 +477,10 @@ int ctx_build(int argc, char **argv)
     prev = cur;
     col_info_update(&cols[bt->colour], bt->stats.total_bases_loaded, bt->stats.contigs_parsed);
   }
+  stage_time("inputs submitted");
+  if (getenv("MCX_TIMING")) fprintf(stderr, "[timing] %8.1f ms  inside mcx_graph_add_reads (%lu calls)\n", submit_ms, submit_calls);
   mcx_check(mcx_graph_sync(g), "sync");
+  stage_time("graph built (device idle)");
 
   uint64_t nk = 0;
   mcx_check(mcx_graph_nkmers(g, &nk), "nkmers");
@@ -473,11 +502,13 @@ int ctx_build(int argc, char **argv)
   size_t hdr = ctx_write_header(fout, (uint32_t)kmer_size, (uint32_t)ncols, cols);
   mcx_check(mcx_graph_export(g, sort_kmers ? 1 : 0, write_sink, fout), "export");
   if (fflush(fout) != 0) die("Cannot write to file");
+  stage_time("graph written");
   const size_t recsz = 8 * W + 5 * ncols;
   status("Dumped %s kmers in %zu colour%s into: %s (format version: 6; %s)", ulong_to_str(nk, s1), ncols,
          ncols == 1 ? "" : "s", strcmp(out_path, "-") ? out_path : "STDOUT", bytes_to_str(hdr + nk * recsz, 1, s2));
   if (fout != stdout) fclose(fout);
   mcx_graph_destroy(g);
+  stage_time("device released");
   for (size_t t = 0; t < ntasks; t++) free(tasks[t].path);
   for (size_t i = 0; i < ncols; i++) col_info_free(&cols[i]);
   free(tasks); free(cols); free(sample_names); free(sample_cols); free(gfiles);

@@ -219,8 +219,16 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
     w->ctx = &c;
     w->rp = (range_parser){prev, next, fmt, want_quals, batch_bases, 255, 0, false};
     w->ready = -1;
-    read_batch_init(&w->batch[0], want_quals);
-    read_batch_init(&w->batch[1], want_quals);
+    for (int i = 0; i < 2; i++) { /* sized for a whole batch up front: no realloc growth while parsing */
+      read_batch *b = &w->batch[i];
+      read_batch_init(b, want_quals);
+      b->cap_bases = batch_bases + (1u << 20);
+      b->cap_reads = batch_bases / 32 + 1024;
+      b->bases = realloc(b->bases, b->cap_bases);
+      if (want_quals) b->quals = realloc(b->quals, b->cap_bases);
+      b->offsets = realloc(b->offsets, (b->cap_reads + 1) * sizeof(uint64_t));
+      if (!b->bases || !b->offsets || (want_quals && !b->quals)) die("Out of memory");
+    }
     prev = next;
   }
   for (int t = 0; t < nthreads; t++) pthread_create(&c.w[t].th, NULL, worker_main, &c.w[t]);
