@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <vector>
+#include <chrono>
 
 #include "../../include/mcx_gpu.h"
 #include "mcx_kernels.h"
@@ -1038,9 +1039,20 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
 // ---------------------------------------------------------------------------
 // export
 // ---------------------------------------------------------------------------
+// MCX_TIMING=1: stage clock of the export (stderr)
+static void export_clock(const char *what)
+{
+  static const bool on = getenv("MCX_TIMING") != nullptr;
+  if (!on) return;
+  static auto t0 = std::chrono::steady_clock::now();
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(stderr, "[timing]   export %8.1f ms  %s\n", ms, what);
+}
+
 template <int W>
 static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
 {
+  export_clock("start");
   int rc = fetch_counters(g);
   if (rc != MCX_OK) return rc;
   const uint64_t n = g->h_ctr->novel;
@@ -1064,10 +1076,12 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
       return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     }                                                                                     \
   } while (0)
+  export_clock("counters fetched");
   EXP_TRY(hipMalloc((void **)&d_k0, n * 8));
   if (W == 2) EXP_TRY(hipMalloc((void **)&d_k1, n * 8));
   EXP_TRY(hipMalloc((void **)&d_slot, n * 8));
   EXP_TRY(hipMalloc((void **)&d_cursor, 8));
+  export_clock("key arrays allocated");
   EXP_TRY(hipMemsetAsync(d_cursor, 0, 8, st));
   hipLaunchKernelGGL((k_compact<W>), dim3(g->grid), dim3(kThreads), 0, st, g->t, d_k0, d_k1, d_slot, d_cursor, n);
   EXP_TRY(hipGetLastError());
@@ -1075,6 +1089,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   EXP_TRY(hipMemcpyAsync(&found, d_cursor, 8, hipMemcpyDeviceToHost, st));
   EXP_TRY(hipStreamSynchronize(st));
   if (found != n) { cleanup(); return fail(MCX_ERR_HIP, "table scan found %llu nodes, counter says %llu", found, (unsigned long long)n); }
+  export_clock("compacted");
 
   // permutation of the compacted entries: by key (sorted) or by slot (table order)
   EXP_TRY(hipMalloc((void **)&d_idx, n * 8));
@@ -1094,19 +1109,49 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
     perm = d_idx;
   }
 
+  EXP_TRY(hipStreamSynchronize(st));
+  export_clock("sorted");
+  // records are produced and copied to pinned memory in 64 MiB chunks, double buffered: while the
+  // sink consumes chunk i on the host, the device emits and copies chunk i + 1
   const uint32_t recsz = 8u * W + 5u * (uint32_t)g->ncols;
   const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz);
-  EXP_TRY(hipMalloc((void **)&d_rec, chunk * recsz));
-  EXP_TRY(hipHostMalloc((void **)&h_rec, chunk * recsz, hipHostMallocDefault));
-  for (uint64_t first = 0; first < n; first += chunk) {
+  hipEvent_t done[2] = {nullptr, nullptr};
+  uint8_t *d_rec2[2] = {nullptr, nullptr}, *h_rec2[2] = {nullptr, nullptr};
+  auto cleanup2 = [&]() {
+    for (int i = 0; i < 2; i++) {
+      if (done[i]) (void)hipEventDestroy(done[i]);
+      (void)hipFree(d_rec2[i]);
+      if (h_rec2[i]) (void)hipHostFree(h_rec2[i]);
+    }
+  };
+#define EXP2_TRY(expr) do { hipError_t _e2 = (expr); if (_e2 != hipSuccess) { cleanup2(); EXP_TRY(_e2); } } while (0)
+  for (int i = 0; i < 2; i++) {
+    EXP2_TRY(hipMalloc((void **)&d_rec2[i], chunk * recsz));
+    EXP2_TRY(hipHostMalloc((void **)&h_rec2[i], chunk * recsz, hipHostMallocDefault));
+    EXP2_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+  }
+  auto produce = [&](uint64_t first, int b) -> hipError_t {
     const uint64_t cnt = std::min(chunk, n - first);
     hipLaunchKernelGGL((k_emit_records<W>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g->t,
-                       (const uint64_t *)d_slot, (const uint64_t *)perm, first, cnt, (uint32_t)g->ncols, d_rec);
-    EXP_TRY(hipGetLastError());
-    EXP_TRY(hipMemcpyAsync(h_rec, d_rec, cnt * recsz, hipMemcpyDeviceToHost, st));
-    EXP_TRY(hipStreamSynchronize(st));
-    if (sink(ctx, h_rec, cnt * recsz) != 0) { cleanup(); return fail(MCX_ERR_SINK, "export sink failed"); }
+                       (const uint64_t *)d_slot, (const uint64_t *)perm, first, cnt, (uint32_t)g->ncols, d_rec2[b]);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(h_rec2[b], d_rec2[b], cnt * recsz, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    return hipEventRecord(done[b], st);
+  };
+  export_clock("buffers allocated");
+  EXP2_TRY(produce(0, 0));
+  int b = 0;
+  for (uint64_t first = 0; first < n; first += chunk, b ^= 1) {
+    const uint64_t cnt = std::min(chunk, n - first);
+    if (first + chunk < n) EXP2_TRY(produce(first + chunk, b ^ 1));
+    EXP2_TRY(hipEventSynchronize(done[b]));
+    if (sink(ctx, h_rec2[b], cnt * recsz) != 0) { cleanup2(); cleanup(); return fail(MCX_ERR_SINK, "export sink failed"); }
   }
+  export_clock("records delivered");
+  cleanup2();
+#undef EXP2_TRY
 #undef EXP_TRY
   cleanup();
   return MCX_OK;

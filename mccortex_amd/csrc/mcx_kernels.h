@@ -788,22 +788,50 @@ __global__ void k_qh_contigs(const uint8_t *bases, const uint8_t *quals, const u
 // ---------------------------------------------------------------------------
 // Export: compact occupied slots
 // ---------------------------------------------------------------------------
-// Pass over the table; every occupied slot appends (key words, slot index).
+// Pass over the table; every occupied slot appends (key words, slot index).  A lane looks at 16
+// consecutive slots and the wave reserves its output range with ONE atomic on the cursor (all
+// waves hit the same address: ~12 ns each, so one atomic per 64 slots made the 2^29-slot scan take
+// 100 ms; per 1024 slots it is 6 ms).
 template <int W>
 __global__ __launch_bounds__(kThreads) void k_compact(TableView t, uint64_t *key0, uint64_t *key1, uint64_t *slot_out,
                                                       unsigned long long *cursor, uint64_t cap_out)
 {
-  const uint64_t stride = (uint64_t)gridDim.x * kThreads;
-  for (uint64_t s = (uint64_t)blockIdx.x * kThreads + threadIdx.x; s < t.nslots; s += stride) {
-    const uint64_t w0 = *key_ptr(t, s);
-    if (w0 & kFlag) {
-      const unsigned long long pos = atomicAdd(cursor, 1ULL);
-      if (pos < cap_out) {
-        key0[pos] = w0 & kKeyMask;  // hash_table_fetch masks the top two bits (hash_table.h:41-46)
-        if (W == 2) key1[pos] = key_ptr(t, s)[1];
-        slot_out[pos] = s;
-      }
+  constexpr int PER = 16;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t stride = (uint64_t)gridDim.x * kThreads * PER;
+  // nslots is a multiple of 2048 (sub-table size) and of the 4096 slots a block covers per round
+  // only when it is a multiple of kThreads * PER: the tail is guarded per slot
+  for (uint64_t s0 = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) * PER; s0 - (uint64_t)lane * PER < t.nslots; s0 += stride) {
+    uint64_t w0[PER];
+    uint32_t occ = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      w0[i] = (s0 + i < t.nslots) ? *key_ptr(t, s0 + i) : 0;
+      occ |= (uint32_t)((w0[i] & kFlag) != 0) << i;
     }
+    const uint32_t cnt = __popc(occ);
+    uint32_t incl = cnt;  // inclusive prefix sum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d) incl += y;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0) continue;  // uniform
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)total);
+    base = __shfl(base, 0, 64);
+    unsigned long long pos = base + (incl - cnt);
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+      if (occ >> i & 1u) {
+        if (pos < cap_out) {
+          key0[pos] = w0[i] & kKeyMask;  // hash_table_fetch masks the top two bits (hash_table.h:41-46)
+          if (W == 2) key1[pos] = key_ptr(t, s0 + i)[1];
+          slot_out[pos] = s0 + i;
+        }
+        pos++;
+      }
   }
 }
 
