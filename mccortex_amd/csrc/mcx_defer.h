@@ -431,9 +431,9 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
     }
   }
 
-  if (n_kmers) atomicAdd(&a.ctr->kmers, (unsigned long long)n_kmers);
-  if (n_contigs) atomicAdd(&a.ctr->contigs, (unsigned long long)n_contigs);
-  if (n_novel) atomicAdd(&a.ctr->novel, (unsigned long long)n_novel);
+  block_add(&a.ctr->kmers, n_kmers);
+  block_add(&a.ctr->contigs, n_contigs);
+  block_add(&a.ctr->novel, n_novel);
   if (full == 1) a.ctr->full = 1;
   if (full == 2) a.ctr->bin_over = 1;
   if (a.flag && n_contigs) *a.flag = 1;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
       bin_writeout<W, ONECOL, false, 0, LDS>(L, round, bs, out, ob0, region, isink, n_novel, full);
     }
   }
-  if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
+  block_add(&ctr->novel, n_novel);
   if (full == 1) ctr->full = 1;
   if (full == 2) ctr->bin_over = 1;
 }
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
     slice_store<W, ONECOL, kLdsThreads>(t, sub, col, tid, lds);
     bi = nb;
   }
-  if (n_novel) atomicAdd(&ctr->novel, (unsigned long long)n_novel);
+  block_add(&ctr->novel, n_novel);
   if (full) ctr->full = 1;
 }
 
