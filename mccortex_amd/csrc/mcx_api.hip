@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <vector>
+#include <thread>
 #include <chrono>
 
 #include "../../include/mcx_gpu.h"
@@ -771,6 +772,17 @@ extern "C" uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int 
 // ---------------------------------------------------------------------------
 // host-buffer entry: stage reads as a '\n'-separated stream
 // ---------------------------------------------------------------------------
+// threads that copy reads into the pinned staging buffer (MCX_STAGE_THREADS, default 4)
+static int stage_threads()
+{
+  static const int n = [] {
+    const char *e = getenv("MCX_STAGE_THREADS");
+    const int v = e ? atoi(e) : 4;
+    return v < 1 ? 1 : v > 32 ? 32 : v;
+  }();
+  return n;
+}
+
 static int ensure_stage(mcx_graph *g)
 {
   if (g->stage_alloc) return MCX_OK;
@@ -828,6 +840,35 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
     uint64_t L = 0, nwhole = 0;
     const uint64_t r0 = r;
     long long piece_of = -1;  // >= 0: chunk holds a piece of this (long) read only
+    if (r_pos == 0 && stage_threads() > 1) {
+      // Whole reads that fit this chunk, found without copying; then a few threads copy their
+      // share (read r lands at (off[r] - off[r0]) + (r - r0): every read is followed by one
+      // separator).  One thread moves ~10 GB/s into pinned memory, PCIe takes ~25 GB/s.
+      uint64_t nf = 0, bytes = 0;
+      while (r0 + nf < nreads && nf < max_offs) {
+        const uint64_t len = off[r0 + nf + 1] - off[r0 + nf];
+        if (bytes + len + 1 > kStageBytes) break;
+        bytes += len + 1;
+        nf++;
+      }
+      if (nf >= 4096) {
+        const int T = stage_threads();
+        auto work = [&](int ti) {
+          const uint64_t lo = nf * (uint64_t)ti / (uint64_t)T, hi = nf * (uint64_t)(ti + 1) / (uint64_t)T;
+          for (uint64_t i = lo; i < hi; i++) {
+            const uint64_t at = (off[r0 + i] - off[r0]) + i, len = off[r0 + i + 1] - off[r0 + i];
+            hoff[i] = kCarry + at;
+            memcpy(hs + kCarry + at, bases + off[r0 + i], len);
+            hs[kCarry + at + len] = '\n';
+          }
+        };
+        std::vector<std::thread> th;
+        for (int ti = 1; ti < T; ti++) th.emplace_back(work, ti);
+        work(0);
+        for (auto &x : th) x.join();
+        nwhole = nf; L = bytes; r += nf;
+      }
+    }
     while (r < nreads) {
       const uint64_t len = off[r + 1] - off[r];
       const uint64_t remain = len - r_pos;
