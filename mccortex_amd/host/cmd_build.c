@@ -197,6 +197,9 @@ static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
 {
   submit_ctx *sc = arg;
   if (!b->nreads) return;
+  static int parse_only = -1;  /* MCX_PARSE_ONLY=1: measure the parser alone (nothing reaches the GPU) */
+  if (parse_only < 0) parse_only = getenv("MCX_PARSE_ONLY") != NULL;
+  if (parse_only) return;
   if (sc->use_q && !sc->fq_abs) { /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 */
     int off = sc->bt->fq_offset ? sc->bt->fq_offset : fq_offset_guess;
     if (!off) off = 33;
@@ -485,7 +488,7 @@ int ctx_build(int argc, char **argv)
     submit_ctx sc = {g, bt, bt->fq_cutoff > 0 && bt->fmt == SEQ_FMT_FASTQ, 0};
     int prc = 1;
     if (nthreads > 1 && strcmp(bt->path, "-") != 0)
-      prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, PAR_BATCH_BASES, submit_batch, &sc);
+      prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, getenv("MCX_PAR_BATCH") ? (size_t)atol(getenv("MCX_PAR_BATCH")) : PAR_BATCH_BASES, submit_batch, &sc);
     if (prc == 2) die("Irregular %s record in %s (multi-line FASTQ?): rerun with -t 1", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
     if (prc == 1) {
       seq_in *in = seq_in_open(bt->path);
