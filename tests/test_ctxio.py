@@ -412,3 +412,37 @@ def test_sort_and_index_commands(mcx, orc, tmp_path):
     assert rc == 0 and out.decode() == _index_expected(want, 100)
     rc, _, err = run(31, "index", "-s", "1800", "-b", "100", s1)
     assert rc == 1 and "Cannot use --block-kmers and --block-size together" in err
+
+
+@pytest.mark.gpu
+def test_reference_build0_command_lines(mcx, orc, tmp_path):
+    """The reference's own integration test tests/build/build0/Makefile: 60 random bases, k=21,
+    `build --sample Wallace --sample Gromit --seq seq.fa --sample Trousers --seq seq.fa --seq2
+    seq.fa:seq.fa`, then `sort` in place on a copy and `index` (its later steps -- view, check,
+    contigs, rmsubstr -- are other commands).  Expected bytes come from the oracle."""
+    k = 21
+    rng = np.random.default_rng(60)
+    seq = bytes(rng.choice(list(b"ACGT"), 60).astype(np.uint8))
+    fa = tmp_path / "seq.fa"
+    fa.write_bytes(b">seq\n" + seq + b"\n")
+    out = str(tmp_path / "seq.k21.ctx")
+    rc, _, err = run(31, "build", "-q", "-m", "1M", "-k", str(k), "--sample", "Wallace", "--sample", "Gromit", "--seq", str(fa),
+                     "--sample", "Trousers", "--seq", str(fa), "--seq2", str(fa) + ":" + str(fa), out)
+    assert rc == 0, err
+    b, o = orc.pack_reads([seq.decode()])
+    og, gi = _reads_graph(orc, k, 3, [(1, b, o), (2, b, o), (2, b, o), (2, b, o)], ["Wallace", "Gromit", "Trousers"])
+    want_sorted = ctxio.header_bytes(k, gi) + og.body_bytes(True)
+    got = open(out, "rb").read()
+    hdr, hs = ctxio.read_header(got)
+    assert got[:hs] == want_sorted[:hs] and hdr["num_cols"] == 3
+    keys, covgs, edges = ctxio.records(got, hdr, hs)
+    assert len(keys) == 40 and (covgs[:, 0] == 0).all() and (covgs[:, 1] == 1).all() and (covgs[:, 2] == 3).all()
+    assert (edges[:, 0] == 0).all() and (edges[:, 1] == edges[:, 2]).all()
+    srt = str(tmp_path / "sort.k21.ctx")
+    open(srt, "wb").write(got)
+    rc, _, err = run(31, "sort", "-q", srt)
+    assert rc == 0, err
+    assert open(srt, "rb").read() == want_sorted
+    rc, outb, err = run(31, "index", "-q", srt)
+    assert rc == 0 and outb.decode() == _index_expected(want_sorted, (4 << 20) // (8 + 15))
+    assert len(outb.decode().splitlines()) == 2      # header line + one block
