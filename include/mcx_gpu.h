@@ -86,6 +86,13 @@ int mcx_graph_reset(mcx_graph *g);
  *   "defer_tuples" occurrences buffered per flush (sizes the bin workspace in HBM)
  *   "flush_regions" table regions split + applied per step of a flush (0 = automatic: 16 K sub-tables
  *                  per step); bounds the sub-table bin workspace to that share of the table
+ *   "intersect"    1: `build --intersect` (ctx_build.c:341-363,384-413).  The graph must have been
+ *                  created with ONE colour more than the output: the last colour becomes hidden (not
+ *                  exported, not scanned) and holds the union of the intersection graphs' edges,
+ *                  loaded with mcx_graph_add_records(... into = that colour).  Implies "defer" 0.
+ *   "must_exist"   1: mcx_graph_add_reads only updates k-mers that are already in the graph and adds
+ *                  an edge only between consecutive k-mers that were both found
+ *                  (BuildGraphTask.prefs.must_exist_in_graph, src/tools/build_graph.c:99-150)
  *   "profile"      1: time every kernel launch with HIP events (see mcx_graph_profile) */
 int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value);
 /* "kernel calls total_ms" per line for the launches recorded since "profile" was set. */
@@ -180,14 +187,21 @@ uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_words);
  * object) of the first record with zero coverage in every file colour / with edges but no coverage
  * in some colour (the reference warns once for each), or -1; an oversized k-mer fails the call
  * with MCX_ERR_ARG (the reference dies).  Synchronous. */
-enum { MCX_RECORDS_MUST_EXIST = 1 };
+enum { MCX_RECORDS_MUST_EXIST = 1, MCX_RECORDS_MASK_EDGES = 2 };
 typedef struct {
   uint64_t nkmers_read, nkmers_loaded, nkmers_novel;
   int64_t first_oversized, first_zero_covg, first_edges_no_covg; /* initialise to -1 */
 } mcx_records_stats;
+/* MCX_RECORDS_MASK_EDGES (intersect mode): only OR in edges that the hidden colour has for that
+ * k-mer (GraphLoadingPrefs.must_exist_in_edges, graphs_load.c:166-167). */
 int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nrecs, int file_ncols,
                           const int32_t *from_col, const int32_t *into_col, int nmap, uint32_t flags,
                           mcx_records_stats *stats_accum);
+
+/* End of an intersect build: remove k-mers with no coverage in any visible colour and AND every
+ * colour's edges with the intersection graphs' edges (db_graph_remove_no_covg_kmers +
+ * db_graph_intersect_edges, src/graph/db_graph.c:630-673).  *removed = k-mers dropped. */
+int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed);
 
 /* Table scans (imply a sync).
  * mcx_graph_kmer_covg       db_graph_get_kmer_covg (src/graph/db_graph.c:490-534): per colour, the

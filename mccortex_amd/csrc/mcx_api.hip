@@ -84,6 +84,10 @@ struct mcx_graph {
   uint32_t l2_regions = 0;      // regions the L2 (sub-table) bins cover: a flush splits and applies
                                 // the L1 bins in groups of this many regions, reusing the same bins
   uint32_t flush_regions = 0;   // configured group size (0 = automatic)
+  // ---- build --intersect (ctx_build.c:341-363,384-413) ----
+  int hidden = -1;              // colour that holds the intersection graphs' edges, or -1
+  int ncols_vis = 0;            // colours that are exported / scanned (ncols, or ncols - 1)
+  bool must_exist = false;      // reads only update k-mers already in the graph
   int pending_colour = 0;
   // ---- optional per-kernel timing (mcx_graph_configure("profile", 1)) ----
   bool profile = false;
@@ -148,6 +152,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   g->k = kmer_size;
   g->W = words_for_k(kmer_size);
   g->ncols = ncols;
+  g->ncols_vis = ncols;
   g->device = device;
   // geometry of the quotient-hashed table: 2^lb1 regions x spb sub-tables x 4096 (W=2: 2048) slots
   const uint64_t sub_slots = 1ull << sub_shift_for_words(g->W);
@@ -563,6 +568,22 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     if (g->l1_keys) return ensure_l2(g, flush_group(g));
     return MCX_OK;
   }
+  if (!strcmp(key, "intersect")) {  // the last colour becomes the hidden holder of the intersection edges
+    if (!value) return fail(MCX_ERR_ARG, "intersect mode cannot be switched off");
+    if (g->ncols < 2) return fail(MCX_ERR_ARG, "intersect mode needs one colour more than the output has");
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->hidden = g->ncols - 1;
+    g->ncols_vis = g->ncols - 1;
+    g->defer = false;  // every update goes straight to the table
+    return MCX_OK;
+  }
+  if (!strcmp(key, "must_exist")) {
+    int rc = flush_deferred(g);
+    if (rc != MCX_OK) return rc;
+    g->must_exist = value != 0;
+    if (g->must_exist) g->defer = false;
+    return MCX_OK;
+  }
   if (!strcmp(key, "profile")) {
     HIP_TRY(hipStreamSynchronize(g->stream));
     for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -801,6 +822,8 @@ static int ensure_stage(mcx_graph *g)
 
 static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
                         const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp);
+static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
+                                const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp);
 
 extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
                                    const uint64_t *off, uint64_t nreads, uint8_t fq_cutoff_abs,
@@ -815,6 +838,8 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
     stats_accum->total_bases_read += nreads ? off[nreads] - off[0] : 0;
   }
   if (!nreads) return MCX_OK;
+  if (colour >= g->ncols_vis) return fail(MCX_ERR_ARG, "colour %d is the intersection colour", colour);
+  if (g->must_exist) return add_reads_must_exist(g, colour, bases, quals, off, nreads, fq_cutoff_abs, hp_cutoff);
   if ((fq_cutoff_abs > 0 && quals) || hp_cutoff > 0)
     return add_reads_qh(g, colour, bases, quals, off, nreads, fq_cutoff_abs, hp_cutoff);
 
@@ -913,6 +938,62 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
   hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, g->stream, (const unsigned char *)d_flags, nreads, g->d_ctr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipFreeAsync(d_flags, g->stream));
+  return MCX_OK;
+}
+
+// build --intersect: reads are uploaded whole (bases, qualities, offsets) and one lane per read
+// restates the reference's must-exist loading loop (k_reads_must_exist)
+static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
+                                const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp)
+{
+  const uint64_t base0 = off[0], nb = off[nreads] - off[0];
+  uint8_t *d_bases = nullptr, *d_quals = nullptr;
+  uint64_t *d_off = nullptr;
+  std::vector<uint64_t> rel(nreads + 1);
+  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
+  auto cleanup = [&]() { (void)hipFree(d_bases); (void)hipFree(d_quals); (void)hipFree(d_off); };
+  if (hipMalloc((void **)&d_bases, nb + 16) != hipSuccess || hipMalloc((void **)&d_off, (nreads + 1) * 8) != hipSuccess ||
+      (quals && fq > 0 && hipMalloc((void **)&d_quals, nb + 16) != hipSuccess)) {
+    cleanup();
+    (void)hipGetLastError();
+    return fail(MCX_ERR_NOMEM, "out of device memory for a read batch");
+  }
+  HIP_TRY(hipMemcpyAsync(d_bases, bases + base0, nb, hipMemcpyHostToDevice, g->stream));
+  if (d_quals) HIP_TRY(hipMemcpyAsync(d_quals, quals + base0, nb, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(hipMemcpyAsync(d_off, rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
+  const unsigned blocks = (unsigned)((nreads + 127) / 128);
+  {
+    SpanGuard sp(g, "k_reads_must_exist");
+    if (g->W == 1)
+      hipLaunchKernelGGL((k_reads_must_exist<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
+                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr);
+    else
+      hipLaunchKernelGGL((k_reads_must_exist<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
+                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  cleanup();
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (g->hidden < 0) return fail(MCX_ERR_ARG, "the graph is not in intersect mode");
+  HIP_TRY(hipSetDevice(g->device));
+  int rc = flush_deferred(g);
+  if (rc != MCX_OK) return rc;
+  unsigned long long *d_removed = nullptr, h_removed = 0;
+  HIP_TRY(hipMalloc((void **)&d_removed, 8));
+  HIP_TRY(hipMemsetAsync(d_removed, 0, 8, g->stream));
+  hipLaunchKernelGGL(k_intersect_finish, dim3(g->grid), dim3(256), 0, g->stream, g->t, (uint32_t)g->ncols_vis, (uint32_t)g->hidden,
+                     g->d_ctr, d_removed);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(&h_removed, d_removed, 8, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  (void)hipFree(d_removed);
+  if (removed) *removed = h_removed;
   return MCX_OK;
 }
 
@@ -1025,6 +1106,7 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
       return fail(MCX_ERR_ARG, "filter entry %d loads into colour %d of a %d colour graph", m, into_col[m], g->ncols);
   }
   if (nrecs && !recs) return fail(MCX_ERR_ARG, "null records");
+  if ((flags & MCX_RECORDS_MASK_EDGES) && g->hidden < 0) return fail(MCX_ERR_ARG, "edge masking needs intersect mode");
   HIP_TRY(hipSetDevice(g->device));
   int rc = ensure_stage(g);
   if (rc != MCX_OK) return rc;
@@ -1050,10 +1132,10 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
     SpanGuard sp(g, "k_load_records");
     if (g->W == 1)
       hipLaunchKernelGGL((k_load_records<1>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, g->k, g->d_ctr, d_st);
+                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st);
     else
       hipLaunchKernelGGL((k_load_records<2>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, g->k, g->d_ctr, d_st);
+                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->ev[cur], g->stream));
   }
@@ -1154,7 +1236,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   export_clock("sorted");
   // records are produced and copied to pinned memory in 64 MiB chunks, double buffered: while the
   // sink consumes chunk i on the host, the device emits and copies chunk i + 1
-  const uint32_t recsz = 8u * W + 5u * (uint32_t)g->ncols;
+  const uint32_t recsz = 8u * W + 5u * (uint32_t)g->ncols_vis;
   const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz);
   hipEvent_t done[2] = {nullptr, nullptr};
   uint8_t *d_rec2[2] = {nullptr, nullptr}, *h_rec2[2] = {nullptr, nullptr};
@@ -1174,7 +1256,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   auto produce = [&](uint64_t first, int b) -> hipError_t {
     const uint64_t cnt = std::min(chunk, n - first);
     hipLaunchKernelGGL((k_emit_records<W>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g->t,
-                       (const uint64_t *)d_slot, (const uint64_t *)perm, first, cnt, (uint32_t)g->ncols, d_rec2[b]);
+                       (const uint64_t *)d_slot, (const uint64_t *)perm, first, cnt, (uint32_t)g->ncols_vis, d_rec2[b]);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(h_rec2[b], d_rec2[b], cnt * recsz, hipMemcpyDeviceToHost, st);
@@ -1213,7 +1295,7 @@ static int covg_scan(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov, uint64_t 
   HIP_TRY(hipSetDevice(g->device));
   int rc = flush_deferred(g);
   if (rc != MCX_OK) return rc;
-  const uint32_t nc = (uint32_t)g->ncols;
+  const uint32_t nc = (uint32_t)g->ncols_vis;
   const uint32_t lbins = hist ? std::min<uint32_t>(nbins, 4096u) : 0;
   unsigned long long *d_out = nullptr, *d_hist = nullptr;
   HIP_TRY(hipMalloc((void **)&d_out, 2 * nc * 8));

@@ -306,7 +306,7 @@ __device__ __forceinline__ uint32_t load_le32(const uint8_t *p)
 template <int W>
 __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t *recs, uint64_t nrecs, uint64_t rec0,
                                                       uint32_t file_ncols, const int32_t *from, const int32_t *into,
-                                                      uint32_t nmap, uint32_t must_exist, int kmer_size,
+                                                      uint32_t nmap, uint32_t must_exist, int mask_col, int kmer_size,
                                                       Counters *ctr, RecordStats *st)
 {
   const uint32_t rec_bytes = 8u * W + 5u * file_ncols;
@@ -332,9 +332,11 @@ __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t
     if (!any_loaded) continue;
     const uint64_t slot = find_or_insert_rec<W>(t, key, must_exist != 0, novel, full);
     if (slot == kNoSlot) continue;
+    // must_exist_in_edges (graphs_load.c:166-167): only edges the intersection graph has
+    const uint32_t emask = mask_col >= 0 ? (uint32_t)(*val_ptr(t, slot, (uint32_t)mask_col) & 0xffULL) : 0xffu;
     for (uint32_t m = 0; m < nmap; m++) {
       const uint32_t cv = load_le32(pc + 4 * from[m]);
-      const uint32_t e = pe[from[m]];
+      const uint32_t e = pe[from[m]] & emask;
       uint64_t *val = val_ptr(t, slot, (uint32_t)into[m]);
       if (cv) __hip_atomic_fetch_add(val, (uint64_t)cv << 8, MCX_RLX, MCX_AGENT);
       if (e) __hip_atomic_fetch_or(val, (uint64_t)e, MCX_RLX, MCX_AGENT);
@@ -797,6 +799,83 @@ __global__ void k_qh_contigs(const uint8_t *bases, const uint8_t *quals, const u
     w += ce - cs + 1;
   }
   if (!pass) out_sizes[r] = w;
+}
+
+// ---------------------------------------------------------------------------
+// build --intersect: reads only update k-mers that are already in the graph
+// ---------------------------------------------------------------------------
+// One lane per read walks it exactly as load_read + build_graph_from_str_mt do with
+// must_exist_in_graph (src/tools/build_graph.c:99-150,154-189): every k-mer of every contig is
+// looked up; a found k-mer gets coverage +1; an edge is added between consecutive k-mers only
+// when BOTH were found.  Not a fast path (intersection builds are small and rare): clarity first.
+template <int W>
+__global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                                   uint64_t nreads, int k, uint32_t qcut, uint32_t hcut, uint32_t col, Counters *ctr)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  const uint8_t *seq = bases + off[r];
+  const uint8_t *qual = (quals && qcut > 0) ? quals + off[r] : nullptr;
+  const uint64_t len = off[r + 1] - off[r];
+  const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
+  const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);
+  unsigned long long n_kmers = 0, n_contigs = 0;
+  uint32_t dummy_novel = 0, full = 0;
+  uint64_t cs, ce, search = 0;
+  while ((cs = qh_contig_start(seq, len, qual, search, (uint64_t)k, qcut, hcut)) < len) {
+    ce = qh_contig_end(seq, len, qual, cs, (uint64_t)k, qcut, hcut, &search);
+    Kmer<W> fw;
+    fw.w[0] = 0; if (W == 2) fw.w[W - 1] = 0;
+    uint64_t prev_slot = kNoSlot;
+    uint32_t prev_o = 0, prev_first = 0;
+    for (uint64_t i = cs; i < ce; i++) {
+      const uint32_t nuc = ((seq[i] >> 1) ^ (seq[i] >> 2)) & 3u;  // A C G T (either case) -> 0 1 2 3
+      if (W == 1) fw.w[0] = ((fw.w[0] << 2) | nuc) & top_mask;
+      else { fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask; fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc; }
+      if (i + 1 < cs + (uint64_t)k) continue;  // first k - 1 bases
+      const Kmer<W> rc = revcomp<W>(fw, k);
+      uint32_t o;
+      const Kmer<W> key = canonical<W>(fw, rc, o);
+      const uint64_t slot = find_or_insert_rec<W>(t, key, true, dummy_novel, full);
+      const uint32_t first = (uint32_t)(fw.w[0] >> first_shift) & 3u;  // first base of this k-mer, read strand
+      if (slot != kNoSlot) {
+        __hip_atomic_fetch_add(val_ptr(t, slot, col), 256ULL, MCX_RLX, MCX_AGENT);
+        if (prev_slot != kNoSlot) {  // db_graph_add_edge_mt(prev, curr): db_graph.c:152-166
+          __hip_atomic_fetch_or(val_ptr(t, prev_slot, col), (uint64_t)(1u << (nuc + 4u * prev_o)), MCX_RLX, MCX_AGENT);
+          __hip_atomic_fetch_or(val_ptr(t, slot, col), (uint64_t)(1u << ((3u - prev_first) + 4u * (1u - o))), MCX_RLX, MCX_AGENT);
+        }
+      }
+      prev_slot = slot; prev_o = o; prev_first = first;
+      n_kmers++;
+    }
+    n_contigs++;
+  }
+  if (n_kmers) atomicAdd(&ctr->kmers, n_kmers);
+  if (n_contigs) atomicAdd(&ctr->contigs, n_contigs);
+  atomicAdd(n_contigs ? &ctr->good_reads : &ctr->bad_reads, 1ULL);
+}
+
+// db_graph_remove_no_covg_kmers + db_graph_intersect_edges (src/graph/db_graph.c:630-673): drop
+// k-mers without coverage in any visible colour (the slot becomes a tombstone: non-zero, flag
+// clear) and AND every colour's edges with the intersection graph's edges, kept in colour `hidden`
+__global__ __launch_bounds__(256) void k_intersect_finish(TableView t, uint32_t ncols_vis, uint32_t hidden, Counters *ctr,
+                                                          unsigned long long *removed)
+{
+  unsigned long long gone = 0;
+  for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < t.nslots; slot += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t *r = key_ptr(t, slot);
+    if (!(r[0] & kFlag)) continue;
+    const uint64_t mask = *val_ptr(t, slot, hidden) & 0xffULL;
+    uint64_t any = 0;
+    for (uint32_t c = 0; c < ncols_vis; c++) {
+      uint64_t *v = val_ptr(t, slot, c);
+      const uint64_t x = *v;
+      any |= x >> 8;
+      *v = (x & ~0xffULL) | (x & mask);
+    }
+    if (!any) { r[0] = kPending; gone++; }
+  }
+  if (gone) { atomicAdd(removed, gone); atomicAdd(&ctr->novel, 0ULL - gone); }
 }
 
 // ---------------------------------------------------------------------------

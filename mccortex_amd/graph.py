@@ -14,7 +14,7 @@ SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
     "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_kmer_covg", "mcx_graph_covg_histogram", "mcx_sort_records",
-    "mcx_records_sorted", "mcx_graph_destroy",
+    "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
@@ -85,6 +85,7 @@ def lib():
     L.mcx_graph_covg_histogram.argtypes = [vp, u64p, C.c_uint32]
     L.mcx_sort_records.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int]
     L.mcx_records_sorted.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    L.mcx_graph_intersect_finish.argtypes = [vp, u64p]
     L.mcx_graph_key_owner.restype = C.c_uint32
     L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
@@ -218,7 +219,12 @@ class Graph:
                                           len(offsets) - 1, fq_cutoff, hp_cutoff, C.byref(st)))
         return st
 
-    def add_records(self, recs, file_ncols, colour_filter, must_exist=False, stats=None):
+    def intersect_finish(self):
+        n = C.c_uint64(0)
+        _check(self.L.mcx_graph_intersect_finish(self.h, C.byref(n)))
+        return int(n.value)
+
+    def add_records(self, recs, file_ncols, colour_filter, must_exist=False, stats=None, mask_edges=False):
         """recs: .ctx body bytes (W x u64 key, file_ncols x u32 coverage, file_ncols x u8 edges per
         record); colour_filter: [(from file colour, into graph colour)]"""
         recs = np.frombuffer(recs, dtype=np.uint8) if isinstance(recs, (bytes, bytearray, memoryview)) else np.ascontiguousarray(recs, dtype=np.uint8)
@@ -228,7 +234,7 @@ class Graph:
         into = np.array([t for _, t in colour_filter], dtype=np.int32)
         st = stats if stats is not None else RecordStats()
         _check(self.L.mcx_graph_add_records(self.h, _ptr(recs), recs.size // rs, file_ncols, _ptr(frm), _ptr(into),
-                                            len(frm), RECORDS_MUST_EXIST if must_exist else 0, C.byref(st)))
+                                            len(frm), (RECORDS_MUST_EXIST if must_exist else 0) | (2 if mask_edges else 0), C.byref(st)))
         return st
 
     def kmer_covg(self):

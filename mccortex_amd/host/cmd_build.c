@@ -56,8 +56,8 @@ static const char build_usage[] =
 "  Note: Argument must come before input file\n"
 "  --sample <name> is required before sequence input can be loaded.\n"
 "  Consecutive sequence options are loaded into the same colour.\n"
-"  This build runs the graph construction on an MI355X: --remove-pcr, --intersect\n"
-"  and SAM/BAM/CRAM input are not available; -m/-n size the table in HBM.\n"
+"  This build runs the graph construction on an MI355X: --remove-pcr and SAM/BAM/CRAM\n"
+"  input are not available; -m/-n size the table in HBM.\n"
 "\n";
 
 static struct option longopts[] = {
@@ -88,6 +88,8 @@ static int *sample_cols = NULL;   /* SampleName.colour: ctx_build.c:83-86,159-16
 static size_t nsamples = 0;
 static ctx_reader *gfiles = NULL; /* --graph inputs, in command-line order (gfilebuf) */
 static size_t ngfiles = 0;
+static ctx_reader *gisec = NULL;  /* --intersect inputs (gisecbuf) */
+static size_t ngisec = 0;
 
 #define usage_die(...) print_usage(build_usage, __VA_ARGS__)
 
@@ -230,7 +232,9 @@ static void filter_status(const ctx_reader *r)
 
 /* graph_load (graphs_load.c:86-214) with the hash table on the GPU: merge the header's GraphInfo
  * into the colours it loads into, then stream the records through mcx_graph_add_records */
-static void load_graph_file(mcx_graph *g, ctx_reader *r, col_info *cols, size_t ncols)
+/* isec_col >= 0: the file is an intersection graph, every colour of it goes to that (hidden) colour
+ * and its header is not merged (ctx_build.c:347-363); rec_flags: MCX_RECORDS_* */
+static void load_graph_file(mcx_graph *g, ctx_reader *r, col_info *cols, size_t ncols, int isec_col, uint32_t rec_flags)
 {
   char a[64], b[64];
   filter_status(r);
@@ -240,14 +244,18 @@ static void load_graph_file(mcx_graph *g, ctx_reader *r, col_info *cols, size_t 
   /* graph_load_ginfo: graphs_load.c:48-77 */
   if (r->into_ncols > ncols)
     die("Program has not assigned enough colours! [colours in graph: %zu vs file: %zu; path: %s]", ncols, r->into_ncols, r->path);
-  for (size_t i = 0; i < r->nfilter; i++) col_info_merge(&cols[r->filter[i].into], &r->ginfo[r->filter[i].from]);
+  if (isec_col < 0)
+    for (size_t i = 0; i < r->nfilter; i++) col_info_merge(&cols[r->filter[i].into], &r->ginfo[r->filter[i].from]);
 
   const size_t rec_bytes = 8 * (size_t)r->num_words + 5 * (size_t)r->num_cols;
   const size_t chunk_recs = (64u << 20) / rec_bytes;
   unsigned char *buf = malloc(chunk_recs * rec_bytes);
   int32_t *from = malloc(r->nfilter * sizeof(int32_t)), *into = malloc(r->nfilter * sizeof(int32_t));
   if (!buf || !from || !into) die("Out of memory");
-  for (size_t i = 0; i < r->nfilter; i++) { from[i] = (int32_t)r->filter[i].from; into[i] = (int32_t)r->filter[i].into; }
+  for (size_t i = 0; i < r->nfilter; i++) {
+    from[i] = (int32_t)r->filter[i].from;
+    into[i] = isec_col >= 0 ? isec_col : (int32_t)r->filter[i].into;
+  }
   mcx_records_stats st = {0, 0, 0, -1, -1, -1};
   bool warned_zero = false, warned_edges = false;
   for (;;) {
@@ -258,7 +266,7 @@ static void load_graph_file(mcx_graph *g, ctx_reader *r, col_info *cols, size_t 
       die("Unexpected end of file: %s", r->path);
     }
     const uint64_t base = st.nkmers_read;
-    int rc = mcx_graph_add_records(g, buf, got / rec_bytes, (int)r->num_cols, from, into, (int)r->nfilter, 0, &st);
+    int rc = mcx_graph_add_records(g, buf, got / rec_bytes, (int)r->num_cols, from, into, (int)r->nfilter, rec_flags, &st);
     if (rc != MCX_OK && st.first_oversized >= 0) die("Oversized kmer in path [kmer: %u]: %s", r->kmer_size, r->path);
     mcx_check(rc, "load graph records");
     if (st.first_zero_covg >= 0 && !warned_zero) {
@@ -364,7 +372,14 @@ int ctx_build(int argc, char **argv)
         if ((int)gfiles[ngfiles].into_ncols - 1 > intocolour) intocolour = (int)gfiles[ngfiles].into_ncols - 1;
         ngfiles++;
         sample_named = false; break;
-      case 'I': die("--intersect is not available in this build (SURVEY.md 8f)");
+      case 'I': /* ctx_build.c:197-203 */
+        gisec = realloc(gisec, (ngisec + 1) * sizeof(ctx_reader));
+        ctx_reader_open(&gisec[ngisec], optarg, 0, MIN_KMER_SIZE, MAX_KMER_SIZE);
+        if (gisec[ngisec].into_ncols > 1) warn("Flattening intersection graph into colour 0: %s", optarg);
+        for (size_t i = 0; i < gisec[ngisec].nfilter; i++) gisec[ngisec].filter[i].into = 0; /* file_filter_flatten */
+        gisec[ngisec].into_ncols = 1;
+        ngisec++;
+        break;
       case 'D': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int x >= 0: %s", cmd, optarg);
         device = (int)u; break;
       case ':': case '?':
@@ -414,10 +429,15 @@ int ctx_build(int argc, char **argv)
     }
   }
   if (size_unknown) max_kmers = SIZE_MAX;
+  if (ngisec > 0) { /* ctx_build.c:291-303: reads and graphs can only touch k-mers of the intersection */
+    if (remove_pcr) usage_die("Cannot use --remove-pcr and --intersect");
+    max_kmers = 0;
+    for (size_t i = 0; i < ngisec; i++) max_kmers += (size_t)gisec[i].num_kmers;
+  }
 
   /* ---- decide on memory (ctx_build.c:305-322, cmd_mem.c:38-130) ---- */
   const size_t W = (2 * kmer_size + 63) / 64;
-  size_t bits_per_kmer = W * 64 + (4 + 1) * 8 * ncols + (sort_kmers ? 64 : 0);
+  size_t bits_per_kmer = W * 64 + (4 + 1) * 8 * ncols + (ngisec > 0 ? 8 : 0) + (sort_kmers ? 64 : 0);
   uint64_t kmers_in_hash = 0;
   size_t graph_mem = 0;
   char s1[64], s2[64];
@@ -442,7 +462,8 @@ int ctx_build(int argc, char **argv)
   stage_time("HIP runtime up");
   uint64_t hbm_free = 0, hbm_total = 0;
   mcx_check(mcx_device_memory(device, &hbm_free, &hbm_total), "device query");
-  const uint64_t dev_bytes = kmers_in_hash * 8 * (W + ncols);
+  const size_t dev_cols = ncols + (ngisec > 0 ? 1 : 0); /* + the hidden colour of the intersection edges */
+  const uint64_t dev_bytes = kmers_in_hash * 8 * (W + dev_cols);
   if (dev_bytes > hbm_free)
     die("Requesting more memory than is available [ Reqeusted: %s HBM free: %s ]",
         bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_free, 1, s2));
@@ -458,7 +479,8 @@ int ctx_build(int argc, char **argv)
   status("Writing %zu colour graph to %s\n", ncols, strcmp(out_path, "-") ? out_path : "STDOUT");
 
   mcx_graph *g = NULL;
-  mcx_check(mcx_graph_create(&g, (int)kmer_size, (int)ncols, kmers_in_hash, device), "Cannot allocate graph");
+  mcx_check(mcx_graph_create(&g, (int)kmer_size, (int)dev_cols, kmers_in_hash, device), "Cannot allocate graph");
+  if (ngisec > 0) mcx_check(mcx_graph_configure(g, "intersect", 1), "intersect mode");
   uint64_t slots = 0, tbytes = 0;
   mcx_graph_capacity(g, &slots, &tbytes);
   status("[hasht] Allocated table in HBM with %s entries, using %s", ulong_to_str(slots, s1), bytes_to_str(tbytes, 1, s2));
@@ -468,14 +490,21 @@ int ctx_build(int argc, char **argv)
   for (size_t i = 0; i < ncols; i++) col_info_init(&cols[i]);
 
   /* ---- load graphs (graph_load: graphs_load.c:86-214), then name the samples (ctx_build.c:365-382) ---- */
+  for (size_t i = 0; i < ngisec; i++) { /* intersection graphs: keys + their edges (ctx_build.c:347-363) */
+    if (gisec[i].kmer_size != kmer_size)
+      die("Graph has different kmer size [kmer_size: %u vs %zu; path: %s]", gisec[i].kmer_size, kmer_size, gisec[i].path);
+    load_graph_file(g, &gisec[i], cols, ncols, (int)ncols, 0);
+    ctx_reader_close(&gisec[i]);
+  }
   for (size_t i = 0; i < ngfiles; i++) {
-    load_graph_file(g, &gfiles[i], cols, ncols);
+    load_graph_file(g, &gfiles[i], cols, ncols, -1, ngisec > 0 ? (MCX_RECORDS_MUST_EXIST | MCX_RECORDS_MASK_EDGES) : 0);
     uint64_t nk0 = 0;
     mcx_check(mcx_graph_nkmers(g, &nk0), "nkmers");
     status("[hash] occupancy: %s / %s (%.2f%%)", ulong_to_str(nk0, s1), ulong_to_str(slots, s2), 100.0 * (double)nk0 / (double)slots);
     ctx_reader_close(&gfiles[i]);
   }
   for (size_t i = 0; i < nsamples; i++) col_info_set_name(&cols[sample_cols[i]], sample_names[i]);
+  if (ngisec > 0) mcx_check(mcx_graph_configure(g, "must_exist", 1), "must-exist mode"); /* ctx_build.c:297-298 */
 
   /* ---- load every input in task order (build_graph(): build_graph.c:257-300) ---- */
   read_batch batch;
@@ -513,6 +542,10 @@ int ctx_build(int argc, char **argv)
     bt->stats.num_kmers_novel = cur.num_kmers_novel - prev.num_kmers_novel;
     prev = cur;
     col_info_update(&cols[bt->colour], bt->stats.total_bases_loaded, bt->stats.contigs_parsed);
+  }
+  if (ngisec > 0) { /* ctx_build.c:409-413 */
+    uint64_t removed = 0;
+    mcx_check(mcx_graph_intersect_finish(g, &removed), "intersect");
   }
   stage_time("inputs submitted");
   if (getenv("MCX_TIMING")) fprintf(stderr, "[timing] %8.1f ms  inside mcx_graph_add_reads (%lu calls)\n", submit_ms, submit_calls);
@@ -556,6 +589,6 @@ int ctx_build(int argc, char **argv)
   stage_time("device released");
   for (size_t t = 0; t < ntasks; t++) free(tasks[t].path);
   for (size_t i = 0; i < ncols; i++) col_info_free(&cols[i]);
-  free(tasks); free(cols); free(sample_names); free(sample_cols); free(gfiles);
+  free(tasks); free(cols); free(sample_names); free(sample_cols); free(gfiles); free(gisec);
   return EXIT_SUCCESS;
 }

@@ -256,6 +256,9 @@ struct orc_graph {
   char (*sample)[256];
   volatile int full;
   int force_generic; /* tests: run the multi-word code even when W == 1 */
+  /* build --intersect (ctx_build.c:341-363,384-413) */
+  uint8_t *isec_edges;  /* [capacity]: union of the intersection graphs' edges, NULL when not intersecting */
+  int must_exist;       /* BuildGraphTask.prefs.must_exist_in_graph */
 };
 
 orc_graph *orc_graph_new(int k, int ncols, uint64_t capacity_kmers, uint32_t seed)
@@ -284,7 +287,7 @@ void orc_graph_free(orc_graph *g)
 {
   if(!g) return;
   free(g->table); free(g->bsize); free((void *)g->locks); free(g->covgs); free(g->edges);
-  free(g->mean_read_length); free(g->total_sequence); free(g->sample);
+  free(g->mean_read_length); free(g->total_sequence); free(g->sample); free(g->isec_edges);
   free(g);
 }
 
@@ -341,6 +344,25 @@ static uint64_t find_or_insert(orc_graph *g, const orc_bkmer *key, int *found)
   return ORC_NOT_FOUND;
 }
 
+/* hash_table_find: hash_table.c:125-154 (a bucket that is not full ends the search) */
+static uint64_t find_only(const orc_graph *g, const orc_bkmer *key)
+{
+  const int W = g->W;
+  int i, w;
+  for(i = 0; i < ORC_REHASH_LIMIT; i++) {
+    uint64_t h = orc_kmer_hash(*key, g->k, g->seed + (uint32_t)i) & g->hash_mask;
+    const uint64_t *slot = g->table + h * g->bucket_size * (uint64_t)W;
+    unsigned n = g->bsize[h], j;
+    for(j = 0; j < n; j++, slot += W) {
+      if(slot[0] != (key->b[0] | ORC_FLAG)) continue;
+      for(w = 1; w < W && slot[w] == key->b[w]; w++) {}
+      if(w == W) return h * g->bucket_size + j;
+    }
+    if(n < g->bucket_size) break;
+  }
+  return ORC_NOT_FOUND;
+}
+
 /* db_node.c:139-144: saturating thread-safe +1 */
 static inline void covg_inc(uint32_t *p)
 {
@@ -355,7 +377,12 @@ static inline orc_node find_or_add_node(orc_graph *g, const orc_bkmer *bk, int c
 {
   orc_bkmer key = orc_kmer_get_key(*bk, g->k);
   orc_node n;
-  n.hkey = find_or_insert(g, &key, found);
+  if(g->must_exist) { /* _find_or_insert with must_exist_in_graph: build_graph.c:99-117 */
+    n.hkey = find_only(g, &key);
+    *found = n.hkey != ORC_NOT_FOUND;
+  } else {
+    n.hkey = find_or_insert(g, &key, found);
+  }
   n.orient = bkmer_eq(&key, bk, g->W) ? 0 : 1; /* db_node.h:109-110 */
   if(n.hkey != ORC_NOT_FOUND) covg_inc(&g->covgs[n.hkey * (uint64_t)g->ncols + (uint64_t)colour]);
   return n;
@@ -457,19 +484,20 @@ static size_t build_from_str_w1(orc_graph *g, int colour, const char *seq, size_
 /* build_graph.c:122-150 */
 static size_t build_from_str(orc_graph *g, int colour, const char *seq, size_t len)
 {
-  if(g->W == 1 && !g->force_generic) return build_from_str_w1(g, colour, seq, len);
+  if(g->W == 1 && !g->force_generic && !g->must_exist) return build_from_str_w1(g, colour, seq, len);
   const int k = g->k;
   size_t i, nonnovel = 0;
   int found = 0;
   orc_bkmer bk = orc_kmer_from_str(seq, k);
   orc_node prev = find_or_add_node(g, &bk, colour, &found), curr;
-  if(prev.hkey == ORC_NOT_FOUND) { g->full = 1; return 0; }
+  if(prev.hkey == ORC_NOT_FOUND && !g->must_exist) { g->full = 1; return 0; }
   nonnovel += (size_t)found;
   for(i = (size_t)k; i < len; i++, prev = curr) {
     bk = orc_kmer_shift_add(bk, k, orc_char_to_nuc((unsigned char)seq[i]));
     curr = find_or_add_node(g, &bk, colour, &found);
-    if(curr.hkey == ORC_NOT_FOUND) { g->full = 1; return nonnovel; }
-    add_edge(g, colour, prev, curr);
+    if(curr.hkey == ORC_NOT_FOUND && !g->must_exist) { g->full = 1; return nonnovel; }
+    if(prev.hkey != ORC_NOT_FOUND && curr.hkey != ORC_NOT_FOUND) /* build_graph.c:143-144 */
+      add_edge(g, colour, prev, curr);
     nonnovel += (size_t)found;
   }
   return nonnovel;
@@ -610,18 +638,11 @@ int orc_graph_add_record(orc_graph *g, const uint64_t *key_words, const uint32_t
   memset(&key, 0, sizeof(key));
   for(c = 0; c < g->W; c++) key.b[c] = key_words[c];
   uint64_t hkey;
+  uint8_t edge_mask = 0xff;
   if(must_exist) {
-    /* hash_table_find: probe the same bucket sequence without inserting */
-    const uint64_t before = g->num_kmers;
-    hkey = find_or_insert(g, &key, &found);
+    hkey = find_only(g, &key);
     if(hkey == ORC_NOT_FOUND) return 0;
-    if(!found) { /* undo: the restatement has no find-only entry; the slot was appended last in its bucket */
-      uint64_t h = hkey / g->bucket_size;
-      memset(g->table + hkey * (uint64_t)g->W, 0, sizeof(uint64_t) * (size_t)g->W);
-      g->bsize[h]--;
-      g->num_kmers = before;
-      return 0;
-    }
+    if(g->isec_edges) edge_mask = g->isec_edges[hkey]; /* prefs.must_exist_in_edges: graphs_load.c:166-167 */
   } else {
     hkey = find_or_insert(g, &key, &found);
     if(hkey == ORC_NOT_FOUND) { g->full = 1; return -1; }
@@ -629,9 +650,48 @@ int orc_graph_add_record(orc_graph *g, const uint64_t *key_words, const uint32_t
   for(c = 0; c < g->ncols; c++) { /* db_node_add_col_covg: SAFE_SUM_COVG, cortex_types.h:10-11 */
     uint32_t *cv = &g->covgs[hkey * (uint64_t)g->ncols + (uint64_t)c];
     *cv = ((uint64_t)*cv + covgs[c] > UINT32_MAX) ? UINT32_MAX : *cv + covgs[c];
-    g->edges[hkey * (uint64_t)g->ncols + (uint64_t)c] |= edges[c]; /* edge_mask = 0xff */
+    g->edges[hkey * (uint64_t)g->ncols + (uint64_t)c] |= edges[c] & edge_mask;
   }
   return 1;
+}
+
+/* ---- build --intersect ------------------------------------------------------------------ */
+void orc_graph_set_must_exist(orc_graph *g, int on) { g->must_exist = on; }
+
+/* One record of an intersection graph: graph_load with col_covgs == NULL and col_edges ==
+ * isec_edges, one edge column, filter flattened into colour 0 (ctx_build.c:197-203,347-361;
+ * graphs_load.c:117-186).  covg_sum / edges_or are the flattened values of the record. */
+int orc_graph_add_isec_record(orc_graph *g, const uint64_t *key_words, uint32_t covg_sum, uint8_t edges_or)
+{
+  int c, found = 0;
+  if(!g->isec_edges) g->isec_edges = calloc(g->capacity, 1); /* ctx_build.c:341-343 */
+  if(covg_sum == 0) return 0;
+  orc_bkmer key;
+  memset(&key, 0, sizeof(key));
+  for(c = 0; c < g->W; c++) key.b[c] = key_words[c];
+  uint64_t hkey = find_or_insert(g, &key, &found);
+  if(hkey == ORC_NOT_FOUND) { g->full = 1; return -1; }
+  g->isec_edges[hkey] |= edges_or;
+  return 1;
+}
+
+/* db_graph_remove_no_covg_kmers + db_graph_intersect_edges (db_graph.c:630-673, ctx_build.c:409-413) */
+void orc_graph_isec_finish(orc_graph *g)
+{
+  uint64_t s;
+  int c;
+  if(!g->isec_edges) return;
+  for(s = 0; s < g->capacity; s++) {
+    if(!(g->table[s * (uint64_t)g->W] & ORC_FLAG)) continue;
+    uint32_t covg = 0;
+    for(c = 0; c < g->ncols; c++) covg |= g->covgs[s * (uint64_t)g->ncols + (uint64_t)c];
+    if(!covg) { /* hash_table_delete: hash_table.c:285-299 */
+      memset(g->table + s * (uint64_t)g->W, 0, sizeof(uint64_t) * (size_t)g->W);
+      g->num_kmers--;
+    }
+  }
+  for(s = 0; s < g->capacity; s++)
+    for(c = 0; c < g->ncols; c++) g->edges[s * (uint64_t)g->ncols + (uint64_t)c] &= g->isec_edges[s];
 }
 
 size_t orc_graph_header_size(const orc_graph *g)

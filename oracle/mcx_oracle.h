@@ -75,6 +75,11 @@ void orc_graph_update_stats(orc_graph *g, int colour, const orc_stats *stats);
 /* one record of graph_load (graphs_load.c:117-186), colours already mapped onto the graph's */
 int orc_graph_add_record(orc_graph *g, const uint64_t *key_words, const uint32_t *covgs, const uint8_t *edges,
                          int must_exist);
+/* build --intersect (ctx_build.c:341-363,384-413): intersection-graph records, must-exist reads,
+ * final removal of k-mers without coverage + edge intersection */
+void orc_graph_set_must_exist(orc_graph *g, int on);
+int  orc_graph_add_isec_record(orc_graph *g, const uint64_t *key_words, uint32_t covg_sum, uint8_t edges_or);
+void orc_graph_isec_finish(orc_graph *g);
 size_t orc_graph_ctx_size(const orc_graph *g);
 size_t orc_graph_write_ctx(const orc_graph *g, int sorted, uint8_t *out);
 size_t orc_graph_header_size(const orc_graph *g);

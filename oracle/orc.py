@@ -88,6 +88,10 @@ def lib():
     L.orc_graph_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]
     L.orc_graph_add_record.restype = C.c_int
     L.orc_graph_add_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_graph_set_must_exist.argtypes = [C.c_void_p, C.c_int]
+    L.orc_graph_add_isec_record.restype = C.c_int
+    L.orc_graph_add_isec_record.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint8]
+    L.orc_graph_isec_finish.argtypes = [C.c_void_p]
     L.orc_tuples.restype = C.c_uint64
     L.orc_tuples.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                              C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p]
@@ -165,6 +169,19 @@ class Graph:
         if rc < 0:
             raise RuntimeError("Hash table is full")
         return rc
+
+    def set_must_exist(self, on=True):
+        self.L.orc_graph_set_must_exist(self.h, 1 if on else 0)
+
+    def add_isec_record(self, key_words, covg_sum, edges_or):
+        kw = np.ascontiguousarray(key_words, dtype=np.uint64)
+        rc = self.L.orc_graph_add_isec_record(self.h, _ptr(kw), int(covg_sum), int(edges_or))
+        if rc < 0:
+            raise RuntimeError("Hash table is full")
+        return rc
+
+    def isec_finish(self):
+        self.L.orc_graph_isec_finish(self.h)
 
     def body_bytes(self, sorted_=True):
         return self.ctx_bytes(sorted_)[self.header_size():]

@@ -446,3 +446,97 @@ def test_reference_build0_command_lines(mcx, orc, tmp_path):
     rc, outb, err = run(31, "index", "-q", srt)
     assert rc == 0 and outb.decode() == _index_expected(want_sorted, (4 << 20) // (8 + 15))
     assert len(outb.decode().splitlines()) == 2      # header line + one block
+
+
+# ---- build --intersect ------------------------------------------------------------------------
+def _oracle_intersect(orc, k, ncols, isec_bufs, graph_loads, names, jobs):
+    """ctx_build.c:341-413 with the oracle: intersection graphs (flattened), --graph files loaded
+    must-exist with the edge mask, must-exist reads, removal of k-mers without coverage and edge
+    intersection.  -> expected file bytes"""
+    og = orc.Graph(k, ncols, 1 << 20)
+    gi = [ctxio.GraphInfo() for _ in range(ncols)]
+    for buf in isec_bufs:
+        hdr, hs = ctxio.read_header(buf)
+        keys, covgs, edges = ctxio.records(buf, hdr, hs)
+        for i in range(len(keys)):
+            cv = min(0xFFFFFFFF, int(covgs[i].astype(np.uint64).sum()))
+            og.add_isec_record(keys[i], cv, int(np.bitwise_or.reduce(edges[i])))
+    # (the intersection graphs' headers are merged into colour 0 and then reset: no trace)
+    for buf, spec, off in graph_loads:
+        hdr, _ = ctxio.read_header(buf)
+        _, filt = ctxio.parse_filter(spec, hdr["num_cols"], off)
+        ctxio.load_into(og, gi, buf, filt, must_exist=True)
+    for c, n in names.items():
+        gi[c].sample_name = n
+    og.set_must_exist(True)
+    for col, b, o in jobs:
+        st = og.add_reads(col, b, o)
+        gi[col].update_contigs(st.total_bases_loaded, st.contigs_parsed)
+    og.isec_finish()
+    return ctxio.header_bytes(k, gi) + og.body_bytes(True), og
+
+
+@pytest.mark.gpu
+def test_reference_build1_intersect_and_graph(mcx, orc, tmp_path):
+    """The reference's own integration test tests/build/build1/Makefile: two --intersect graphs, a
+    --graph loaded into colour 1 and reads into colour 2 must leave exactly 8 k-mers (6 of SEQA_SUB
+    via the reads, 2 of SEQB_SUB via the graph; the 100 extra bases are in neither intersection)."""
+    K = 11
+    SEQA, SEQB = "TCCCTGGTATCAACTTGTCTCTGGTCGGCC", "TACCAATCGGGACAACACGGGTCACTACGA"
+    SEQA_SUB, SEQB_SUB = "GGTATCAACTTGTCTC", "CGGGACAACACG"
+    EXTRA = "GTTATTAGAATGTTTAATTAATCATAGAAGCAACCTGGGGACACGTCCTCGTGACTGGAGCAGTACAACCCATCAATTAACTCTATTACTATACGGGAAC"
+
+    def fasta(name, seqs):
+        p = tmp_path / name
+        p.write_text("".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+        return str(p)
+
+    # dnacat -F -n 9 prints the given sequence and appends 9 random bases: any 9 do
+    isec0, isec1 = fasta("isec0.fa", [SEQA + "ACGTTGCAA"]), fasta("isec1.fa", [SEQB + "TTGCAGTCA"])
+    seq, small = fasta("seq.fa", [SEQA_SUB, EXTRA]), fasta("small.fa", [SEQB_SUB, EXTRA])
+    ctx = {}
+    for name, fa in (("isec0", isec0), ("isec1", isec1), ("small", small)):
+        ctx[name] = str(tmp_path / (name + ".ctx"))
+        rc, _, err = run(31, "build", "-q", "-m", "1M", "-k", str(K), "--sample", name, "--seq", fa, ctx[name])
+        assert rc == 0, err
+    merged = str(tmp_path / "merge.ctx")
+    rc, _, err = run(31, "build", "-q", "-m", "1M", "-k", str(K), "--sort", "--intersect", ctx["isec1"], "--intersect", ctx["isec0"],
+                     "--graph", "1:" + ctx["small"], "--sample", "Spiderman", "--seq", seq, merged)
+    assert rc == 0, err
+    got = open(merged, "rb").read()
+    hdr, hs = ctxio.read_header(got)
+    keys, covgs, edges = ctxio.records(got, hdr, hs)
+    assert hdr["num_cols"] == 3 and len(keys) == 8                      # the reference's assertion
+    assert (covgs[:, 0] == 0).all() and sorted((covgs[:, 1] > 0).tolist()) == [False] * 6 + [True] * 2
+    assert int((covgs[:, 2] > 0).sum()) == 6
+    b, o = orc.pack_reads([SEQA_SUB, EXTRA])
+    want, _ = _oracle_intersect(orc, K, 3, [open(ctx["isec1"], "rb").read(), open(ctx["isec0"], "rb").read()],
+                                [(open(ctx["small"], "rb").read(), "1:" + ctx["small"], 0)], {2: "Spiderman"}, [(2, b, o)])
+    assert got == want
+    rc, _, err = run(31, "build", "-q", "-k", str(K), "-I", ctx["isec0"], "-s", "a", "-p", "--seq", seq, str(tmp_path / "x.ctx"))
+    assert rc == 1 and "--remove-pcr" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxk,k", [(31, 21), (63, 41)])
+def test_intersect_matches_oracle_on_random_graphs(mcx, orc, tmp_path, maxk, k):
+    """Larger case: a 2-colour intersection graph (flattened) whose reads have errors, reads and a
+    --graph that only partly overlap it, lowercase / N-containing reads."""
+    g0 = synth.genome(20000, 31)
+    g1 = synth.genome(20000, 32)
+    ra = synth.reads(1500, 90, seed=1, g=g0, n_frac=0.05)
+    rb = synth.reads(800, 90, seed=2, g=g1)
+    rq = synth.reads(1200, 100, seed=3, g=np.concatenate([g0[:12000], g1[:8000]]), n_frac=0.05, lower_frac=0.1)
+    rg = synth.reads(900, 80, seed=4, g=np.concatenate([g1[:5000], g0[5000:9000]]))
+    f = [_fasta(tmp_path / ("r%d.fa" % i), *r) for i, r in enumerate((ra, rb, rq, rg))]
+    I = str(tmp_path / "I.ctx"); G = str(tmp_path / "G.ctx"); out = str(tmp_path / "o.ctx")
+    rc, _, err = run(maxk, "build", "-q", "-k", str(k), "-n", "1M", "-s", "a", "--seq", f[0], "-s", "b", "--seq", f[1], I)
+    assert rc == 0, err
+    rc, _, err = run(maxk, "build", "-q", "-k", str(k), "-n", "1M", "-s", "g", "--seq", f[3], G)
+    assert rc == 0, err
+    rc, _, err = run(maxk, "build", "-k", str(k), "-n", "1M", "--sort", "-I", I, "-g", G, "-s", "q", "--seq", f[2], "--seq", f[0], out)
+    assert rc == 0, err
+    assert "Flattening intersection graph into colour 0" in err
+    want, og = _oracle_intersect(orc, k, 2, [open(I, "rb").read()], [(open(G, "rb").read(), G, 0)], {1: "q"}, [(1, *rq), (1, *ra)])
+    got = open(out, "rb").read()
+    assert 0 < og.nkmers and got == want
