@@ -413,7 +413,7 @@ int ctx_build(int argc, char **argv)
     else {
       build_task *bt = &tasks[t];
       bt->fmt = SEQ_FMT_UNKNOWN;
-      if (strcmp(bt->path, "-")) { /* stdin can only be read once: no format probe */
+      if (file_size(bt->path) >= 0) { /* stdin, pipes and <(...) can only be read once: no format probe */
         seq_in *probe = seq_in_open(bt->path);
         if (!probe) die("Cannot open -1 file: %s", bt->path);
         bt->fmt = seq_in_format(probe);

@@ -540,3 +540,26 @@ def test_intersect_matches_oracle_on_random_graphs(mcx, orc, tmp_path, maxk, k):
     want, og = _oracle_intersect(orc, k, 2, [open(I, "rb").read()], [(open(G, "rb").read(), G, 0)], {1: "q"}, [(1, *rq), (1, *ra)])
     got = open(out, "rb").read()
     assert 0 < og.nkmers and got == want
+
+
+@pytest.mark.gpu
+def test_reference_inferedges_build_inputs(mcx, orc, tmp_path):
+    """The `build` invocations of the reference's tests/inferedges/Makefile: k=5, plain one-sequence-
+    per-line input through process substitution (a pipe: read once, no format probe), an empty input."""
+    cases = {
+        "RightEdges": "AAGGA\nAAGGC\nAAGGG\nCAAGGT\n",
+        "LeftEdges": "ACAAG\nCCAAGG\nGCAAG\nTCAAG",          # no trailing newline
+        "MsEmpty": "\n",
+    }
+    for name, text in cases.items():
+        out = str(tmp_path / (name + ".ctx"))
+        src = tmp_path / (name + ".txt")
+        src.write_text(text)
+        cmd = "%s build -q -m 1M -k 5 --sort --sample %s --seq <(cat %s) %s" % (os.path.join(BIN, "mccortex31"), name, src, out)
+        p = subprocess.run(["bash", "-c", cmd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        reads = [l for l in text.split("\n") if l]
+        og, gi = _reads_graph(orc, 5, 1, [(0, *orc.pack_reads(reads))] if reads else [], [name])
+        assert open(out, "rb").read() == ctxio.header_bytes(5, gi) + og.body_bytes(True), name
+    keys = ctxio.records(*(lambda b: (b,) + ctxio.read_header(b))(open(str(tmp_path / "RightEdges.ctx"), "rb").read()))[0]
+    assert len(keys) == 5     # AAGGA, AAGGC, AAGGG, and CAAGG + AAGGT of the 6-base read
