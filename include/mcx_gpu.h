@@ -221,6 +221,29 @@ int mcx_sort_records(void *recs, uint64_t nrecs, int kmer_size, int ncols, int d
 int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_size, int ncols, int device,
                        int64_t *first_unsorted);
 
+/* Sharded build, exchange format v3 ("reads travel, not occurrences"; one-word keys with odd k in
+ * 29..31, mcx_superk_supported()).  The owner of a k-mer is a function of its canonical minimizer
+ * (smallest hashed canonical 13-mer), so consecutive k-mers of a read mostly share an owner and
+ * are sent as one 16-byte record: the 48-base window of 16 consecutive positions plus the start and
+ * length of the run -- about 2.3 bytes per occurrence instead of 8.5.  Every rank holds an ordinary
+ * (unsharded) table with the k-mers it owns.
+ *   mcx_superk_owner           owner of a canonical key (host; tests)
+ *   mcx_graph_superk_layout    records per (owner, replica) segment for calls of at most
+ *                              `positions_per_call` stream bytes; segs_per_owner replicas per owner
+ *   mcx_graph_superk_bins_dev  sender: d_recs[nparts][segs][seg_cap] 16-byte records with fills
+ *                              d_counts[nparts][segs] (u64, zeroed by the caller); a full segment
+ *                              drops records and raises MCX_ERR_FULL at the next sync
+ *   mcx_graph_add_superk_dev   owner: k-merise received segments (fills in device memory) into the
+ *                              region bins; applied at the next flush */
+int mcx_superk_supported(int kmer_size);
+uint32_t mcx_superk_owner(const uint64_t *key_words, int kmer_size, int nparts);
+int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positions_per_call, uint32_t *segs_per_owner,
+                            uint64_t *seg_cap);
+int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, int nparts, void *d_recs,
+                              void *d_counts, uint64_t seg_cap);
+int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_recs, const void *d_counts, uint32_t nseg,
+                             uint64_t seg_cap, uint64_t kmers_upper_bound);
+
 /* Wait for all submitted work; reports MCX_ERR_FULL if any insert ran out of
  * slots (the reference dies with "Hash table is full"). */
 int mcx_graph_sync(mcx_graph *g);

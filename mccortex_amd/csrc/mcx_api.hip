@@ -18,7 +18,7 @@
 
 #include "../../include/mcx_gpu.h"
 #include "mcx_kernels.h"
-#include "mcx_defer.h"
+#include "mcx_superk.h"
 
 using namespace mcx;
 
@@ -759,6 +759,97 @@ extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *
   DISPATCH_WC(g, launch_split_regions, g, in, colour, bs, out);
   HIP_TRY(hipGetLastError());
   g->pending_l2 += ntuples;
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sharded build, exchange format v3: super-k-mer records (mcx_superk.h)
+// ---------------------------------------------------------------------------
+static const uint32_t kSuperkRep = 8;
+
+extern "C" int mcx_superk_supported(int kmer_size) { return kmer_size >= kSuperkMinK && kmer_size <= 31 && (kmer_size & 1); }
+
+extern "C" uint32_t mcx_superk_owner(const uint64_t *key_words, int kmer_size, int nparts)
+{
+  uint32_t lbo = 0;
+  while ((1 << lbo) < nparts) lbo++;
+  return superk_owner(key_words[0], kmer_size, lbo);
+}
+
+extern "C" int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positions_per_call, uint32_t *segs_per_owner,
+                                       uint64_t *seg_cap)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1))) return fail(MCX_ERR_ARG, "shards must be a power of two <= 32");
+  if (segs_per_owner) *segs_per_owner = kSuperkRep;
+  // ~2.3 records per 16 positions on random reads; room for 4 (a bin that overflows is reported as
+  // MCX_ERR_FULL at the next sync of the sending handle: nothing is lost silently)
+  if (seg_cap) *seg_cap = positions_per_call / 4 / ((uint64_t)nparts * kSuperkRep) + 4096;
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, int nparts, void *d_recs,
+                                         void *d_counts, uint64_t seg_cap)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..31 (got %d)", kSuperkMinK, g->k);
+  if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1))) return fail(MCX_ERR_ARG, "shards must be a power of two <= 32");
+  if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  if (!nbytes) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  uint32_t lbo = 0;
+  while ((1 << lbo) < nparts) lbo++;
+  StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
+  const StreamArgs a = make_args(g, L);
+  const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
+  if (!nt) return MCX_OK;
+  SuperkOut out{(ulonglong2 *)d_recs, (unsigned long long *)d_counts, seg_cap, lbo, kSuperkRep};
+  SpanGuard sp(g, "k_stream_superk");
+  hipLaunchKernelGGL(k_stream_superk, dim3((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid)), dim3(kThreads), 0, g->stream, a, out);
+  HIP_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+template <int W, bool ONECOL> static void launch_superk_bin(mcx_graph *g, SuperkIn in, int colour, BinSpec bs, BinOut out)
+{
+  if (W != 1) return;
+  const uint64_t ntiles = (in.seg_cap + kThreads - 1) / kThreads * in.nseg;
+  InsertSink<1, ONECOL> is{g->t, (uint32_t)colour};
+  static bool once = false;
+  if (!once) {
+    allow_lds(k_superk_bin<ONECOL, 512>, sizeof(BinLds<1, 512, false>));
+    allow_lds(k_superk_bin<ONECOL, kMaxBins>, sizeof(BinLds<1, kMaxBins, false>));
+    once = true;
+  }
+  SpanGuard sp(g, "k_superk_bin");
+  const dim3 grid((unsigned)std::min<uint64_t>(ntiles, (uint64_t)g->grid * 4));
+  if (bs.nlocal <= 512)
+    hipLaunchKernelGGL((k_superk_bin<ONECOL, 512>), grid, dim3(kThreads), sizeof(BinLds<1, 512, false>), g->stream, in, g->k, bs, out, is, g->d_ctr);
+  else
+    hipLaunchKernelGGL((k_superk_bin<ONECOL, kMaxBins>), grid, dim3(kThreads), sizeof(BinLds<1, kMaxBins, false>), g->stream, in, g->k, bs, out, is, g->d_ctr);
+}
+
+extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_recs, const void *d_counts, uint32_t nseg,
+                                        uint64_t seg_cap, uint64_t kmers_upper_bound)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (colour < 0 || colour >= g->ncols_vis) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+  if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..31 (got %d)", kSuperkMinK, g->k);
+  if (g->t.lbo) return fail(MCX_ERR_ARG, "super-k-mer shards use ordinary (unsharded) tables");
+  if (!nseg || !seg_cap) return MCX_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  int rc = ensure_defer(g);
+  if (rc != MCX_OK) return rc;
+  if (!g->defer) return fail(MCX_ERR_ARG, "super-k-mer records need the deferred insert path (table too small or defer=0)");
+  rc = defer_reserve(g, colour, kmers_upper_bound);
+  if (rc != MCX_OK) return rc;
+  SuperkIn in{(const ulonglong2 *)d_recs, (const unsigned long long *)d_counts, seg_cap, nseg};
+  BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
+  BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
+  if (g->ncols == 1) launch_superk_bin<1, true>(g, in, colour, bs, out);
+  else launch_superk_bin<1, false>(g, in, colour, bs, out);
+  HIP_TRY(hipGetLastError());
+  g->pending += kmers_upper_bound;
   return MCX_OK;
 }
 

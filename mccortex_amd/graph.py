@@ -14,7 +14,8 @@ SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
     "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_kmer_covg", "mcx_graph_covg_histogram", "mcx_sort_records",
-    "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_graph_destroy",
+    "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_superk_supported", "mcx_superk_owner",
+    "mcx_graph_superk_layout", "mcx_graph_superk_bins_dev", "mcx_graph_add_superk_dev", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
@@ -86,6 +87,12 @@ def lib():
     L.mcx_sort_records.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int]
     L.mcx_records_sorted.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.mcx_graph_intersect_finish.argtypes = [vp, u64p]
+    L.mcx_superk_supported.argtypes = [C.c_int]
+    L.mcx_superk_owner.restype = C.c_uint32
+    L.mcx_superk_owner.argtypes = [u64p, C.c_int, C.c_int]
+    L.mcx_graph_superk_layout.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(C.c_uint32), u64p]
+    L.mcx_graph_superk_bins_dev.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_uint64]
+    L.mcx_graph_add_superk_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]
     L.mcx_graph_key_owner.restype = C.c_uint32
     L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
@@ -219,6 +226,17 @@ class Graph:
                                           len(offsets) - 1, fq_cutoff, hp_cutoff, C.byref(st)))
         return st
 
+    def superk_layout(self, nparts, positions_per_call):
+        segs, cap = C.c_uint32(), C.c_uint64()
+        _check(self.L.mcx_graph_superk_layout(self.h, nparts, int(positions_per_call), C.byref(segs), C.byref(cap)))
+        return int(segs.value), int(cap.value)
+
+    def superk_bins_dev(self, d_stream, nbytes, nparts, d_recs, d_counts, seg_cap):
+        _check(self.L.mcx_graph_superk_bins_dev(self.h, _ptr(d_stream), nbytes, nparts, _ptr(d_recs), _ptr(d_counts), seg_cap))
+
+    def add_superk_dev(self, colour, d_recs, d_counts, nseg, seg_cap, kmers_upper_bound):
+        _check(self.L.mcx_graph_add_superk_dev(self.h, colour, _ptr(d_recs), _ptr(d_counts), nseg, seg_cap, int(kmers_upper_bound)))
+
     def intersect_finish(self):
         n = C.c_uint64(0)
         _check(self.L.mcx_graph_intersect_finish(self.h, C.byref(n)))
@@ -337,3 +355,12 @@ def records_sorted(recs, kmer_size, ncols, device=0):
     bad = C.c_int64(-1)
     _check(lib().mcx_records_sorted(_ptr(a), a.size // rs, kmer_size, ncols, device, C.byref(bad)))
     return int(bad.value)
+
+
+def superk_supported(kmer_size):
+    return bool(lib().mcx_superk_supported(kmer_size))
+
+
+def superk_owner(words, kmer_size, nparts):
+    a = (C.c_uint64 * 2)(*(list(words) + [0])[:2])
+    return int(lib().mcx_superk_owner(a, kmer_size, nparts))

@@ -303,3 +303,51 @@ def test_sharded_table_compact_exchange(mcx, orc, k, nparts):
         g.close()
     assert shard.merge_sorted_bodies(bodies, 8 * W + 5, 8 * W) == want
     assert all(len(b) > 0 for b in bodies)
+
+
+@pytest.mark.parametrize("k,nparts", [(31, 4), (29, 8), (31, 2), (31, 1)])
+def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
+    """Exchange format v3: every 'rank' turns its reads into per-owner super-k-mer records, every
+    owner k-merises the records addressed to it; the union of the (unsharded) owner tables is the
+    oracle's graph and every key sits on the shard its canonical minimizer names."""
+    import torch
+    from mccortex_amd import shard
+    assert mcx.superk_supported(k) and not mcx.superk_supported(27) and not mcx.superk_supported(33)
+    g0 = synth.genome(50000, 77)
+    graphs = [mcx.Graph(k, 1, 1 << 20) for _ in range(nparts)]
+    all_reads = []
+    for r in range(nparts):
+        bases, offs = synth.reads(2500, 140, seed=90 + r, g=g0, n_frac=0.08, lower_frac=0.05)
+        if r == 0:  # low-complexity reads, short reads, reads of exactly k and k + 1 bases
+            hb, ho = orc.pack_reads(["A" * 150] * 50 + ["ACGTTGCA" * 20] * 40 + ["ACG" * 5, "T" * k, "G" * (k + 1), "ACGT" * 9][:4])
+            bases = np.concatenate([bases, hb]); offs = np.concatenate([offs, offs[-1] + ho[1:]])
+        all_reads.append((bases, offs))
+        stream = torch.from_numpy(synth.to_stream(bases, offs)).cuda()
+        segs, seg_cap = graphs[r].superk_layout(nparts, stream.numel())
+        recs = torch.zeros((nparts, segs, seg_cap, 2), dtype=torch.int64, device="cuda")
+        counts = torch.zeros((nparts, segs), dtype=torch.int64, device="cuda")
+        graphs[r].superk_bins_dev(stream, stream.numel(), nparts, recs, counts, seg_cap)
+        graphs[r].sync()                       # a dropped record would raise here
+        assert int(counts.max()) <= seg_cap
+        nrec = int(counts.sum())
+        assert nrec > 0
+        for o in range(nparts):                # "exchange": owner o takes the segments addressed to it
+            graphs[o].add_superk_dev(0, recs[o], counts[o], segs, seg_cap, int(counts[o].sum()) * 16)
+            graphs[o].sync()
+        if r == 1:  # bytes on the wire: well below 8 bytes per occurrence
+            st = graphs[r].device_stats()
+            assert nrec * 16 < 5.0 * max(1, st.num_kmers_loaded) or nparts == 1
+    og = orc.Graph(k, 1, 1 << 21)
+    for b, o in all_reads:
+        og.add_reads(0, b, o)
+    bodies = []
+    for p, g in enumerate(graphs):
+        kk, cc, ee = g.records(True)
+        for row in kk[::29]:
+            assert mcx.superk_owner([int(x) for x in row], k, nparts) == p
+        bodies.append(g.export(True))
+        g.close()
+    assert shard.merge_sorted_bodies(bodies, 8 + 5, 8) == og.body_bytes(True)
+    if nparts > 1:
+        sizes = [len(b) for b in bodies]
+        assert min(sizes) > 0.5 * max(sizes)   # minimizer ownership is reasonably balanced
