@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DEFER_TUPLES = 8_000_000_000  # k-mer occurrences buffered per flush of the partition->LDS-insert path
 # algorithmic bytes per k-mer occurrence of every kernel of that path
 KERNEL_ALG_BYTES = {"k_stream": 21.25, "k_stream_bin": 1.25 + 8.0, "k_tuples_bin": 16.0, "k_lds_insert": 8.0,
-                    "k_insert_tuples": 29.0}
+                    "k_insert_tuples": 29.0, "k_stream_superk": 1.25 + 2.3, "k_superk_bin": 2.3 + 8.0}
 
 
 def make_genome(n, device, seed):
@@ -196,7 +196,13 @@ def main():
     sharded = world > 1 or force_shard
     # N > 1: the table is sharded by quotient-hash prefix; every rank holds one shard of the same
     # per-GPU size (weak scaling)
-    graph = mcx.Graph(K, 1, args.table_slots, device=local_rank, nparts=world, part=rank)
+    # exchange format: v3 (super-k-mer records, minimizer ownership, ordinary per-rank tables) when
+    # k allows it, else v2 (packed tuples, table sharded by quotient-hash prefix); MCX_EXCHANGE=v2 forces v2
+    use_v3 = sharded and mcx.superk_supported(K) and os.environ.get("MCX_EXCHANGE", "v3") != "v2"
+    if use_v3:
+        graph = mcx.Graph(K, 1, args.table_slots, device=local_rank)
+    else:
+        graph = mcx.Graph(K, 1, args.table_slots, device=local_rank, nparts=world, part=rank)
     if args.direct:
         graph.configure("defer", 0)
     else:
@@ -216,9 +222,18 @@ def main():
         # (handle's stream) overlaps with the RCCL all-to-all of step n (torch's stream) and with
         # the owner-side split of step n-1.  Nothing here reads the graph, so nothing flushes it.
         ntup = B * (READ_LEN - K + 1)
-        segs, seg_cap, ov_cap = graph.shard_layout(ntup)
-        send = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
-        recv = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
+        if use_v3:
+            # v3: the sender only computes minimizers and cuts the reads into per-owner records
+            # (16 bytes per run of <= 16 k-mers: ~2.3 B per occurrence on the links instead of 8.5);
+            # the owner k-merises what it receives.  Only filled parts travel, which costs one
+            # host read of the fills per step.
+            segs, seg_cap = graph.superk_layout(world, batches[0].numel())
+            send = [shard.SuperkExchange(world, segs, seg_cap, device) for _ in range(2)]
+            recv = [shard.SuperkExchange(world, segs, seg_cap, device) for _ in range(2)]
+        else:
+            segs, seg_cap, ov_cap = graph.shard_layout(ntup)
+            send = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
+            recv = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
         filled = [torch.cuda.Event() for _ in range(2)]     # send[b] k-merised          (ext)
         sent = [torch.cuda.Event() for _ in range(2)]       # send[b] -> recv[b] exchanged (torch)
         consumed = [torch.cuda.Event() for _ in range(2)]   # recv[b] split by the owner  (ext)
@@ -248,16 +263,16 @@ def main():
             cur.wait_event(filled[buf])
             if n >= 2:
                 cur.wait_event(consumed[buf])           # recv[buf] is free again
-            send[buf].exchange_into(recv[buf])
+            got = send[buf].exchange_into(recv[buf])
             sent[buf].record(cur)
             ext.wait_event(sent[buf])
-            recv[buf].consume(graph, 0, ntup)
+            recv[buf].consume(graph, 0, got if use_v3 else ntup)
             consumed[buf].record(ext)
         ext.synchronize()
         cur.synchronize()
         for b in send:
             if b.overflowed():
-                raise SystemExit("an exchange overflow bin overflowed (tuples lost): raise ov_cap")
+                raise SystemExit("an exchange bin overflowed (occurrences lost): raise its capacity")
 
     def fence():
         torch.cuda.synchronize()
@@ -305,7 +320,7 @@ def main():
                                    "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
                                    "table %d slots per GPU" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots),
                        "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
-                       "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else "hash-prefix x%d, all-to-all" % world,
+                       "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel)},
         }

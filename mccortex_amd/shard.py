@@ -126,6 +126,54 @@ class BlockExchange:
         return bool((self.ov_counts > self.ov_cap).any().item())
 
 
+class SuperkExchange:
+    """Exchange format v3 (mcx_graph_superk_bins_dev / mcx_graph_add_superk_dev): per-owner bins of
+    16-byte super-k-mer records, `segs` replica segments per owner with fills counts[world][segs].
+    Only the filled part of every segment travels: the fills are exchanged first (one small
+    all-to-all and one host read), then one all-to-all per replica segment moves the records."""
+
+    def __init__(self, world, segs, seg_cap, device):
+        self.world, self.segs, self.seg_cap = world, segs, seg_cap
+        self.recs = torch.empty((world, segs, seg_cap, 2), dtype=torch.int64, device=device)
+        self.counts = torch.zeros((world, segs), dtype=torch.int64, device=device)
+
+    def zero_counts(self):
+        self.counts.zero_()
+
+    def fill(self, graph, d_stream, nbytes):
+        graph.superk_bins_dev(d_stream, nbytes, self.world, self.recs, self.counts, self.seg_cap)
+
+    def exchange_into(self, recv, group=None):
+        """recv.recs[p][s][:n] <- rank p's recs[my rank][s][:n]; returns the records received"""
+        world = self.world
+        dist.all_to_all_single(recv.counts, self.counts, group=group)
+        sc = torch.clamp(self.counts, max=self.seg_cap).tolist()      # host read: this step's fills
+        rc = torch.clamp(recv.counts, max=self.seg_cap).tolist()
+        nccl = dist.get_backend(group) == "nccl"
+        for s_ in range(self.segs):
+            if nccl:
+                dist.all_to_all([recv.recs[p, s_, :rc[p][s_]] for p in range(world)],
+                                [self.recs[p, s_, :sc[p][s_]] for p in range(world)], group=group)
+            else:
+                ins = [sc[p][s_] for p in range(world)]
+                outs = [rc[p][s_] for p in range(world)]
+                pk = torch.cat([self.recs[p, s_, :ins[p]] for p in range(world)])
+                tk = torch.empty((sum(outs), 2), dtype=self.recs.dtype, device=self.recs.device)
+                dist.all_to_all_single(tk, pk, output_split_sizes=outs, input_split_sizes=ins, group=group)
+                o = 0
+                for p in range(world):
+                    recv.recs[p, s_, :outs[p]] = tk[o:o + outs[p]]
+                    o += outs[p]
+        return sum(sum(r) for r in rc)
+
+    def consume(self, graph, colour, nrecords):
+        """owner: k-merise the received segments (this object is a receive set)"""
+        graph.add_superk_dev(colour, self.recs, self.counts, self.world * self.segs, self.seg_cap, nrecords * 16)
+
+    def overflowed(self):
+        return bool((self.counts > self.seg_cap).any().item())
+
+
 def merge_sorted_bodies(bodies, record_size, key_bytes):
     """N-way merge of per-rank sorted .ctx bodies (disjoint key sets) into one sorted body."""
     recs = [np.frombuffer(b, dtype=np.uint8).reshape(-1, record_size) for b in bodies if len(b)]

@@ -112,3 +112,39 @@ def _block_worker(rank, world, port):
 @pytest.mark.parametrize("world", [2, 4])
 def test_block_exchange_routes_fixed_blocks(mcx, world):
     mp.spawn(_block_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def _superk_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mccortex_amd import shard
+    segs, seg_cap = 8, 300
+
+    def stamp(src, dst):  # what rank `src` addresses to rank `dst`: fills and records
+        g = torch.Generator().manual_seed(7000 * src + dst)
+        cnt = torch.randint(0, seg_cap + 1, (segs,), generator=g)
+        cnt[0] = 0
+        cnt[1] = seg_cap
+        return cnt, torch.randint(-2**62, 2**62, (segs, seg_cap, 2), generator=g)
+
+    send = shard.SuperkExchange(world, segs, seg_cap, "cpu")
+    recv = shard.SuperkExchange(world, segs, seg_cap, "cpu")
+    for p in range(world):
+        send.counts[p], send.recs[p] = stamp(rank, p)
+    n = send.exchange_into(recv)
+    tot = 0
+    for p in range(world):
+        cnt, recs = stamp(p, rank)
+        assert torch.equal(recv.counts[p], cnt)
+        for s_ in range(segs):
+            assert torch.equal(recv.recs[p, s_, :cnt[s_]], recs[s_, :cnt[s_]])
+        tot += int(cnt.sum())
+    assert n == tot and not send.overflowed()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_superk_exchange_routes_filled_parts(mcx, world):
+    mp.spawn(_superk_worker, args=(world, _free_port()), nprocs=world, join=True)
