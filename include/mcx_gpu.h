@@ -231,10 +231,11 @@ int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_size, int ncol
  *   mcx_graph_superk_layout    records per (owner, replica) segment for calls of at most
  *                              `positions_per_call` stream bytes; segs_per_owner replicas per owner
  *   mcx_graph_superk_bins_dev  sender: d_recs[nparts][segs][seg_cap] 16-byte records with fills
- *                              d_counts[nparts][segs] (u64, zeroed by the caller); a full segment
- *                              drops records and raises MCX_ERR_FULL at the next sync
- *   mcx_graph_add_superk_dev   owner: k-merise received segments (fills in device memory) into the
- *                              region bins; applied at the next flush */
+ *                              d_counts[segs][nparts] (u64, replica-major, zeroed by the caller); a
+ *                              full segment drops records and raises MCX_ERR_FULL at the next sync
+ *   mcx_graph_add_superk_dev   owner: k-merise nseg received segments d_recs[nseg][seg_cap] (fills
+ *                              d_counts[nseg] in device memory) into the region bins; applied at the
+ *                              next flush */
 int mcx_superk_supported(int kmer_size);
 uint32_t mcx_superk_owner(const uint64_t *key_words, int kmer_size, int nparts);
 int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positions_per_call, uint32_t *segs_per_owner,

@@ -56,7 +56,9 @@ constexpr uint32_t kSkStartMask = 0xFu, kSkLenShift = 4, kSkPrevOk = 1u << 8, kS
 
 struct SuperkOut {
   ulonglong2 *recs;             // [nparts][rep][cap]
-  unsigned long long *counts;   // [nparts][rep] (zeroed by the caller); > cap: records were dropped
+  // fills, REPLICA-major [rep][nparts] (zeroed by the caller; > cap: records were dropped): the
+  // blocks of one replica reserve from one 64-byte line, other replicas from other lines
+  unsigned long long *counts;
   uint64_t cap;
   uint32_t lbo, rep;
 };
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
           const ulonglong2 rec = make_ulonglong2(hiW, w1hi | hdr);
           if (slot < (uint32_t)kSkStage) { s_rec[slot] = rec; s_own[slot] = (uint8_t)cur; }
           else {  // staging full (pathological input): straight to the bin, one global atomic
-            const unsigned long long pos = atomicAdd(&out.counts[cur * out.rep + rep], 1ULL);
+            const unsigned long long pos = atomicAdd(&out.counts[rep * nparts + cur], 1ULL);
             if (pos < out.cap) out.recs[((uint64_t)cur * out.rep + rep) * out.cap + pos] = rec;
             else dropped = 1;
           }
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
     for (uint32_t q = tid; q < nst; q += kThreads) atomicAdd(&s_cnt[s_own[q]], 1u);
     __syncthreads();
     if ((uint32_t)tid < nparts && s_cnt[tid])  // one wave instruction reserves for every owner
-      s_base[tid] = atomicAdd(&out.counts[(uint32_t)tid * out.rep + rep], (unsigned long long)s_cnt[tid]);
+      s_base[tid] = atomicAdd(&out.counts[rep * nparts + (uint32_t)tid], (unsigned long long)s_cnt[tid]);
     __syncthreads();
     for (uint32_t q = tid; q < nst; q += kThreads) {
       const uint32_t o = s_own[q];

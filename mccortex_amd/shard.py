@@ -128,26 +128,30 @@ class BlockExchange:
 
 class SuperkExchange:
     """Exchange format v3 (mcx_graph_superk_bins_dev / mcx_graph_add_superk_dev): per-owner bins of
-    16-byte super-k-mer records, `segs` replica segments per owner with fills counts[world][segs].
+    16-byte super-k-mer records, `segs` replica segments per owner.  A send set keeps its fills
+    replica-major (fills[segs][world], what the kernel wants); a receive set per source
+    (counts[world][segs], one fill per received segment).
     Only the filled part of every segment travels: the fills are exchanged first (one small
     all-to-all and one host read), then one all-to-all per replica segment moves the records."""
 
     def __init__(self, world, segs, seg_cap, device):
         self.world, self.segs, self.seg_cap = world, segs, seg_cap
         self.recs = torch.empty((world, segs, seg_cap, 2), dtype=torch.int64, device=device)
-        self.counts = torch.zeros((world, segs), dtype=torch.int64, device=device)
+        self.fills = torch.zeros((segs, world), dtype=torch.int64, device=device)    # sender side
+        self.counts = torch.zeros((world, segs), dtype=torch.int64, device=device)   # receiver side
 
     def zero_counts(self):
-        self.counts.zero_()
+        self.fills.zero_()
 
     def fill(self, graph, d_stream, nbytes):
-        graph.superk_bins_dev(d_stream, nbytes, self.world, self.recs, self.counts, self.seg_cap)
+        graph.superk_bins_dev(d_stream, nbytes, self.world, self.recs, self.fills, self.seg_cap)
 
     def exchange_into(self, recv, group=None):
         """recv.recs[p][s][:n] <- rank p's recs[my rank][s][:n]; returns the records received"""
         world = self.world
-        dist.all_to_all_single(recv.counts, self.counts, group=group)
-        sc = torch.clamp(self.counts, max=self.seg_cap).tolist()      # host read: this step's fills
+        mine = self.fills.t().contiguous()                           # [owner][segment]
+        dist.all_to_all_single(recv.counts, mine, group=group)
+        sc = torch.clamp(mine, max=self.seg_cap).tolist()             # host read: this step's fills
         rc = torch.clamp(recv.counts, max=self.seg_cap).tolist()
         nccl = dist.get_backend(group) == "nccl"
         for s_ in range(self.segs):
@@ -171,7 +175,7 @@ class SuperkExchange:
         graph.add_superk_dev(colour, self.recs, self.counts, self.world * self.segs, self.seg_cap, nrecords * 16)
 
     def overflowed(self):
-        return bool((self.counts > self.seg_cap).any().item())
+        return bool((self.fills > self.seg_cap).any().item())
 
 
 def merge_sorted_bodies(bodies, record_size, key_bytes):

@@ -325,9 +325,10 @@ def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
         stream = torch.from_numpy(synth.to_stream(bases, offs)).cuda()
         segs, seg_cap = graphs[r].superk_layout(nparts, stream.numel())
         recs = torch.zeros((nparts, segs, seg_cap, 2), dtype=torch.int64, device="cuda")
-        counts = torch.zeros((nparts, segs), dtype=torch.int64, device="cuda")
-        graphs[r].superk_bins_dev(stream, stream.numel(), nparts, recs, counts, seg_cap)
+        fills = torch.zeros((segs, nparts), dtype=torch.int64, device="cuda")   # replica-major
+        graphs[r].superk_bins_dev(stream, stream.numel(), nparts, recs, fills, seg_cap)
         graphs[r].sync()                       # a dropped record would raise here
+        counts = fills.t().contiguous()
         assert int(counts.max()) <= seg_cap
         nrec = int(counts.sum())
         assert nrec > 0

@@ -131,7 +131,7 @@ def _superk_worker(rank, world, port):
     send = shard.SuperkExchange(world, segs, seg_cap, "cpu")
     recv = shard.SuperkExchange(world, segs, seg_cap, "cpu")
     for p in range(world):
-        send.counts[p], send.recs[p] = stamp(rank, p)
+        send.fills[:, p], send.recs[p] = stamp(rank, p)
     n = send.exchange_into(recv)
     tot = 0
     for p in range(world):
