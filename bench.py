@@ -6,10 +6,10 @@ Workload (BASELINE.json configs[1], "C2"): k=31, 1 colour, synthetic 150 bp read
 2^30 slots.  One step = one batch of 5,000,000 reads (600M k-mer occurrences) that is already
 resident in HBM as a '\\n'-separated byte stream; the default 10 steps are the 50M x 150bp set.
 
-N>1 (one process per GPU, torchrun): weak scaling -- every rank k-merises its own 5M-read batch
-per step (genome scaled to N x 200 Mbp so every shard sees the same load), bins the tuples by
-(owner shard, table region), exchanges fixed-size blocks of packed tuples with one RCCL all-to-all
-and inserts what it owns.
+N>1 (one process per GPU, torchrun): weak scaling -- every rank takes its own 5M-read batch per step
+(genome scaled to N x 200 Mbp so every shard sees the same load), cuts the reads into per-owner
+super-k-mer records (owner = hash of the k-mer's canonical minimizer), exchanges them with RCCL
+all-to-alls and k-merises + inserts what it owns (exchange format v3).
 """
 import argparse
 import json
@@ -194,9 +194,7 @@ def main():
     torch.cuda.empty_cache()  # hand the generator's temporaries back before the graph allocates
 
     sharded = world > 1 or force_shard
-    # N > 1: the table is sharded by quotient-hash prefix; every rank holds one shard of the same
-    # per-GPU size (weak scaling)
-    # exchange format: v3 (super-k-mer records, minimizer ownership, ordinary per-rank tables) when
+    # N > 1: every rank holds a table of the same per-GPU size (weak scaling).  Exchange format: v3 (super-k-mer records, minimizer ownership, ordinary per-rank tables) when
     # k allows it, else v2 (packed tuples, table sharded by quotient-hash prefix); MCX_EXCHANGE=v2 forces v2
     use_v3 = sharded and mcx.superk_supported(K) and os.environ.get("MCX_EXCHANGE", "v3") != "v2"
     if use_v3:
@@ -216,11 +214,11 @@ def main():
     W = graph.W
 
     if sharded:
-        # Exchange format v2: the sender bins packed tuples by (owner, region); every owner's block
-        # has a fixed size, so one all-to-all per step moves them with no count round trip and no
-        # host synchronisation.  Send and receive sets are double buffered: k-merising step n+1
-        # (handle's stream) overlaps with the RCCL all-to-all of step n (torch's stream) and with
-        # the owner-side split of step n-1.  Nothing here reads the graph, so nothing flushes it.
+        # Send and receive sets are double buffered: the sender kernel of step n+1 (handle's stream)
+        # overlaps with the RCCL all-to-all of step n (torch's stream) and with the owner-side
+        # kernel of step n-1.  Nothing here reads the graph, so nothing flushes it.
+        # v2: the sender bins packed tuples by (owner, region); every owner's block has a fixed
+        # size, so one all-to-all per buffer moves them with no count round trip and no host sync.
         ntup = B * (READ_LEN - K + 1)
         if use_v3:
             # v3: the sender only computes minimizers and cuts the reads into per-owner records
