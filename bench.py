@@ -342,6 +342,13 @@ def main():
                                         "achieved": pipe_bytes / (gpu_ms * 1e-3) / 1e9,
                                         "frac": pipe_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "note": "SURVEY 8(d) 21.25 B per occurrence (+8 B per novel key) over the whole timed region"}}
+        # SURVEY 8(d)'s second ceiling: one random 64-byte sector RMW per occurrence is what the
+        # reference's algorithm (and the direct path here) costs; the chip does 17.3 G of those per
+        # second on a 16 GiB table (tools/ubench_atomics*.hip, profiles/r01_ubench_atomics*.log).
+        # The partition + LDS-insert path is not bound by it: that is the point of the design.
+        out["roofline"]["random_access"] = {"occurrences_per_s": kmers_local / (gpu_ms * 1e-3),
+                                            "measured_random_rmw_peak_per_s": 17.3e9,
+                                            "ratio": kmers_local / (gpu_ms * 1e-3) / 17.3e9}
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(batches[0], rank)
     if world > 1 or force_shard:
