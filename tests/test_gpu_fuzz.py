@@ -69,3 +69,35 @@ def test_stream_boundaries_are_separators(mcx, orc):
     g.add_stream_dev(0, pad, len(b))
     assert g.export(True) == want
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_superkmer_records_on_arbitrary_bytes(mcx, orc, seed):
+    """Exchange format v3 on arbitrary byte streams and ragged lengths: the union of the owner
+    tables (simulated shards) is the oracle's graph."""
+    import torch
+    from mccortex_amd import shard
+    rng = np.random.default_rng(500 + seed)
+    alphabet = np.concatenate([np.frombuffer(b"ACGT" * 60 + b"acgtNn\n\r @+>", np.uint8), rng.integers(0, 256, 10).astype(np.uint8)])
+    for n in (0, 1, 29, 31, 32, 47, 4095, 4096, 4097, 4096 * 3 + 7, 60001):
+        s = bytes(rng.choice(alphabet, n)) if n else b""
+        for k, nparts in ((31, 4), (29, 2), (31, 32)):
+            og, st, want = _oracle_body(orc, k, s)
+            graphs = [mcx.Graph(k, 1, 1 << 20) for _ in range(nparts)]
+            t = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+            t[n:] = ord("A")
+            if n:
+                t[:n] = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+            segs, cap = graphs[0].superk_layout(nparts, max(n, 1))
+            recs = torch.zeros((nparts, segs, cap, 2), dtype=torch.int64, device="cuda")
+            fills = torch.zeros((segs, nparts), dtype=torch.int64, device="cuda")
+            graphs[0].superk_bins_dev(t, n, nparts, recs, fills, cap)
+            graphs[0].sync()
+            assert graphs[0].device_stats().num_kmers_loaded == st.num_kmers_loaded, (n, k, nparts)
+            counts = fills.t().contiguous()
+            bodies = []
+            for o, g in enumerate(graphs):
+                g.add_superk_dev(0, recs[o], counts[o], segs, cap, int(counts[o].sum()) * 16)
+                bodies.append(g.export(True))
+                g.close()
+            assert shard.merge_sorted_bodies(bodies, 13, 8) == want, (n, k, nparts)
