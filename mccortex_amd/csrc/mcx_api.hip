@@ -316,7 +316,8 @@ static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour,
   const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
   if (!nt) return;
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
-  static bool once = false;
+  static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
+  bool &once = once_dev[g->device & 63];
   if (!once) {
     allow_lds(k_stream_bin<W, ONECOL, 512, FULL, SH>, sizeof(BinLds<W, 512, FULL>));
     allow_lds(k_stream_bin<W, ONECOL, 1024, FULL, SH>, sizeof(BinLds<W, 1024, FULL>));
@@ -341,7 +342,8 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   const uint64_t nchunks = (in.seg_cap + kTile - 1) / kTile * in.nseg;
   if (!nchunks) return;
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
-  static bool once = false;
+  static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
+  bool &once = once_dev[g->device & 63];
   if (!once) {
     allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>, sizeof(BinLds<W, 512, false>));
     allow_lds(k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD>, sizeof(BinLds<W, 1024, false>));
@@ -374,7 +376,8 @@ template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, Tupl
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour, uint32_t sub0, uint32_t nsub)
 {
   const size_t lds = Sub<W>::kSlots * (W + 1) * 8;
-  static bool once = false;
+  static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
+  bool &once = once_dev[g->device & 63];
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
   BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
   SpanGuard sp(g, "k_lds_insert");
@@ -815,7 +818,8 @@ template <int W, bool ONECOL> static void launch_superk_bin(mcx_graph *g, Superk
   if (W != 1) return;
   const uint64_t ntiles = (in.seg_cap + kThreads - 1) / kThreads * in.nseg;
   InsertSink<1, ONECOL> is{g->t, (uint32_t)colour};
-  static bool once = false;
+  static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
+  bool &once = once_dev[g->device & 63];
   if (!once) {
     allow_lds(k_superk_bin<ONECOL, 512>, sizeof(BinLds<1, 512, false>));
     allow_lds(k_superk_bin<ONECOL, kMaxBins>, sizeof(BinLds<1, kMaxBins, false>));
