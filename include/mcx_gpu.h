@@ -212,6 +212,13 @@ int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed);
 int mcx_graph_kmer_covg(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov);
 int mcx_graph_covg_histogram(mcx_graph *g, uint64_t *hist, uint32_t nbins);
 
+/* Order-independent checksum of the graph: the sum, over its k-mers, of a 64-bit mix of the
+ * exported record (key words, coverages clamped to 2^32-1, edges).  mcx_records_checksum computes
+ * the same sum on the host from `.ctx` body records, so that two builds -- or a build and a file --
+ * can be compared at sizes where byte-wise comparison of sorted exports is impractical. */
+int mcx_graph_checksum(mcx_graph *g, uint64_t *checksum, uint64_t *nkmers);
+uint64_t mcx_records_checksum(const void *recs, uint64_t nrecs, int kmer_size, int ncols);
+
 /* `.ctx` records on the device without a graph handle (host buffers, .ctx body layout).
  * mcx_sort_records    sort in place by k-mer, most significant word first -- what `sort` does with
  *                     qsort (src/commands/ctx_sort.c:133-152; binary_kmers_qcmp_unaligned_ptrs)

@@ -1416,6 +1416,44 @@ static int covg_scan(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov, uint64_t 
   return MCX_OK;
 }
 
+extern "C" int mcx_graph_checksum(mcx_graph *g, uint64_t *checksum, uint64_t *nkmers)
+{
+  if (!g || !checksum) return fail(MCX_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(g->device));
+  int rc = flush_deferred(g);
+  if (rc != MCX_OK) return rc;
+  unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
+  HIP_TRY(hipMalloc((void **)&d_out, 16));
+  HIP_TRY(hipMemsetAsync(d_out, 0, 16, g->stream));
+  {
+    SpanGuard sp(g, "k_checksum");
+    hipLaunchKernelGGL(k_checksum, dim3(g->grid), dim3(256), 0, g->stream, g->t, (uint32_t)g->W, (uint32_t)g->ncols_vis, d_out);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  (void)hipFree(d_out);
+  *checksum = h_out[0];
+  if (nkmers) *nkmers = h_out[1];
+  return MCX_OK;
+}
+
+extern "C" uint64_t mcx_records_checksum(const void *recs, uint64_t nrecs, int kmer_size, int ncols)
+{
+  const int W = words_for_k(kmer_size);
+  const size_t rb = 8 * (size_t)W + 5 * (size_t)ncols;
+  const uint8_t *p = (const uint8_t *)recs;
+  uint64_t sum = 0;
+  std::vector<uint32_t> cv((size_t)ncols);
+  for (uint64_t i = 0; i < nrecs; i++, p += rb) {
+    uint64_t kw[2] = {0, 0};
+    memcpy(kw, p, 8 * (size_t)W);
+    memcpy(cv.data(), p + 8 * W, 4 * (size_t)ncols);
+    sum += record_hash(kw, W, cv.data(), p + 8 * W + 4 * ncols, (uint32_t)ncols);
+  }
+  return sum;
+}
+
 extern "C" int mcx_graph_kmer_covg(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov)
 {
   if (!g) return fail(MCX_ERR_ARG, "null graph");

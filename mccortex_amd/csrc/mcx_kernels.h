@@ -802,6 +802,47 @@ __global__ void k_qh_contigs(const uint8_t *bases, const uint8_t *quals, const u
 }
 
 // ---------------------------------------------------------------------------
+// Order-independent checksum of the graph: sum over nodes of a 64-bit mix of the exported record
+// (key words, per colour min(coverage, 2^32-1) and edges).  Two tables hold the same graph iff
+// their exports are equal as sets; the checksum lets that be tested at sizes where comparing
+// exports byte by byte is impractical (tests/test_gpu_fullsize.py).
+// ---------------------------------------------------------------------------
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{  // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+  return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t record_hash(const uint64_t *key_words, int W, const uint32_t *covgs, const uint8_t *edges, uint32_t ncols)
+{
+  uint64_t h = 0x9E3779B97F4A7C15ULL;
+  for (int w = 0; w < W; w++) h = mix64(h ^ key_words[w]);
+  for (uint32_t c = 0; c < ncols; c++) h = mix64(h ^ (((uint64_t)covgs[c] << 8) | edges[c]) ^ ((uint64_t)(c + 1) << 48));
+  return h;
+}
+
+__global__ __launch_bounds__(256) void k_checksum(TableView t, uint32_t W, uint32_t ncols, unsigned long long *out)
+{
+  unsigned long long acc = 0, cnt = 0;
+  for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < t.nslots; slot += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t *r = key_ptr(t, slot);
+    if (!(r[0] & kFlag)) continue;
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    h = mix64(h ^ (r[0] & kKeyMask));
+    if (W == 2) h = mix64(h ^ r[1]);
+    for (uint32_t c = 0; c < ncols; c++) {
+      const uint64_t v = *val_ptr(t, slot, c);
+      uint64_t cv = v >> 8;
+      if (cv > 0xFFFFFFFFull) cv = 0xFFFFFFFFull;
+      h = mix64(h ^ ((cv << 8) | (v & 0xff)) ^ ((uint64_t)(c + 1) << 48));
+    }
+    acc += h; cnt++;
+  }
+  block_add(&out[0], acc);
+  block_add(&out[1], cnt);
+}
+
+// ---------------------------------------------------------------------------
 // build --intersect: reads only update k-mers that are already in the graph
 // ---------------------------------------------------------------------------
 // One lane per read walks it exactly as load_read + build_graph_from_str_mt do with

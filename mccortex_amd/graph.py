@@ -14,7 +14,7 @@ SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
     "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_kmer_covg", "mcx_graph_covg_histogram", "mcx_sort_records",
-    "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_superk_supported", "mcx_superk_owner",
+    "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_superk_supported", "mcx_superk_owner", "mcx_graph_checksum", "mcx_records_checksum",
     "mcx_graph_superk_layout", "mcx_graph_superk_bins_dev", "mcx_graph_add_superk_dev", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
@@ -93,6 +93,9 @@ def lib():
     L.mcx_graph_superk_layout.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(C.c_uint32), u64p]
     L.mcx_graph_superk_bins_dev.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_uint64]
     L.mcx_graph_add_superk_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.mcx_graph_checksum.argtypes = [vp, u64p, u64p]
+    L.mcx_records_checksum.restype = C.c_uint64
+    L.mcx_records_checksum.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     L.mcx_graph_key_owner.restype = C.c_uint32
     L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
@@ -237,6 +240,12 @@ class Graph:
     def add_superk_dev(self, colour, d_recs, d_counts, nseg, seg_cap, kmers_upper_bound):
         _check(self.L.mcx_graph_add_superk_dev(self.h, colour, _ptr(d_recs), _ptr(d_counts), nseg, seg_cap, int(kmers_upper_bound)))
 
+    def checksum(self):
+        """(order-independent checksum of the exported records, number of k-mers)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self.L.mcx_graph_checksum(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def intersect_finish(self):
         n = C.c_uint64(0)
         _check(self.L.mcx_graph_intersect_finish(self.h, C.byref(n)))
@@ -364,3 +373,10 @@ def superk_supported(kmer_size):
 def superk_owner(words, kmer_size, nparts):
     a = (C.c_uint64 * 2)(*(list(words) + [0])[:2])
     return int(lib().mcx_superk_owner(a, kmer_size, nparts))
+
+
+def records_checksum(recs, kmer_size, ncols):
+    a = np.frombuffer(bytes(recs), dtype=np.uint8)
+    rs = 8 * _words(kmer_size) + 5 * ncols
+    assert a.size % rs == 0
+    return int(lib().mcx_records_checksum(_ptr(a), a.size // rs, kmer_size, ncols))

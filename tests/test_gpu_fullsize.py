@@ -1,0 +1,158 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties.
+
+At 6 G occurrences the oracle is out of reach (hours) and byte-wise comparison of exports is
+impractical, so the graph is reduced to an order-independent checksum of its exported records
+(mcx_graph_checksum; pinned to the oracle's records at small size below) and independent ways of
+building the same graph must agree on it: the partition + LDS-insert path with one flush and with
+many, the direct HBM-atomics path, and the sharded builds (exchange formats v2 and v3, shards
+simulated on one GPU: the sum of the shard checksums is the checksum of the union).  Plus counting
+identities: every occurrence is counted exactly once (sum of coverage == k-mers loaded), every node
+has coverage (histogram bin 0 empty), node count == novel counter."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+M64 = (1 << 64) - 1
+
+
+@pytest.mark.parametrize("k,ncols", [(31, 1), (63, 1), (31, 3), (45, 2)])
+def test_checksum_is_pinned_to_oracle_records(mcx, orc, k, ncols):
+    g0 = synth.genome(20000, 5)
+    og = orc.Graph(k, ncols, 1 << 20)
+    g = mcx.Graph(k, ncols, 1 << 20)
+    for c in range(ncols):
+        b, o = synth.reads(2500, 110, seed=70 + c, g=g0, n_frac=0.05)
+        og.add_reads(c, b, o); g.add_reads(c, b, o)
+    body = og.body_bytes(True)
+    want = mcx.records_checksum(body, k, ncols)
+    cs, n = g.checksum()
+    assert (cs, n) == (want, og.nkmers)
+    assert mcx.records_checksum(g.export(False), k, ncols) == want      # order does not matter
+    # the checksum sees every field: flip one edge bit / one coverage
+    rs = 8 * og.W + 5 * ncols
+    bad = bytearray(body); bad[rs - 1] ^= 1
+    assert mcx.records_checksum(bytes(bad), k, ncols) != want
+    bad = bytearray(body); bad[8 * og.W] ^= 1
+    assert mcx.records_checksum(bytes(bad), k, ncols) != want
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def c2_batches():
+    """BASELINE config C2: 50 M x 150 bp reads from a 200 Mbp random genome, as bench.py makes them"""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    genome = bench.make_genome(bench.GENOME_PER_GPU, dev, seed=42)
+    batches = [bench.make_batch(genome, bench.BATCH_READS, seed=1000 + i, device=dev) for i in range(10)]
+    del genome
+    torch.cuda.empty_cache()
+    yield batches
+    del batches
+    torch.cuda.empty_cache()
+
+
+def _build(mcx, batches, k, ncols, slots, cfg, colours=None):
+    g = mcx.Graph(k, ncols, slots)
+    for key, v in cfg.items():
+        g.configure(key, v)
+    for i, b in enumerate(batches):
+        g.add_stream_dev(colours[i] if colours else 0, b, b.numel())
+    g.sync()
+    st = g.device_stats()
+    cs, n = g.checksum()
+    nk, sc = g.kmer_covg()
+    hist = g.covg_histogram(64)
+    out = dict(checksum=cs, nodes=n, nkmers=g.nkmers, loaded=st.num_kmers_loaded, contigs=st.contigs_parsed,
+               covg_nodes=nk.tolist(), covg_sum=sc.tolist(), hist0=int(hist[0]), hist_total=int(hist.sum()))
+    g.close()
+    return out
+
+
+def test_c2_full_size_all_paths_agree(mcx, c2_batches):
+    import torch
+    from mccortex_amd import shard
+    K, SLOTS = 31, 1 << 30
+    ref = _build(mcx, c2_batches, K, 1, SLOTS, {"defer_tuples": 8_000_000_000})
+    assert ref["loaded"] == 5_987_568_952 or ref["loaded"] > 5.9e9        # ~120 k-mers per read minus the N reads
+    assert ref["nodes"] == ref["nkmers"] == ref["covg_nodes"][0] == ref["hist_total"]
+    assert ref["covg_sum"][0] == ref["loaded"] and ref["hist0"] == 0
+    many = _build(mcx, c2_batches, K, 1, SLOTS, {"defer_tuples": 700_000_000, "flush_regions": 64})   # 9-10 flushes
+    direct = _build(mcx, c2_batches, K, 1, SLOTS, {"defer": 0})
+    for other in (many, direct):
+        assert other == ref
+    # sharded, exchange format v3: 4 owners with ordinary tables of a quarter of the size
+    N = 4
+    owners = [mcx.Graph(K, 1, SLOTS // N) for _ in range(N)]
+    for o in owners:
+        o.configure("defer_tuples", 2_500_000_000)
+    segs, cap = owners[0].superk_layout(N, c2_batches[0].numel())
+    recs = torch.empty((N, segs, cap, 2), dtype=torch.int64, device="cuda")
+    fills = torch.zeros((segs, N), dtype=torch.int64, device="cuda")
+    sender = owners[0]
+    loaded0 = 0
+    for b in c2_batches:
+        fills.zero_()
+        sender.superk_bins_dev(b, b.numel(), N, recs, fills, cap)
+        sender.sync()                      # the owners run on their own streams
+        counts = fills.t().contiguous()
+        assert int(fills.max()) <= cap
+        for p, o in enumerate(owners):
+            o.add_superk_dev(0, recs[p], counts[p], segs, cap, int(counts[p].sum()) * 16)
+        torch.cuda.synchronize()
+        for o in owners:
+            o.sync()
+    loaded0 = sender.device_stats().num_kmers_loaded
+    parts = [o.checksum() for o in owners]
+    sums = [o.kmer_covg()[1][0] for o in owners]
+    for o in owners:
+        o.close()
+    assert loaded0 == ref["loaded"]
+    assert (sum(c for c, _ in parts) & M64, sum(n for _, n in parts)) == (ref["checksum"], ref["nodes"])
+    assert int(sum(int(x) for x in sums)) == ref["loaded"]
+    assert max(n for _, n in parts) < 1.05 * ref["nodes"] / N              # balanced ownership
+    # sharded, exchange format v2: 2 shards of the quotient-hash-prefix sharded table
+    N = 2
+    shards = [mcx.Graph(K, 1, SLOTS // N, nparts=N, part=p) for p in range(N)]
+    for o in shards:
+        o.configure("defer_tuples", 4_000_000_000)
+    ntup = c2_batches[0].numel()
+    segs, seg_cap, ov_cap = shards[0].shard_layout(ntup * 120 // 151)
+    blk = shard.BlockExchange(N, segs, seg_cap, ov_cap, 1, "cuda")
+    for b in c2_batches:
+        blk.zero_counts()
+        blk.fill(shards[0], b, b.numel())
+        shards[0].sync()                   # the other shard runs on its own stream
+        for p, o in enumerate(shards):
+            rb = shard.BlockExchange(1, segs, seg_cap, ov_cap, 1, "cuda")
+            rb.keys, rb.counts = blk.keys[p:p + 1], blk.counts[p:p + 1]
+            rb.ov_keys, rb.ov_edges, rb.ov_counts = blk.ov_keys[p:p + 1], blk.ov_edges[p:p + 1], blk.ov_counts[p:p + 1]
+            rb.consume(o, 0, ntup)
+        torch.cuda.synchronize()
+        assert not blk.overflowed()
+        for o in shards:
+            o.sync()
+    parts = [o.checksum() for o in shards]
+    for o in shards:
+        o.close()
+    assert (sum(c for c, _ in parts) & M64, sum(n for _, n in parts)) == (ref["checksum"], ref["nodes"])
+
+
+def test_c4_and_c5_full_size_paths_agree(mcx, c2_batches):
+    # C4: k = 63 on the same reads (4.4 G occurrences)
+    a = _build(mcx, c2_batches, 63, 1, 1 << 30, {"defer_tuples": 5_000_000_000})
+    b = _build(mcx, c2_batches, 63, 1, 1 << 30, {"defer": 0})
+    assert a == b and a["covg_sum"][0] == a["loaded"] and a["hist0"] == 0 and a["loaded"] > 4.3e9
+    # C5-like: the 10 batches spread over 4 colours
+    cols = [0, 0, 0, 1, 1, 1, 2, 2, 3, 3]
+    a = _build(mcx, c2_batches, 31, 4, 1 << 30, {}, cols)
+    b = _build(mcx, c2_batches, 31, 4, 1 << 30, {"defer": 0}, cols)
+    assert a == b and sum(a["covg_sum"]) == a["loaded"] and a["hist0"] == 0
+    assert all(n > 0 for n in a["covg_nodes"])
