@@ -296,6 +296,12 @@ def main():
 
     st = graph.device_stats()
     kmers_local = st.num_kmers_loaded  # k-mer occurrences this rank k-merised (== inserted job-wide)
+    cs_local, nodes_local = graph.checksum()   # order-independent checksum of this rank's k-mers
+    ident = torch.tensor([cs_local & 0xFFFFFFFF, cs_local >> 32, nodes_local], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(ident, op=dist.ReduceOp.SUM)   # 32-bit halves: the sums cannot overflow
+    cs_total = (int(ident[0].item()) + (int(ident[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
+    nodes_total = int(ident[2].item())
     tot = torch.tensor([float(kmers_local), dt], dtype=torch.float64, device=device)
     if world > 1:
         k_all = tot[:1].clone()
@@ -320,7 +326,8 @@ def main():
                        "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
                        "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
-                       "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel)},
+                       "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel),
+                       "distinct_kmers_total": nodes_total, "graph_checksum": "%016x" % cs_total},
         }
         prof = graph.profile()  # {kernel: (launches, total ms)} measured live with HIP events
         gpu_ms = ev0.elapsed_time(ev1)
