@@ -296,6 +296,7 @@ def main():
 
     st = graph.device_stats()
     kmers_local = st.num_kmers_loaded  # k-mer occurrences this rank k-merised (== inserted job-wide)
+    prof = graph.profile()  # {kernel: (launches, total ms)} of the timed region, measured live with HIP events
     cs_local, nodes_local = graph.checksum()   # order-independent checksum of this rank's k-mers
     ident = torch.tensor([cs_local & 0xFFFFFFFF, cs_local >> 32, nodes_local], dtype=torch.int64, device=device)
     if world > 1:
@@ -329,7 +330,6 @@ def main():
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel),
                        "distinct_kmers_total": nodes_total, "graph_checksum": "%016x" % cs_total},
         }
-        prof = graph.profile()  # {kernel: (launches, total ms)} measured live with HIP events
         gpu_ms = ev0.elapsed_time(ev1)
         dom = max(prof, key=lambda n: prof[n][1])
         calls, tot_ms = prof[dom]
