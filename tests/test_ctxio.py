@@ -563,3 +563,29 @@ def test_reference_inferedges_build_inputs(mcx, orc, tmp_path):
         assert open(out, "rb").read() == ctxio.header_bytes(5, gi) + og.body_bytes(True), name
     keys = ctxio.records(*(lambda b: (b,) + ctxio.read_header(b))(open(str(tmp_path / "RightEdges.ctx"), "rb").read()))[0]
     assert len(keys) == 5     # AAGGA, AAGGC, AAGGG, and CAAGG + AAGGT of the 6-base read
+
+
+@pytest.mark.parametrize("name,maxk", [("tiny_k31", 31), ("tiny_k63", 63), ("tiny_k5", 31)])
+def test_index_command_on_golden_files_cpu(mcx, name, maxk, tmp_path):
+    """`index` needs no GPU (its device sortedness check is skipped without one): the table it
+    prints for the committed golden graphs equals the restatement of ctx_index.c:117-158."""
+    path = os.path.join(GOLD, name + ".ctx")
+    buf = open(path, "rb").read()
+    hdr, hs = ctxio.read_header(buf)
+    km = 8 * hdr["num_words"] + 5 * hdr["num_cols"]
+    rc, out, err = run(maxk, "index", "-q", path)
+    assert rc == 0, err
+    assert out.decode() == _index_expected(buf, (4 << 20) // km)
+    idx = str(tmp_path / "g.idx")
+    rc, out, err = run(maxk, "index", "-b", "7", "-o", idx, path)
+    assert rc == 0 and out == b"" and "[index] block bytes: %d kmers: 7" % (7 * km) in err
+    assert open(idx).read() == _index_expected(buf, 7)
+    # an unsorted file is refused by the host-side check of consecutive block starts
+    n = (len(buf) - hs) // km
+    if n >= 16:
+        recs = [buf[hs + i * km: hs + (i + 1) * km] for i in range(n)]
+        recs[0], recs[8] = recs[8], recs[0]
+        bad = tmp_path / "bad.ctx"
+        bad.write_bytes(buf[:hs] + b"".join(recs))
+        rc, _, err = run(maxk, "index", "-b", "4", str(bad))
+        assert rc == 1 and "File is not sorted" in err
