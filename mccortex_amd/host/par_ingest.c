@@ -29,6 +29,7 @@ typedef struct {
   size_t max_bases;
   int qmin, qmax;
   bool bad; /* structure the fast path does not handle */
+  unsigned nsampled; /* records whose qualities went into qmin/qmax (a sample is enough for the offset guess) */
 } range_parser;
 
 static inline const unsigned char *line_end(const unsigned char *p, const unsigned char *end)
@@ -102,9 +103,12 @@ static size_t range_fill(range_parser *rp, read_batch *b)
       const unsigned char *q = ple + 1, *qe = line_end(q, end);
       size_t n = strip_cr(s, (size_t)(se - s)), qn = strip_cr(q, (size_t)(qe - q));
       if (qn != n) { rp->bad = true; break; }
-      for (size_t i = 0; i < (qn < 64 ? qn : 64); i++) { /* sample for the offset guess */
-        if (q[i] < rp->qmin) rp->qmin = q[i];
-        if (q[i] > rp->qmax) rp->qmax = q[i];
+      if (rp->nsampled < 4096) { /* sample for the offset guess */
+        rp->nsampled++;
+        for (size_t i = 0; i < (qn < 64 ? qn : 64); i++) {
+          if (q[i] < rp->qmin) rp->qmin = q[i];
+          if (q[i] > rp->qmax) rp->qmax = q[i];
+        }
       }
       batch_append(b, s, n, rp->want_quals ? q : NULL);
       batch_close_read(b); added++;
@@ -197,7 +201,7 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
 
   /* probe: the first records must have the regular structure */
   {
-    range_parser rp = {base, base + (size < (4u << 20) ? size : (4u << 20)), fmt, false, 1u << 20, 255, 0, false};
+    range_parser rp = {base, base + (size < (4u << 20) ? size : (4u << 20)), fmt, false, 1u << 20, 255, 0, false, 0};
     read_batch b;
     read_batch_init(&b, false);
     range_fill(&rp, &b);
@@ -217,7 +221,7 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
     const unsigned char *next = t + 1 == nthreads ? base + size : find_record(base, size, size / (size_t)nthreads * (size_t)(t + 1), fmt);
     if (next < prev) next = prev;
     w->ctx = &c;
-    w->rp = (range_parser){prev, next, fmt, want_quals, batch_bases, 255, 0, false};
+    w->rp = (range_parser){prev, next, fmt, want_quals, batch_bases, 255, 0, false, 0};
     w->ready = -1;
     for (int i = 0; i < 2; i++) { /* sized for a whole batch up front: no realloc growth while parsing */
       read_batch *b = &w->batch[i];
