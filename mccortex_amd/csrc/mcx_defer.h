@@ -614,9 +614,10 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
 #pragma unroll
     for (int j = kBucket - 1; j >= 0; j--) {
       if (k[j] == 0) empty = j;
-      if ((k[j] & ~kPending) == want) {
-        if (W == 1) hit = j;
-        else if (k[j] & kPending) retry = true;  // its owner has not published word 1 yet
+      if (W == 1) {  // (no pending state for one-word keys: compare as is)
+        if (k[j] == want) hit = j;
+      } else if ((k[j] & ~kPending) == want) {
+        if (k[j] & kPending) retry = true;  // its owner has not published word 1 yet
         else if (__hip_atomic_load(bp + j * R + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1]) hit = j;
       }
     }
