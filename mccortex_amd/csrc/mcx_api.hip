@@ -861,15 +861,13 @@ extern "C" uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_
 {
   if (!g) return 0;
   const uint32_t lbq = g->t.lb1 + g->t.lbo;
-  uint32_t r = 0, b = 0, c;
+  uint32_t r = 0, m;
   if (g->W == 1) {
-    Kmer<1> q = key_quot<1>(Kmer<1>{{key_words[0]}}, lbq, r);
-    c = kmer_hash<1>(q, 0, &b);
+    m = region_mix<1>(key_quot<1>(Kmer<1>{{key_words[0]}}, lbq, r));
   } else {
-    Kmer<2> q = key_quot<2>(Kmer<2>{{key_words[0], key_words[1]}}, lbq, r);
-    c = kmer_hash<2>(q, 0, &b);
+    m = region_mix<2>(key_quot<2>(Kmer<2>{{key_words[0], key_words[1]}}, lbq, r));
   }
-  return (r ^ (c & ((1u << lbq) - 1u))) >> g->t.lb1;
+  return (r ^ (m & ((1u << lbq) - 1u))) >> g->t.lb1;
 }
 
 extern "C" uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts)

@@ -214,11 +214,9 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
       if (W == 2) tq.w[W - 1] = L.skey[q * W + 1];
       const uint32_t e = (uint32_t)(tq.w[0] >> 56);
       const Kmer<W> qq = tuple_q<W>(tq);
-      uint32_t hb;
-      const uint32_t c = kmer_hash<W>(qq, 0, &hb);
       const uint32_t lbq = lbq_of(isink.t);
       if (SH == 2) {  // BIN_GLOBAL ... appended to the owner's overflow bin (full format)
-        const Kmer<W> key = key_unquot<W>(qq, lbq, b ^ (c & ((1u << lbq) - 1u)));
+        const Kmer<W> key = key_unquot<W>(qq, lbq, b ^ (region_mix<W>(qq) & ((1u << lbq) - 1u)));
         const uint32_t owner = b >> bs.lb1;
         const unsigned long long pos = atomicAdd(&out.ov_counts[owner], 1ULL);
         if (pos < out.ov_cap) {
@@ -231,7 +229,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
         }
       } else {                      // ... lock-free insert into the HBM table
         const uint32_t region = bs.mode == BIN_GROUP ? b : region_of_seg;
-        const Kmer<W> key = key_unquot<W>(qq, lbq, r_of(isink.t, region, c));
+        const Kmer<W> key = key_unquot<W>(qq, lbq, r_of<W>(isink.t, region, qq));
         const uint64_t slot = key_slot<W>(isink.t, key);
         const uint64_t cur = *key_ptr_t<W, ONECOL>(isink.t, slot);
         probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
@@ -387,11 +385,10 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
             tk[j] = key;
             tle[j] = (local << 8) | e;
           } else {
-            uint32_t r, hb;
+            uint32_t r;
             const uint32_t lbq = lbq_of(isink.t);
             const Kmer<W> q = key_quot<W>(key, lbq, r);
-            const uint32_t c = kmer_hash<W>(q, 0, &hb);
-            const uint32_t G = r ^ (c & ((1u << lbq) - 1u));  // (owner, region) of the key
+            const uint32_t G = r ^ (region_mix<W>(q) & ((1u << lbq) - 1u));  // (owner, region) of the key
             local = SH == 2 ? G : (G & ((1u << isink.t.lb1) - 1u));
             tk[j] = tuple_pack<W>(q, e);
             tle[j] = local << 8;
@@ -540,8 +537,8 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
         const uint32_t lbq = lbq_of(isink.t);
         const Kmer<W> key = tk[q];
         const Kmer<W> qq = key_quot<W>(key, lbq, r);
-        const uint32_t c = kmer_hash<W>(qq, 0, &hb);
-        const uint32_t G = r ^ (c & ((1u << lbq) - 1u));
+        const uint32_t G = r ^ (region_mix<W>(qq) & ((1u << lbq) - 1u));
+        hb = 0;
         loc[q] = G & lmask;
         tk[q] = tuple_pack<W>(qq, ev[q]);
         if (SHARD && (okm >> q & 1u) && (G >> isink.t.lb1) != isink.t.part) {
@@ -802,7 +799,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
           const Kmer<W> qq = tuple_q<W>(tk[q]);
           uint32_t hb;
           const uint32_t c = kmer_hash<W>(qq, 0, &hb);
-          const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), r_of(t, region, c));
+          const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), r_of<W>(t, region, qq));
           lds_apply<W>(lds, key, (c >> lbq_of(t)) & (Sub<W>::kBuckets - 1), e, n_novel, full);
         }
     };

@@ -73,18 +73,27 @@ template <int W, bool ONECOL> __device__ __forceinline__ uint64_t *val_ptr_t(con
 }
 
 // ---------------------------------------------------------------------------
-// Table addressing: a quotient hash built on Lookup3
+// Table addressing: a quotient hash; Lookup3 picks the sub-table and the bucket
 // ---------------------------------------------------------------------------
-// key = (q << lbq) | r with lbq = lb1 + lbo.  With (c, b) = lookup3(q) (the reference's bklk3
-// hash, both result words):
-//     G       = r ^ (c & (2^lbq - 1))            one Feistel round: uniform whatever r is
+// key = (q << lbq) | r with lbq = lb1 + lbo.
+//     G       = r ^ (mix(q) & (2^lbq - 1))       one Feistel round: uniform whatever r is
 //     owner   = G >> lb1                         shard (GPU) that holds the key: a hash prefix
 //     region  = G & (2^lb1 - 1)                  region of that shard's table
+// and with (c, b) = lookup3(q) (the reference's bklk3 hash, both result words):
 //     sub     = region * spb + mulhi(b, spb)     sub-table
 //     bucket  = (c >> lbq) & 1023                start bucket inside the sub-table
-// Given (owner, region), r = G ^ (c & mask) is recoverable from q alone, so a k-mer occurrence
+// mix(q) is the upper half of q times an odd constant (5 instructions): the region is needed by
+// the k-merising kernel, which is bound by its instruction count, while the kernels that need
+// sub-table and bucket have VALU to spare for Lookup3 (24 instructions).
+// Given (owner, region), r = G ^ (mix(q) & mask) is recoverable from q alone, so a k-mer occurrence
 // that has been binned by region travels as q plus its edge byte in ONE 64-bit word per key
 // word (2k - lbq <= 56 bits of q in the top word, edges in bits 56..63) -- mcx_defer.h.
+template <int W> __device__ __host__ __forceinline__ uint32_t region_mix(const Kmer<W> &q)
+{
+  uint64_t x = q.w[0] * 0x9E3779B97F4A7C15ULL;
+  if (W == 2) x ^= q.w[W - 1] * 0xC2B2AE3D27D4EB4FULL;
+  return (uint32_t)(x >> 32);
+}
 template <int W> __device__ __host__ __forceinline__ Kmer<W> key_quot(const Kmer<W> &key, uint32_t lb1 /* bits to split off */, uint32_t &r)
 {
   Kmer<W> q = key;
@@ -116,16 +125,16 @@ template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t
   const uint32_t c = kmer_hash<W>(q, 0, &b);
   const uint32_t lbq = lbq_of(t);
   TableAddr a;
-  a.G = r ^ (c & ((1u << lbq) - 1u));
+  a.G = r ^ (region_mix<W>(q) & ((1u << lbq) - 1u));
   a.region = a.G & ((1u << t.lb1) - 1u);
   a.sub = a.region * t.spb + __umulhi(b, t.spb);
   a.bucket = (c >> lbq) & (Sub<W>::kBuckets - 1);
   return a;
 }
-// remainder of a key of THIS shard from its quotient hash word c and its region
-__device__ __forceinline__ uint32_t r_of(const TableView &t, uint32_t region, uint32_t c)
+// remainder of a key of THIS shard from its quotient and its region
+template <int W> __device__ __forceinline__ uint32_t r_of(const TableView &t, uint32_t region, const Kmer<W> &q)
 {
-  return ((t.part << t.lb1) | region) ^ (c & ((1u << lbq_of(t)) - 1u));
+  return ((t.part << t.lb1) | region) ^ (region_mix<W>(q) & ((1u << lbq_of(t)) - 1u));
 }
 template <int W> __device__ __forceinline__ uint64_t key_slot(const TableView &t, const Kmer<W> &key)
 {

@@ -257,11 +257,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, 
           uint32_t e = 0;
           if (next_ok) e |= 1u << (nuc_next + 4u * o);
           if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
-          uint32_t r, hb;
+          uint32_t r;
           const uint32_t lbq = lbq_of(isink.t);
           const Kmer<W> q = key_quot<W>(key, lbq, r);
-          const uint32_t c = kmer_hash<W>(q, 0, &hb);
-          const uint32_t G = r ^ (c & ((1u << lbq) - 1u));
+          const uint32_t G = r ^ (region_mix<W>(q) & ((1u << lbq) - 1u));
           const uint32_t local = G & ((1u << isink.t.lb1) - 1u);
           tk[j] = tuple_pack<W>(q, e);
           tle[j] = local << 8;
