@@ -598,14 +598,25 @@ template <int W>
 __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W> &key, uint32_t bucket, uint32_t e,
                                           uint32_t &n_novel, uint32_t &full)
 {
+  // LDS image of a bucket.  One-word keys: the four keys first, then the four values
+  // (k0 k1 k2 k3 | v0 v1 v2 v3), so that a probe reads the keys with two 16-byte loads.  Two-word
+  // keys: slot after slot (key word 0, key word 1, value).
   constexpr int R = W + 1;
+  constexpr int KS = W == 1 ? 1 : R;              // words between the first key words of two slots
   const unsigned long long want = key.w[0] | kFlag;
   uint32_t b = bucket, steps = 0;
   for (;;) {
     unsigned long long *bp = lds + (size_t)b * (kBucket * R);
     unsigned long long k[kBucket];
+    if (W == 1) {
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      const u64x2 k01 = *reinterpret_cast<const volatile u64x2 *>(bp);      // (volatile: re-read on every step)
+      const u64x2 k23 = *reinterpret_cast<const volatile u64x2 *>(bp + 2);
+      k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
+    } else {
 #pragma unroll
-    for (int j = 0; j < kBucket; j++) k[j] = __hip_atomic_load(bp + j * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int j = 0; j < kBucket; j++) k[j] = __hip_atomic_load(bp + j * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     int hit = -1, empty = -1;
     bool retry = false;
 #pragma unroll
@@ -619,7 +630,7 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
       }
     }
     if (hit >= 0) {
-      unsigned long long *val = bp + hit * R + W;
+      unsigned long long *val = W == 1 ? bp + kBucket + hit : bp + hit * R + W;
       const unsigned long long old = atomicAdd(val, 256ULL);
       if (e & ~(uint32_t)old) atomicOr(val, (unsigned long long)e);
       return;
@@ -629,7 +640,8 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
       continue;
     }
     if (empty >= 0) {
-      unsigned long long *r = bp + empty * R;
+      unsigned long long *r = bp + empty * KS;
+      unsigned long long *val = W == 1 ? bp + kBucket + empty : r + W;
       const unsigned long long desired = (W == 1) ? want : (want | kPending);
       if (atomicCAS(r, 0ULL, desired) == 0) {
         if (W == 2) {
@@ -637,8 +649,8 @@ __device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W>
           __hip_atomic_store(r, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         n_novel++;
-        atomicAdd(r + W, 256ULL);
-        if (e) atomicOr(r + W, (unsigned long long)e);
+        atomicAdd(val, 256ULL);
+        if (e) atomicOr(val, (unsigned long long)e);
         return;
       }
       if (++steps > (1u << 22)) { full = 1; return; }
@@ -695,13 +707,16 @@ template <int W, bool ONECOL, int T>
 __device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, const SliceRegs &v)
 {
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
-  if (ONECOL) {
+  if (ONECOL && W == 1) {  // vector q * T + tid = slot s = (key, value) -> bucket image k0..k3 | v0..v3
+#define MCX_ST(m, q) { const uint32_t sl = (uint32_t)(q * T + tid); unsigned long long *bp = lds + (size_t)(sl >> 2) * 8 + (sl & 3u); bp[0] = v.m.x; bp[4] = v.m.y; }
+    MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5) MCX_ST(g, 6) MCX_ST(h, 7)
+#undef MCX_ST
+  } else if (ONECOL) {
 #define MCX_ST(m, q) dst[q * T + tid] = make_ulonglong2(v.m.x, v.m.y);
     MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5)
-    if (W == 1) { MCX_ST(g, 6) MCX_ST(h, 7) }
 #undef MCX_ST
-  } else if (W == 1) {  // slots 2p, 2p + 1 = vectors 2p, 2p + 1: {key, value}
-#define MCX_PUT1(q, kv, vv) { const int p = q * T + tid; dst[2 * p] = make_ulonglong2(kv.x, vv.x); dst[2 * p + 1] = make_ulonglong2(kv.y, vv.y); }
+  } else if (W == 1) {  // slots 2p, 2p + 1 share a bucket: their keys are one vector, their values another
+#define MCX_PUT1(q, kv, vv) { const uint32_t p = (uint32_t)(q * T + tid); ulonglong2 *bq = dst + (size_t)(p >> 1) * 4 + (p & 1u); bq[0] = make_ulonglong2(kv.x, kv.y); bq[2] = make_ulonglong2(vv.x, vv.y); }
     MCX_PUT1(0, v.a, v.e) MCX_PUT1(1, v.b, v.f) MCX_PUT1(2, v.c, v.g) MCX_PUT1(3, v.d, v.h)
 #undef MCX_PUT1
   } else {              // slots 2p, 2p + 1 = 6 words = vectors 3p .. 3p + 2: k0a k0b | v0 k1a | k1b v1
@@ -717,7 +732,15 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
 {
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(lds);
   const uint64_t s0 = (uint64_t)sub * Sub<W>::kSlots;
-  if (ONECOL) {
+  if (ONECOL && W == 1) {
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(t.rec + s0 * 2);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t sl = (uint32_t)(q * T + tid);
+      const unsigned long long *bp = lds + (size_t)(sl >> 2) * 8 + (sl & 3u);
+      dst[sl] = make_ulonglong2(bp[0], bp[4]);
+    }
+  } else if (ONECOL) {
     ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(t.rec + s0 * (W + 1));
     constexpr int PER = (int)(Sub<W>::kSlots * (W + 1) * 8 / 16 / T);
 #pragma unroll
@@ -727,10 +750,10 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
     ulonglong2 *V = reinterpret_cast<ulonglong2 *>(t.val + (uint64_t)col * t.VC + s0);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int p = q * T + tid;
-      const ulonglong2 x = src[2 * p], y = src[2 * p + 1];
-      K[p] = make_ulonglong2(x.x, y.x);
-      V[p] = make_ulonglong2(x.y, y.y);
+      const uint32_t p = (uint32_t)(q * T + tid);
+      const ulonglong2 *bq = src + (size_t)(p >> 1) * 4 + (p & 1u);
+      K[p] = bq[0];
+      V[p] = bq[2];
     }
   } else {
     ulonglong2 *K = reinterpret_cast<ulonglong2 *>(t.rec + s0 * 2);
