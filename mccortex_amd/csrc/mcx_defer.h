@@ -820,10 +820,9 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
         if (i0 + (uint64_t)q * kLdsThreads < n) {  // packed tuple + region -> full key, start bucket
           const uint32_t e = (uint32_t)(tk[q].w[0] >> 56);
           const Kmer<W> qq = tuple_q<W>(tk[q]);
-          uint32_t hb;
-          const uint32_t c = kmer_hash<W>(qq, 0, &hb);
-          const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), r_of<W>(t, region, qq));
-          lds_apply<W>(lds, key, (c >> lbq_of(t)) & (Sub<W>::kBuckets - 1), e, n_novel, full);
+          const uint32_t m = region_mix<W>(qq);
+          const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), ((t.part << t.lb1) | region) ^ (m & ((1u << lbq_of(t)) - 1u)));
+          lds_apply<W>(lds, key, (m >> lbq_of(t)) & (Sub<W>::kBuckets - 1), e, n_novel, full);
         }
     };
     {  // first batch of tuple loads, THEN the next slice: loads return in order, so the first

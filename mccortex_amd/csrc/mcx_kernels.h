@@ -76,15 +76,16 @@ template <int W, bool ONECOL> __device__ __forceinline__ uint64_t *val_ptr_t(con
 // Table addressing: a quotient hash; Lookup3 picks the sub-table and the bucket
 // ---------------------------------------------------------------------------
 // key = (q << lbq) | r with lbq = lb1 + lbo.
-//     G       = r ^ (mix(q) & (2^lbq - 1))       one Feistel round: uniform whatever r is
+//     m       = mix(q)                           upper half of q times an odd constant (5 instructions)
+//     G       = r ^ (m & (2^lbq - 1))            one Feistel round: uniform whatever r is
 //     owner   = G >> lb1                         shard (GPU) that holds the key: a hash prefix
 //     region  = G & (2^lb1 - 1)                  region of that shard's table
-// and with (c, b) = lookup3(q) (the reference's bklk3 hash, both result words):
+//     bucket  = (m >> lbq) & 1023                start bucket inside the sub-table
+// and with b = second result word of lookup3(q) (the reference's bklk3 hash):
 //     sub     = region * spb + mulhi(b, spb)     sub-table
-//     bucket  = (c >> lbq) & 1023                start bucket inside the sub-table
-// mix(q) is the upper half of q times an odd constant (5 instructions): the region is needed by
-// the k-merising kernel, which is bound by its instruction count, while the kernels that need
-// sub-table and bucket have VALU to spare for Lookup3 (24 instructions).
+// The k-merising kernel (needs the region) and the LDS insert (needs r and the bucket) are bound by
+// their instruction counts; the split kernel, which needs the sub-table, is HBM-bound and has VALU
+// to spare for the 24 instructions of Lookup3.
 // Given (owner, region), r = G ^ (mix(q) & mask) is recoverable from q alone, so a k-mer occurrence
 // that has been binned by region travels as q plus its edge byte in ONE 64-bit word per key
 // word (2k - lbq <= 56 bits of q in the top word, edges in bits 56..63) -- mcx_defer.h.
@@ -122,13 +123,13 @@ struct TableAddr { uint32_t G, region, sub, bucket; };
 template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t, const Kmer<W> &q, uint32_t r)
 {
   uint32_t b;
-  const uint32_t c = kmer_hash<W>(q, 0, &b);
-  const uint32_t lbq = lbq_of(t);
+  kmer_hash<W>(q, 0, &b);
+  const uint32_t lbq = lbq_of(t), m = region_mix<W>(q);
   TableAddr a;
-  a.G = r ^ (region_mix<W>(q) & ((1u << lbq) - 1u));
+  a.G = r ^ (m & ((1u << lbq) - 1u));
   a.region = a.G & ((1u << t.lb1) - 1u);
   a.sub = a.region * t.spb + __umulhi(b, t.spb);
-  a.bucket = (c >> lbq) & (Sub<W>::kBuckets - 1);
+  a.bucket = (m >> lbq) & (Sub<W>::kBuckets - 1);
   return a;
 }
 // remainder of a key of THIS shard from its quotient and its region
