@@ -45,6 +45,10 @@ typedef struct {
   uint64_t contigs_parsed;
   uint64_t num_kmers_loaded;    /* k-mer occurrences inserted */
   uint64_t num_kmers_novel;     /* occurrences that created a new node */
+  /* --remove-pcr only (mcx_graph_add_reads_pcr) */
+  uint64_t num_pe_reads;        /* reads loaded as mates of a pair */
+  uint64_t num_dup_se_reads;    /* single reads dropped as PCR duplicates */
+  uint64_t num_dup_pe_pairs;    /* pairs dropped as PCR duplicates */
 } mcx_load_stats;
 
 typedef struct mcx_graph mcx_graph;
@@ -122,6 +126,30 @@ int mcx_graph_add_reads(mcx_graph *g, int colour,
                         const uint64_t *read_offsets, uint64_t nreads,
                         uint8_t fq_cutoff_abs, uint8_t hp_cutoff,
                         mcx_load_stats *stats_accum);
+
+/* The same step with prefs.remove_pcr_dups (`build --remove-pcr`): replaces
+ * build_graph_from_reads_mt (src/tools/build_graph.c:192-231) + seq_reads_are_novel (:28-92).
+ *   paired         != 0: reads 2i and 2i + 1 are the two mates of pair i (a --seq2 / --seqi
+ *                  task); 0: single reads (--seq)
+ *   matedir        0 FF, 1 FR, 2 RF, 3 RR (cortex_types.h:18-25): mates are turned to FF and
+ *                  loaded that way (seq_reader_orient_mp_FF, src/basic/seq_reader.c:506-510);
+ *                  a single read is reverse-complemented for RF / RR
+ *   fq_cutoff_abs1/2  the cutoff of the first / second mate's file (single reads: the first)
+ * A read (pair) is dropped when the first k-mer of (each of) its read(s) is the start, in the same
+ * orientation, of a read (pair) loaded before it -- earlier in this batch or in an earlier call.
+ * The reference's outcome depends on the order in which its worker threads reach the reads; this
+ * gives the outcome of walking the reads in input order on one thread.  The start k-mers of
+ * dropped reads stay in the graph, as in the reference.  num_pe_reads / num_se_reads,
+ * total_bases_read and the duplicate counts are added to stats_accum; the call returns when the
+ * filter has run (it is synchronous).  Costs 8 bytes of HBM per table slot while in use. */
+int mcx_graph_add_reads_pcr(mcx_graph *g, int colour,
+                            const uint8_t *bases, const uint8_t *quals,
+                            const uint64_t *read_offsets, uint64_t nreads,
+                            uint8_t fq_cutoff_abs1, uint8_t fq_cutoff_abs2, uint8_t hp_cutoff,
+                            int paired, int matedir, mcx_load_stats *stats_accum);
+/* Forget all read starts: the reference wipes dBGraph.readstrt whenever the colour being loaded
+ * changes (src/commands/ctx_build.c:392-395). */
+int mcx_graph_pcr_reset(mcx_graph *g);
 
 /* Device-resident variant of the same step: `d_stream` is a byte stream in HBM
  * in which reads are separated by at least one byte that is not one of

@@ -731,10 +731,11 @@ __global__ void k_count_flags(const unsigned char *flags, uint64_t n, Counters *
 }
 
 // -Q/-H path: a read is good iff it produced at least one contig byte
-__global__ void k_count_sizes(const uint64_t *sizes, uint64_t n, Counters *ctr)
+__global__ void k_count_sizes(const uint64_t *sizes, const uint8_t *keep, uint64_t n, Counters *ctr)
 {
   unsigned long long good = 0, bad = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (keep && !keep[i]) continue;  // a filtered duplicate is neither (load_read never sees it)
     if (sizes[i]) good++; else bad++;
   }
   if (good) atomicAdd(&ctr->good_reads, good);
@@ -790,12 +791,17 @@ __device__ inline uint64_t qh_contig_end(const uint8_t *seq, uint64_t len, const
   return end;
 }
 
+// (--remove-pcr: mates 2i / 2i + 1 carry their own cutoff, pmask = 1; reads with keep[r] == 0 were
+// filtered out and emit nothing)
 __global__ void k_qh_contigs(const uint8_t *bases, const uint8_t *quals, const uint64_t *off, uint64_t nreads,
-                             int k, uint32_t qcut, uint32_t hcut, int pass, uint64_t *out_sizes,
+                             int k, uint32_t qcut1, uint32_t qcut2, uint32_t pmask, uint32_t hcut,
+                             const uint8_t *keep, int pass, uint64_t *out_sizes,
                              const uint64_t *out_off, uint8_t *out_stream)
 {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nreads) return;
+  if (keep && !keep[r]) { if (!pass) out_sizes[r] = 0; return; }
+  const uint32_t qcut = ((uint32_t)r & pmask) ? qcut2 : qcut1;
   const uint8_t *seq = bases + off[r];
   const uint8_t *qual = (quals && qcut > 0) ? quals + off[r] : nullptr;
   const uint64_t len = off[r + 1] - off[r];
@@ -809,6 +815,104 @@ __global__ void k_qh_contigs(const uint8_t *bases, const uint8_t *quals, const u
     w += ce - cs + 1;
   }
   if (!pass) out_sizes[r] = w;
+}
+
+// ---------------------------------------------------------------------------
+// build --remove-pcr: seq_reads_are_novel (src/tools/build_graph.c:28-92)
+// ---------------------------------------------------------------------------
+// The reference keeps a "read starts here" bit per (node, orientation) and drops a read (pair)
+// whose first k-mer(s) all carry the bit already; otherwise it sets the bits and loads the
+// read(s).  A read that meets a node whose bit is clear is always kept, so the bit of a node is
+// set by the FIRST read (pair) of the input that starts at it: with T(n) = the index of that
+// read, read i is a duplicate iff T(n) < i for each of its start nodes.  T is an atomicMin, which
+// makes the filter a parallel one that gives exactly the result of the reference walking the
+// reads in input order on one thread.  `first[2 * slot + orient]`: 0 = set by an earlier batch,
+// 0xFFFFFFFF = clear, else 1 + the index (in this batch) of the first read (pair) that starts there.
+
+// seq_reader_orient_mp_FF (src/basic/seq_reader.c:506-510): r1 is reverse-complemented when
+// matedir & 2, r2 when matedir & 1 (cortex_types.h:18-25) -- in place, qualities reversed.
+__global__ void k_pcr_orient(uint8_t *bases, uint8_t *quals, const uint64_t *off, uint64_t nreads, uint32_t pmask, uint32_t matedir)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  const bool flip = ((uint32_t)r & pmask) ? (matedir & 1u) : (matedir & 2u);
+  if (!flip) return;
+  uint8_t *s = bases + off[r];
+  uint8_t *q = quals ? quals + off[r] : nullptr;
+  const uint64_t len = off[r + 1] - off[r];
+  auto comp = [](uint8_t c) -> uint8_t {  // A<->T, C<->G keeping the case; anything else stays
+    return base_valid(c) ? (uint8_t)(c ^ (((c & 0x1f) == 1 || (c & 0x1f) == 20) ? 0x15 : 0x04)) : c;
+  };
+  for (uint64_t i = 0; i < len - i; i++) {
+    const uint64_t j = len - 1 - i;
+    const uint8_t a = comp(s[i]), b = comp(s[j]);
+    s[i] = b; s[j] = a;  // (i == j: complemented once)
+    if (q) { const uint8_t t = q[i]; q[i] = q[j]; q[j] = t; }
+  }
+}
+
+constexpr uint64_t kNoNode = ~0ULL;
+// one lane per read: first k-mer of its first contig -> node (created if new, coverage untouched:
+// db_graph_find_or_add_node_mt, build_graph.c:66-76) and T(node) = min(T(node), 1 + read (pair) index)
+template <int W>
+__global__ void k_pcr_starts(TableView t, const uint8_t *bases, const uint8_t *quals, const uint64_t *off, uint64_t nreads,
+                             int k, uint32_t qcut1, uint32_t qcut2, uint32_t pmask, uint32_t hcut,
+                             uint32_t *first, uint64_t *node_of, Counters *ctr)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  const uint32_t qcut = ((uint32_t)r & pmask) ? qcut2 : qcut1;
+  const uint8_t *seq = bases + off[r];
+  const uint8_t *qual = (quals && qcut > 0) ? quals + off[r] : nullptr;
+  const uint64_t len = off[r + 1] - off[r];
+  const uint64_t cs = qh_contig_start(seq, len, qual, 0, (uint64_t)k, qcut, hcut);
+  uint64_t node = kNoNode;
+  if (cs < len) {
+    const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
+    Kmer<W> fw;
+    fw.w[0] = 0; if (W == 2) fw.w[W - 1] = 0;
+    for (uint64_t i = cs; i < cs + (uint64_t)k; i++) {
+      const uint32_t nuc = ((seq[i] >> 1) ^ (seq[i] >> 2)) & 3u;
+      if (W == 1) fw.w[0] = ((fw.w[0] << 2) | nuc) & top_mask;
+      else { fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask; fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc; }
+    }
+    const Kmer<W> rc = revcomp<W>(fw, k);
+    uint32_t o, novel = 0, full = 0;
+    const Kmer<W> key = canonical<W>(fw, rc, o);
+    const uint64_t slot = find_or_insert_rec<W>(t, key, false, novel, full);
+    if (novel) atomicAdd(&ctr->novel, 1ULL);
+    if (full) atomicAdd(&ctr->full, 1ULL);
+    if (slot != kNoSlot) {
+      node = 2 * slot + o;
+      atomicMin(first + node, (uint32_t)(r >> (pmask ? 1 : 0)) + 1u);
+    }
+  }
+  node_of[r] = node;
+}
+
+// one lane per read (pair): duplicate iff every start node it has was claimed by an earlier read
+// (pair) (build_graph.c:78-84; a read (pair) without any k-mer counts as a duplicate there too)
+__global__ void k_pcr_decide(const uint64_t *node_of, const uint32_t *first, uint64_t nunits, uint32_t pmask,
+                             uint8_t *keep, unsigned long long *ndup)
+{
+  const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long dup = 0;
+  if (u < nunits) {
+    const uint32_t me = (uint32_t)u + 1u;
+    const uint64_t r0 = pmask ? 2 * u : u;
+    const uint64_t n1 = node_of[r0], n2 = pmask ? node_of[r0 + 1] : kNoNode;
+    dup = (n1 == kNoNode || first[n1] < me) && (n2 == kNoNode || first[n2] < me);
+    keep[r0] = (uint8_t)!dup;
+    if (pmask) keep[r0 + 1] = (uint8_t)!dup;
+  }
+  block_add(ndup, dup);
+}
+
+// the start nodes of this batch now carry the bit for every later batch
+__global__ void k_pcr_commit(const uint64_t *node_of, uint64_t nreads, uint32_t *first)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nreads && node_of[r] != kNoNode) first[node_of[r]] = 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -16,7 +16,7 @@ SYMBOLS = [
     "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_kmer_covg", "mcx_graph_covg_histogram", "mcx_sort_records",
     "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_superk_supported", "mcx_superk_owner", "mcx_graph_checksum", "mcx_records_checksum",
     "mcx_graph_superk_layout", "mcx_graph_superk_bins_dev", "mcx_graph_add_superk_dev", "mcx_graph_destroy",
-    "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_stream_dev",
+    "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_reads_pcr", "mcx_graph_pcr_reset", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
     "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash",
@@ -33,7 +33,8 @@ class LoadStats(C.Structure):
     """mcx_load_stats (subset of the reference's SeqLoadingStats)."""
     _fields_ = [(n, C.c_uint64) for n in (
         "num_se_reads", "num_good_reads", "num_bad_reads", "total_bases_read",
-        "total_bases_loaded", "contigs_parsed", "num_kmers_loaded", "num_kmers_novel")]
+        "total_bases_loaded", "contigs_parsed", "num_kmers_loaded", "num_kmers_novel",
+        "num_pe_reads", "num_dup_se_reads", "num_dup_pe_pairs")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -106,6 +107,9 @@ def lib():
     L.mcx_graph_profile.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.mcx_graph_add_reads.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint64, C.c_uint8, C.c_uint8,
                                       C.POINTER(LoadStats)]
+    L.mcx_graph_add_reads_pcr.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint64, C.c_uint8, C.c_uint8, C.c_uint8,
+                                          C.c_int, C.c_int, C.POINTER(LoadStats)]
+    L.mcx_graph_pcr_reset.argtypes = [vp]
     L.mcx_graph_add_stream_dev.argtypes = [vp, C.c_int, vp, C.c_uint64]
     L.mcx_graph_partition_stream_dev.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp, vp, vp]
     L.mcx_graph_insert_tuples_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
@@ -228,6 +232,24 @@ class Graph:
         _check(self.L.mcx_graph_add_reads(self.h, colour, _ptr(bases), _ptr(quals), _ptr(offsets),
                                           len(offsets) - 1, fq_cutoff, hp_cutoff, C.byref(st)))
         return st
+
+    MATEDIR = {"FF": 0, "FR": 1, "RF": 2, "RR": 3}
+
+    def add_reads_pcr(self, colour, bases, offsets, quals=None, fq_cutoff=0, fq_cutoff2=None, hp_cutoff=0,
+                      paired=False, matedir="FR", stats=None):
+        """`build --remove-pcr` over one batch (reads 2i, 2i + 1 are mates when `paired`)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        st = stats if stats is not None else LoadStats()
+        _check(self.L.mcx_graph_add_reads_pcr(self.h, colour, _ptr(bases), _ptr(quals), _ptr(offsets), len(offsets) - 1,
+                                              fq_cutoff, fq_cutoff if fq_cutoff2 is None else fq_cutoff2, hp_cutoff,
+                                              1 if paired else 0, self.MATEDIR.get(matedir, matedir), C.byref(st)))
+        return st
+
+    def pcr_reset(self):
+        _check(self.L.mcx_graph_pcr_reset(self.h))
 
     def superk_layout(self, nparts, positions_per_call):
         segs, cap = C.c_uint32(), C.c_uint64()

@@ -56,8 +56,8 @@ static const char build_usage[] =
 "  Note: Argument must come before input file\n"
 "  --sample <name> is required before sequence input can be loaded.\n"
 "  Consecutive sequence options are loaded into the same colour.\n"
-"  This build runs the graph construction on an MI355X: --remove-pcr and SAM/BAM/CRAM\n"
-"  input are not available; -m/-n size the table in HBM.\n"
+"  This build runs the graph construction on an MI355X: SAM/BAM/CRAM input is not\n"
+"  available; -m/-n size the table in HBM.\n"
 "\n";
 
 static struct option longopts[] = {
@@ -74,9 +74,11 @@ static struct option longopts[] = {
   {NULL, 0, NULL, 0}};
 
 typedef struct {
-  char *path;
+  char *path, *path2;   /* path2: second mate file of a --seq2 task kept paired (--remove-pcr) */
   int colour;
   uint8_t fq_cutoff, fq_offset, hp_cutoff;
+  bool remove_pcr, interleaved; /* interleaved: --seqi with --remove-pcr, reads 2i / 2i+1 are mates */
+  int matedir;          /* 0 FF, 1 FR, 2 RF, 3 RR (cortex_types.h:18-21) */
   mcx_load_stats stats;
   seq_fmt fmt;
 } build_task;
@@ -114,7 +116,7 @@ static void check_sample_name(const char *s)
   }
 }
 
-static void add_task(const char *path, int colour, uint8_t fq_cutoff, uint8_t fq_offset, uint8_t hp)
+static build_task *add_task(const char *path, int colour, uint8_t fq_cutoff, uint8_t fq_offset, uint8_t hp)
 { /* add_task: ctx_build.c:99-117 */
   if (fq_offset >= 128) die("fq-offset too big: %i", (int)fq_offset);
   if (fq_offset + fq_cutoff >= 128) die("fq-cutoff too big: %i", fq_offset + fq_cutoff);
@@ -124,6 +126,7 @@ static void add_task(const char *path, int colour, uint8_t fq_cutoff, uint8_t fq
   t->path = strdup(path); t->colour = colour;
   t->fq_cutoff = fq_cutoff; t->fq_offset = fq_offset; t->hp_cutoff = hp;
   if (strcmp(path, "-") != 0 && access(path, R_OK) != 0) die("Cannot open -1 file: %s", path);
+  return t;
 }
 
 static long file_size(const char *path)
@@ -216,6 +219,70 @@ static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
   submit_calls++;
 }
 
+/* --remove-pcr task: reads go to the GPU in input order, mates side by side
+ * (build_graph_from_reads_mt with prefs.remove_pcr_dups, build_graph.c:192-231) */
+static uint8_t fq_abs_of(const build_task *bt, seq_in *in)
+{ /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 */
+  if (!bt->fq_cutoff || seq_in_format(in) != SEQ_FMT_FASTQ) return 0;
+  int off = bt->fq_offset ? bt->fq_offset : seq_in_guess_fq_offset(in);
+  if (!off) off = 33;
+  return (uint8_t)(bt->fq_cutoff + off);
+}
+
+static void load_task_pcr(mcx_graph *g, build_task *bt)
+{
+  seq_in *in1 = seq_in_open(bt->path), *in2 = NULL;
+  if (!in1) die("Cannot open -1 file: %s", bt->path);
+  if (bt->path2 && !(in2 = seq_in_open(bt->path2))) die("Cannot open -2 file: %s", bt->path2);
+  const bool paired = in2 != NULL || bt->interleaved;
+  const bool use_q = bt->fq_cutoff > 0 && (seq_in_format(in1) == SEQ_FMT_FASTQ || (in2 && seq_in_format(in2) == SEQ_FMT_FASTQ));
+  read_batch b1, b2, both;
+  read_batch_init(&b1, use_q); read_batch_init(&b2, use_q); read_batch_init(&both, use_q);
+  for (;;) {
+    const size_t got1 = seq_in_fill(in1, &b1, BATCH_BASES);
+    read_batch *send = &b1;
+    if (in2) { /* zip the two files: pair i = read i of each */
+      const size_t got2 = seq_in_fill(in2, &b2, BATCH_BASES);
+      const size_t n = b1.nreads < b2.nreads ? b1.nreads : b2.nreads;
+      if (!got1 && !got2 && n == 0) {
+        if (b1.nreads != b2.nreads) die("Different number of reads in paired files: %s, %s", bt->path, bt->path2);
+        break;
+      }
+      read_batch_clear(&both);
+      for (size_t i = 0; i < n; i++) { read_batch_append(&both, &b1, i); read_batch_append(&both, &b2, i); }
+      /* keep the unpaired tail of the longer batch for the next round */
+      read_batch *bs[2] = {&b1, &b2};
+      for (int m = 0; m < 2; m++) {
+        read_batch *b = bs[m], tmp;
+        read_batch_init(&tmp, use_q);
+        for (size_t i = n; i < b->nreads; i++) read_batch_append(&tmp, b, i);
+        read_batch_free(b); *b = tmp;
+      }
+      send = &both;
+      if (!n) continue;
+    } else if (!got1 && !b1.nreads) {
+      break;
+    } else if (bt->interleaved && (b1.nreads & 1)) { /* hold the odd read back for its mate */
+      if (!got1) die("Odd number of reads in interleaved file: %s", bt->path);
+      read_batch_clear(&both);
+      for (size_t i = 0; i + 1 < b1.nreads; i++) read_batch_append(&both, &b1, i);
+      read_batch tmp;
+      read_batch_init(&tmp, use_q);
+      read_batch_append(&tmp, &b1, b1.nreads - 1);
+      read_batch_free(&b1); b1 = tmp;
+      send = &both;
+      if (!send->nreads) continue;
+    }
+    const uint8_t fq1 = use_q ? fq_abs_of(bt, in1) : 0, fq2 = use_q ? (in2 ? fq_abs_of(bt, in2) : fq1) : 0;
+    mcx_check(mcx_graph_add_reads_pcr(g, bt->colour, send->bases, use_q ? send->quals : NULL, send->offsets, send->nreads,
+                                      fq1, fq2, bt->hp_cutoff, paired ? 1 : 0, bt->matedir, &bt->stats), "add reads");
+    if (send == &b1) read_batch_clear(&b1);
+  }
+  read_batch_free(&b1); read_batch_free(&b2); read_batch_free(&both);
+  seq_in_close(in1);
+  if (in2) seq_in_close(in2);
+}
+
 /* file_filter_status: file_filter.c:170-192 */
 static void filter_status(const ctx_reader *r)
 {
@@ -296,7 +363,7 @@ int ctx_build(int argc, char **argv)
   bool mem_set = false, nkmers_set = false, force = false, sort_kmers = false;
   bool sample_named = false, pref_unused = false, remove_pcr = false;
   uint8_t fq_offset = 0, fq_cutoff = 0, hp_cutoff = 0;
-  int intocolour = -1, device = 0, c;
+  int intocolour = -1, device = 0, c, matedir = 1 /* FR: build_graph.h:38-42 */;
   char cmd[100];
 
   /* '+': stop at the first non-option; single-dash long options accepted (cmd.c:87-102, ctx_build.c:149) */
@@ -341,21 +408,29 @@ int ctx_build(int argc, char **argv)
       case '1': case '2': case 'i':
         pref_unused = false;
         if (!sample_named) usage_die("Please give sample name first [-s,--sample <name>]");
-        if (remove_pcr) die("--remove-pcr is not available in this build (order-dependent CPU filter, src/tools/build_graph.c:35-92)");
-        if (c == '2') { /* <in1>:<in2> (or a comma): loaded as two single-ended files (ctx_build.c:105-116) */
+        if (c == '2') { /* <in1>:<in2> (or a comma) */
           char *sep = strchr(optarg, ':');
           if (!sep) sep = strchr(optarg, ',');
           if (!sep || strchr(sep + 1, ':')) die("Expected -2 <in1>:<in2>");
           *sep = '\0';
-          add_task(optarg, intocolour, fq_cutoff, fq_offset, hp_cutoff);
-          add_task(sep + 1, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+          build_task *bt = add_task(optarg, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+          if (remove_pcr) { /* mates stay together (ctx_build.c:105-107) */
+            if (strcmp(sep + 1, "-") != 0 && access(sep + 1, R_OK) != 0) die("Cannot open -2 file: %s", sep + 1);
+            bt->path2 = strdup(sep + 1);
+          } else { /* loaded as two single-ended files (ctx_build.c:108-116) */
+            add_task(sep + 1, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+          }
+          bt->remove_pcr = remove_pcr; bt->matedir = matedir;
         } else {
-          add_task(optarg, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+          build_task *bt = add_task(optarg, intocolour, fq_cutoff, fq_offset, hp_cutoff);
+          bt->remove_pcr = remove_pcr; bt->matedir = matedir;
+          bt->interleaved = remove_pcr && c == 'i';
         }
         break;
       case 'M':
         if (strcmp(optarg, "FF") && strcmp(optarg, "FR") && strcmp(optarg, "RF") && strcmp(optarg, "RR"))
           die("-M,--matepair <orient> must be one of: FF,FR,RF,RR");
+        matedir = (optarg[0] == 'R' ? 2 : 0) | (optarg[1] == 'R' ? 1 : 0); /* READPAIR_*: cortex_types.h:18-21 */
         pref_unused = true; break;
       case 'O': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int 0 <= x < 255: %s", cmd, optarg);
         fq_offset = (uint8_t)u; pref_unused = true; break;
@@ -419,25 +494,31 @@ int ctx_build(int argc, char **argv)
         bt->fmt = seq_in_format(probe);
         seq_in_close(probe);
       }
-      status("[task] %s; FASTQ offset: %s, threshold: %s; cut homopolymers: %s; colour: %i",
-             bt->path, bt->fq_offset ? "set" : "auto-detect", bt->fq_cutoff ? "on" : "off",
-             bt->hp_cutoff ? "on" : "off", bt->colour);
-      long fs = file_size(bt->path);
-      if (fs < 0) size_unknown = true;
-      else max_kmers += (size_t)(bt->fmt == SEQ_FMT_FASTQ ? fs / 2 : fs) * 5;
+      char fqo[30] = "auto-detect", fqc[30] = "off", hpc[30] = "off"; /* build_graph_task_print: build_graph.c:332-350 */
+      if (bt->fq_offset > 0) sprintf(fqo, "%u", bt->fq_offset);
+      if (bt->fq_cutoff > 0) sprintf(fqc, "%u", bt->fq_cutoff);
+      if (bt->hp_cutoff > 0) sprintf(hpc, "%u", bt->hp_cutoff);
+      status("[task] %s%s%s; FASTQ offset: %s, threshold: %s; cut homopolymers: %s; remove PCR duplicates: %s; colour: %i\n",
+             bt->path, bt->path2 ? ", " : "", bt->path2 ? bt->path2 : "", fqo, fqc, hpc, bt->remove_pcr ? "yes" : "no", bt->colour);
+      long fs = file_size(bt->path), fs2 = bt->path2 ? file_size(bt->path2) : 0;
+      if (fs < 0 || fs2 < 0) size_unknown = true;
+      else max_kmers += (size_t)(bt->fmt == SEQ_FMT_FASTQ ? (fs + fs2) / 2 : fs + fs2) * 5;
       t++;
     }
   }
   if (size_unknown) max_kmers = SIZE_MAX;
   if (ngisec > 0) { /* ctx_build.c:291-303: reads and graphs can only touch k-mers of the intersection */
-    if (remove_pcr) usage_die("Cannot use --remove-pcr and --intersect");
+    for (size_t t = 0; t < ntasks; t++) if (tasks[t].remove_pcr) usage_die("Cannot use --remove-pcr and --intersect");
     max_kmers = 0;
     for (size_t i = 0; i < ngisec; i++) max_kmers += (size_t)gisec[i].num_kmers;
   }
 
   /* ---- decide on memory (ctx_build.c:305-322, cmd_mem.c:38-130) ---- */
   const size_t W = (2 * kmer_size + 63) / 64;
-  size_t bits_per_kmer = W * 64 + (4 + 1) * 8 * ncols + (ngisec > 0 ? 8 : 0) + (sort_kmers ? 64 : 0);
+  bool remove_pcr_used = false; /* ctx_build.c:260-261 */
+  for (size_t t = 0; t < ntasks; t++) remove_pcr_used |= tasks[t].remove_pcr;
+  /* remove_pcr_dups requires a fw and rv bit per kmer (ctx_build.c:310-315) */
+  size_t bits_per_kmer = W * 64 + (4 + 1) * 8 * ncols + (ngisec > 0 ? 8 : 0) + (remove_pcr_used ? 2 : 0) + (sort_kmers ? 64 : 0);
   uint64_t kmers_in_hash = 0;
   size_t graph_mem = 0;
   char s1[64], s2[64];
@@ -463,7 +544,7 @@ int ctx_build(int argc, char **argv)
   uint64_t hbm_free = 0, hbm_total = 0;
   mcx_check(mcx_device_memory(device, &hbm_free, &hbm_total), "device query");
   const size_t dev_cols = ncols + (ngisec > 0 ? 1 : 0); /* + the hidden colour of the intersection edges */
-  const uint64_t dev_bytes = kmers_in_hash * 8 * (W + dev_cols);
+  const uint64_t dev_bytes = kmers_in_hash * 8 * (W + dev_cols + (remove_pcr_used ? 1 : 0)); /* + the read-start table */
   if (dev_bytes > hbm_free)
     die("Requesting more memory than is available [ Reqeusted: %s HBM free: %s ]",
         bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_free, 1, s2));
@@ -516,7 +597,10 @@ int ctx_build(int argc, char **argv)
      * path declines go through the sequential parser */
     submit_ctx sc = {g, bt, bt->fq_cutoff > 0 && bt->fmt == SEQ_FMT_FASTQ, 0};
     int prc = 1;
-    if (nthreads > 1 && strcmp(bt->path, "-") != 0)
+    /* the read-start bits are wiped when the colour changes (ctx_build.c:389-395) */
+    if (remove_pcr_used && t > 0 && bt->colour != tasks[t - 1].colour) mcx_check(mcx_graph_pcr_reset(g), "pcr reset");
+    if (bt->remove_pcr) { load_task_pcr(g, bt); prc = 0; }
+    else if (nthreads > 1 && strcmp(bt->path, "-") != 0)
       prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, getenv("MCX_PAR_BATCH") ? (size_t)atol(getenv("MCX_PAR_BATCH")) : PAR_BATCH_BASES, submit_batch, &sc);
     if (prc == 2) die("Irregular %s record in %s (multi-line FASTQ?): rerun with -t 1", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
     if (prc == 1) {
@@ -560,9 +644,10 @@ int ctx_build(int argc, char **argv)
   for (size_t t = 0; t < ntasks; t++) {
     const mcx_load_stats *st = &tasks[t].stats;
     char a[64], b[64];
-    status("[task] input: %s colour: %i", tasks[t].path, tasks[t].colour);
-    status("  SE reads: %s  PE reads: 0", ulong_to_str(st->num_se_reads, a));
+    status("[task] input: %s%s%s colour: %i", tasks[t].path, tasks[t].path2 ? ", " : "", tasks[t].path2 ? tasks[t].path2 : "", tasks[t].colour);
+    status("  SE reads: %s  PE reads: %s", ulong_to_str(st->num_se_reads, a), ulong_to_str(st->num_pe_reads, b));
     status("  good reads: %s  bad reads: %s", ulong_to_str(st->num_good_reads, a), ulong_to_str(st->num_bad_reads, b));
+    status("  dup SE reads: %s  dup PE pairs: %s", ulong_to_str(st->num_dup_se_reads, a), ulong_to_str(st->num_dup_pe_pairs, b));
     status("  bases read: %s  bases loaded: %s", ulong_to_str(st->total_bases_read, a), ulong_to_str(st->total_bases_loaded, b));
     status("  num contigs: %s  num kmers: %s novel kmers: %s", ulong_to_str(st->contigs_parsed, a),
            ulong_to_str(st->num_kmers_loaded, b), ulong_to_str(st->num_kmers_novel, s1));
@@ -587,7 +672,7 @@ int ctx_build(int argc, char **argv)
   if (fout != stdout) fclose(fout);
   mcx_graph_destroy(g);
   stage_time("device released");
-  for (size_t t = 0; t < ntasks; t++) free(tasks[t].path);
+  for (size_t t = 0; t < ntasks; t++) { free(tasks[t].path); free(tasks[t].path2); }
   for (size_t i = 0; i < ncols; i++) col_info_free(&cols[i]);
   free(tasks); free(cols); free(sample_names); free(sample_cols); free(gfiles); free(gisec);
   return EXIT_SUCCESS;

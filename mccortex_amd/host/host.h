@@ -62,6 +62,7 @@ void read_batch_init(read_batch *b, bool want_quals);
 void read_batch_clear(read_batch *b);
 void read_batch_free(read_batch *b);
 size_t seq_in_fill(seq_in *s, read_batch *b, size_t max_bases);
+void read_batch_append(read_batch *dst, const read_batch *src, size_t i); /* read i of src */
 /* FASTQ offset guess from the qualities seen so far (33 or 64); 0 if no qualities */
 int seq_in_guess_fq_offset(const seq_in *s);
 

@@ -143,6 +143,19 @@ static void batch_end_read(read_batch *b)
   b->offsets[++b->nreads] = b->nbases;
 }
 
+void read_batch_append(read_batch *dst, const read_batch *src, size_t i)
+{
+  const size_t at = (size_t)src->offsets[i], n = (size_t)(src->offsets[i + 1] - src->offsets[i]);
+  batch_reserve(dst, n);
+  memcpy(dst->bases + dst->nbases, src->bases + at, n);
+  if (dst->want_quals) {
+    if (src->want_quals) memcpy(dst->quals + dst->nbases, src->quals + at, n);
+    else memset(dst->quals + dst->nbases, 0, n);
+  }
+  dst->nbases += n;
+  batch_end_read(dst);
+}
+
 size_t seq_in_fill(seq_in *s, read_batch *b, size_t max_bases)
 {
   size_t added = 0;

@@ -259,6 +259,8 @@ struct orc_graph {
   /* build --intersect (ctx_build.c:341-363,384-413) */
   uint8_t *isec_edges;  /* [capacity]: union of the intersection graphs' edges, NULL when not intersecting */
   int must_exist;       /* BuildGraphTask.prefs.must_exist_in_graph */
+  /* build --remove-pcr: dBGraph.readstrt, one bit per (slot, orientation) (db_graph.c:62-63) */
+  uint8_t *readstrt;
 };
 
 orc_graph *orc_graph_new(int k, int ncols, uint64_t capacity_kmers, uint32_t seed)
@@ -287,7 +289,7 @@ void orc_graph_free(orc_graph *g)
 {
   if(!g) return;
   free(g->table); free(g->bsize); free((void *)g->locks); free(g->covgs); free(g->edges);
-  free(g->mean_read_length); free(g->total_sequence); free(g->sample); free(g->isec_edges);
+  free(g->mean_read_length); free(g->total_sequence); free(g->sample); free(g->isec_edges); free(g->readstrt);
   free(g);
 }
 
@@ -578,6 +580,99 @@ int orc_graph_add_reads(orc_graph *g, int colour, const char *bases, const char 
   }
   if(stats_accum) for(t = 0; t < nthreads; t++) stats_merge(stats_accum, &jobs[t].st);
   free(jobs); free(th);
+  return g->full ? -1 : 0;
+}
+
+/* ---- build --remove-pcr -------------------------------------------------- */
+/* seq_read_reverse_complement lives in the third-party seq_file library (libs/seq_file, an empty
+ * submodule in the checkout): reverse the bases and qualities, complement A<->T, C<->G in either
+ * case; every other byte splits contigs whatever it becomes, so it is left as it is. */
+static void read_revcomp(char *seq, char *qual, size_t len)
+{
+  static const char from[] = "ACGTacgt", to[] = "TGCAtgca";
+  size_t i;
+  for(i = 0; i < len; i++) { const char *p = seq[i] ? strchr(from, seq[i]) : NULL; if(p) seq[i] = to[p - from]; }
+  for(i = 0; i + 1 < len - i; i++) {
+    char t = seq[i]; seq[i] = seq[len - 1 - i]; seq[len - 1 - i] = t;
+    if(qual) { t = qual[i]; qual[i] = qual[len - 1 - i]; qual[len - 1 - i] = t; }
+  }
+}
+
+/* ctx_build.c:392-395: the read-start bits are wiped when the colour being loaded changes */
+void orc_graph_pcr_reset(orc_graph *g)
+{
+  if(g->readstrt) memset(g->readstrt, 0, (size_t)((2 * g->capacity + 7) / 8));
+}
+
+static inline int readstrt_get(const orc_graph *g, orc_node n)
+{ uint64_t b = 2 * n.hkey + (uint64_t)n.orient; return (g->readstrt[b >> 3] >> (b & 7)) & 1; }
+static inline void readstrt_set(orc_graph *g, orc_node n)
+{ uint64_t b = 2 * n.hkey + (uint64_t)n.orient; g->readstrt[b >> 3] |= (uint8_t)(1u << (b & 7)); }
+
+/* the contigs of one read, without the per-read counters of the caller (build_graph.c:154-189) */
+static void load_read_contigs(orc_graph *g, int colour, const char *seq, size_t len, const char *qual,
+                              uint8_t fq_cutoff, uint8_t hp_cutoff, orc_stats *st)
+{
+  orc_stats tmp; memset(&tmp, 0, sizeof(tmp));
+  load_read(g, colour, seq, len, qual, fq_cutoff, hp_cutoff, &tmp);
+  tmp.total_bases_read = 0; tmp.num_se_reads = 0;
+  stats_merge(st, &tmp);
+}
+
+/* build_graph_from_reads_mt with prefs.remove_pcr_dups (build_graph.c:192-231) over a batch, in
+ * read order on one thread (the reference's filter depends on the order in which its workers
+ * reach the reads).  paired: reads 2i and 2i + 1 are mates.  matedir: 0 FF, 1 FR, 2 RF, 3 RR
+ * (cortex_types.h:18-25).  The mates are turned to FF first and are LOADED in that orientation
+ * (seq_reader_orient_mp_FF, seq_reader.c:506-510, called at build_graph.c:49).
+ * counts[0] += duplicate SE reads, counts[1] += duplicate pairs, counts[2] += reads seen as pairs. */
+int orc_graph_add_reads_pcr(orc_graph *g, int colour, const char *bases, const char *quals,
+                            const uint64_t *offsets, uint64_t nreads, uint8_t fq_cutoff1, uint8_t fq_cutoff2,
+                            uint8_t hp_cutoff, int paired, int matedir, orc_stats *st, uint64_t *counts)
+{
+  if(colour < 0 || colour >= g->ncols || (paired && (nreads & 1))) return -2;
+  if(!g->readstrt) g->readstrt = calloc((size_t)((2 * g->capacity + 7) / 8), 1);
+  const size_t k = (size_t)g->k;
+  const uint64_t step = paired ? 2 : 1;
+  uint64_t r;
+  int m;
+  for(r = 0; r < nreads && !g->full; r += step) {
+    char *seq[2] = {NULL, NULL}, *qual[2] = {NULL, NULL};
+    size_t len[2] = {0, 0};
+    const uint8_t fq[2] = {fq_cutoff1, fq_cutoff2};
+    const int nm = paired ? 2 : 1;
+    for(m = 0; m < nm; m++) {
+      len[m] = (size_t)(offsets[r + m + 1] - offsets[r + m]);
+      seq[m] = malloc(len[m] + 1); memcpy(seq[m], bases + offsets[r + m], len[m]); seq[m][len[m]] = 0;
+      if(quals) { qual[m] = malloc(len[m] + 1); memcpy(qual[m], quals + offsets[r + m], len[m]); qual[m][len[m]] = 0; }
+      st->total_bases_read += len[m];
+    }
+    if(paired) counts[2] += 2; else st->num_se_reads += 1; /* build_graph.c:211-212 */
+    /* seq_reads_are_novel, build_graph.c:35-92 */
+    if(matedir & 2) read_revcomp(seq[0], qual[0], len[0]);            /* read_mate_r1 */
+    if(paired && (matedir & 1)) read_revcomp(seq[1], qual[1], len[1]); /* read_mate_r2 */
+    int got[2] = {0, 0}, found;
+    orc_node node[2];
+    uint64_t novel = 0;
+    for(m = 0; m < nm; m++) {
+      size_t start = orc_contig_start(seq[m], len[m], qual[m], qual[m] ? len[m] : 0, 0, k, fq[m], hp_cutoff);
+      got[m] = start < len[m];
+      if(got[m]) { /* db_graph_find_or_add_node_mt: the node is created, its coverage is not touched */
+        orc_bkmer bk = orc_kmer_from_str(seq[m] + start, g->k), key = orc_kmer_get_key(bk, g->k);
+        node[m].hkey = find_or_insert(g, &key, &found);
+        node[m].orient = bkmer_eq(&key, &bk, g->W) ? 0 : 1;
+        if(node[m].hkey == ORC_NOT_FOUND) { g->full = 1; got[m] = 0; break; }
+        novel += !found;
+      }
+    }
+    st->num_kmers_novel += novel;
+    int dup = (!got[0] || readstrt_get(g, node[0])) && (!got[1] || readstrt_get(g, node[1]));
+    if(dup) counts[paired ? 1 : 0] += 1;
+    else {
+      for(m = 0; m < nm; m++) if(got[m]) readstrt_set(g, node[m]);
+      for(m = 0; m < nm; m++) load_read_contigs(g, colour, seq[m], len[m], qual[m], fq[m], hp_cutoff, st);
+    }
+    for(m = 0; m < nm; m++) { free(seq[m]); free(qual[m]); }
+  }
   return g->full ? -1 : 0;
 }
 

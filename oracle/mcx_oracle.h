@@ -67,6 +67,14 @@ int orc_graph_add_reads(orc_graph *g, int colour, const char *bases, const char 
                         uint8_t fq_cutoff, uint8_t hp_cutoff, int nthreads,
                         orc_stats *stats_accum);
 
+/* build --remove-pcr: build_graph_from_reads_mt with prefs.remove_pcr_dups (build_graph.c:28-92,
+ * 192-231), in read order on one thread.  paired: reads 2i, 2i+1 are mates; matedir 0 FF, 1 FR,
+ * 2 RF, 3 RR.  counts[0] += duplicate SE reads, [1] += duplicate pairs, [2] += reads seen as pairs. */
+int orc_graph_add_reads_pcr(orc_graph *g, int colour, const char *bases, const char *quals,
+                            const uint64_t *offsets, uint64_t nreads, uint8_t fq_cutoff1, uint8_t fq_cutoff2,
+                            uint8_t hp_cutoff, int paired, int matedir, orc_stats *stats_accum, uint64_t *counts);
+void orc_graph_pcr_reset(orc_graph *g); /* ctx_build.c:392-395 */
+
 /* graph_info.c:172-175 (called once per input file, in task order) */
 void orc_graph_update_stats(orc_graph *g, int colour, const orc_stats *stats);
 

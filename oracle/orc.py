@@ -92,6 +92,10 @@ def lib():
     L.orc_graph_add_isec_record.restype = C.c_int
     L.orc_graph_add_isec_record.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint8]
     L.orc_graph_isec_finish.argtypes = [C.c_void_p]
+    L.orc_graph_add_reads_pcr.restype = C.c_int
+    L.orc_graph_add_reads_pcr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                          C.c_uint8, C.c_uint8, C.c_uint8, C.c_int, C.c_int, C.POINTER(Stats), C.c_void_p]
+    L.orc_graph_pcr_reset.argtypes = [C.c_void_p]
     L.orc_tuples.restype = C.c_uint64
     L.orc_tuples.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                              C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p]
@@ -158,6 +162,25 @@ class Graph:
         if rc != 0:
             raise RuntimeError("Hash table is full" if rc == -1 else "oracle error %d" % rc)
         return st
+
+    MATEDIR = {"FF": 0, "FR": 1, "RF": 2, "RR": 3}
+
+    def add_reads_pcr(self, colour, bases, offsets, quals=None, fq_cutoff=0, fq_cutoff2=None, hp_cutoff=0,
+                      paired=False, matedir="FR", stats=None):
+        """build --remove-pcr over a batch, in read order; returns (stats, [dup SE reads, dup pairs, PE reads])"""
+        st = stats if stats is not None else Stats()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        counts = np.zeros(3, dtype=np.uint64)
+        rc = self.L.orc_graph_add_reads_pcr(self.h, colour, _ptr(bases), _ptr(quals), _ptr(offsets), len(offsets) - 1,
+                                            fq_cutoff, fq_cutoff if fq_cutoff2 is None else fq_cutoff2, hp_cutoff,
+                                            1 if paired else 0, self.MATEDIR.get(matedir, matedir), C.byref(st), _ptr(counts))
+        if rc != 0:
+            raise RuntimeError("Hash table is full" if rc == -1 else "oracle error %d" % rc)
+        return st, [int(x) for x in counts]
+
+    def pcr_reset(self):
+        self.L.orc_graph_pcr_reset(self.h)
 
     def add_record(self, key_words, covgs, edges, must_exist=False):
         """graph_load's per-record body: colours already mapped onto this graph's (ncols entries)"""

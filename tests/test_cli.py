@@ -49,7 +49,9 @@ def test_usage_and_argument_errors(built, tmp_path):
         (["build", "-k", "31", "-s", "a b", "--seq", str(fa), "o.ctx"], "whitespace"),
         (["build", "-k", "31", "-s", "a", "--seq", str(tmp_path / "missing.fa"), "o.ctx"], "Cannot open"),
         (["build", "-k", "31", "-m", "12XB", "-s", "a", "--seq", str(fa), "o.ctx"], "Invalid memory argument"),
-        (["build", "-k", "31", "-s", "a", "-p", "--seq", str(fa), "o.ctx"], "--remove-pcr is not available"),
+        (["build", "-k", "31", "-s", "a", "-p", "--seq", str(fa), "o.ctx"], "remove PCR duplicates: yes"),
+        (["build", "-k", "31", "-s", "a", "-p", "--seq2", str(fa) + ":" + str(tmp_path / "missing.fa"), "o.ctx"], "Cannot open -2 file"),
+        (["build", "-k", "31", "-s", "a", "-M", "XX", "--seq", str(fa), "o.ctx"], "must be one of: FF,FR,RF,RR"),
         (["build", "-k", "31", "-s", "a", "--bogus", "o.ctx"], "Bad option"),
     ]
     for args, msg in cases:
@@ -240,3 +242,61 @@ def test_parallel_ingest_matches_sequential_and_oracle(built, orc, tmp_path):
     rc, _, err = run(31, "build", "-f", "-t", "4", "-k", "31", "-n", "4M", "-S", "-s", "s", "--seq", str(ml), out)
     assert rc == 0, err
     assert open(out, "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_build_remove_pcr(built, orc, tmp_path):
+    """--remove-pcr with single, paired (--seq2) and interleaved (--seqi) inputs, --keep-pcr in between,
+    a second colour (read starts wiped, ctx_build.c:389-395): whole file against the restatement"""
+    k = 31
+    g = synth.genome(800, 5)
+    b1, o1 = synth.reads(3000, 100, seed=1, g=g, n_frac=0.05)          # mates 1
+    b2, o2 = synth.reads(3000, 100, seed=2, g=g, n_frac=0.05)          # mates 2
+    b3, o3 = synth.reads(2000, 80, seed=3, g=g, lower_frac=0.2)        # single reads
+    rng = np.random.default_rng(4)
+    q1 = rng.integers(40, 74, len(b1)).astype(np.uint8)
+    q2 = rng.integers(40, 74, len(b2)).astype(np.uint8)
+    f1 = _write_inputs(tmp_path, b1, o1, "m1", "fq", qual=q1)
+    f2 = _write_inputs(tmp_path, b2, o2, "m2", "fq", qual=q2, gz=True)
+    f3 = _write_inputs(tmp_path, b3, o3, "se", "fa")
+    # interleaved file: m1[0], m2[0], m1[1], ...
+    n = len(o1) - 1
+    reads = []
+    for i in range(n):
+        reads.append(bytes(b1[int(o1[i]):int(o1[i + 1])]))
+        reads.append(bytes(b2[int(o2[i]):int(o2[i + 1])]))
+    bi, oi = orc.pack_reads(reads)
+    fi = _write_inputs(tmp_path, bi, oi, "il", "fa")
+    out = str(tmp_path / "pcr.ctx")
+    rc, _, err = run(31, "build", "-k", str(k), "-n", "64K", "--sort", "-Q", "10", "-O", "33", "-H", "7",
+                     "--sample", "a", "--remove-pcr", "--seq", f3, "--matepair", "FR", "--seq2", f1 + ":" + f2,
+                     "--keep-pcr", "--seq", f3, "--sample", "b", "--remove-pcr", "-M", "RF", "--seqi", fi, "--seq", f3, out)
+    assert rc == 0, err
+    assert "remove PCR duplicates: yes" in err and "dup SE reads:" in err
+    og = orc.Graph(k, 2, 1 << 16)
+    og.set_sample(0, "a"); og.set_sample(1, "b")
+    # colour 0: single reads (FASTA: no qualities), then the pairs with qualities, then the same single reads unfiltered
+    st, d0 = og.add_reads_pcr(0, b3, o3, hp_cutoff=7, matedir="FR")
+    og.update_stats(0, st)
+    bp, op = orc.pack_reads([r for i in range(n) for r in (bytes(b1[int(o1[i]):int(o1[i + 1])]), bytes(b2[int(o2[i]):int(o2[i + 1])]))])
+    qp = np.frombuffer(b"".join(bytes(x) for i in range(n) for x in (q1[int(o1[i]):int(o1[i + 1])], q2[int(o2[i]):int(o2[i + 1])])), np.uint8)
+    st, d1 = og.add_reads_pcr(0, bp, op, quals=qp, fq_cutoff=43, hp_cutoff=7, paired=True, matedir="FR")
+    og.update_stats(0, st)
+    st = og.add_reads(0, b3, o3, hp_cutoff=7)
+    og.update_stats(0, st)
+    # colour 1: read starts forgotten
+    og.pcr_reset()
+    st, d2 = og.add_reads_pcr(1, bi, oi, hp_cutoff=7, paired=True, matedir="RF")
+    og.update_stats(1, st)
+    st, d3 = og.add_reads_pcr(1, b3, o3, hp_cutoff=7, matedir="RF")
+    og.update_stats(1, st)
+    assert d0[0] > 0 and d1[1] > 0 and d2[1] > 0 and d3[0] > 0
+    for d in (d0[0], d3[0]):
+        assert "dup SE reads: %s  dup PE pairs: 0" % format(d, ",") in err
+    for d in (d1[1], d2[1]):
+        assert "dup SE reads: 0  dup PE pairs: %s" % format(d, ",") in err
+    assert open(out, "rb").read() == og.ctx_bytes(True)
+    # mate files of different length are an error
+    short = _write_inputs(tmp_path, b1[:int(o1[10])], o1[:11], "short", "fa")
+    rc, _, err = run(31, "build", "-f", "-k", str(k), "-n", "64K", "-s", "a", "-p", "--seq2", f1 + ":" + short, out)
+    assert rc == 1 and "Different number of reads" in err

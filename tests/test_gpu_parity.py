@@ -47,7 +47,7 @@ def _compare(mcx, orc, k, ncols, jobs, cap=1 << 20, names=None, **kw):
             og.set_sample(c, n)
             hdr.names[c] = n
     for a, b in zip(gst, ost):
-        assert a.as_dict() == b.as_dict()
+        assert {f: v for f, v in a.as_dict().items() if f in b.as_dict()} == b.as_dict()  # (the duplicate counters are not the oracle's)
     assert g.nkmers == og.nkmers
     want = og.ctx_bytes(True)
     got = mcx.ctx_header_bytes(hdr) + g.export(True)

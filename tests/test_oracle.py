@@ -130,6 +130,48 @@ def test_reference_build_graph_kat(orc):
     assert total == 168 and abs(float(mean) - (168 / 6 + 0.5)) <= 0.5  # build_graph_tests.c:135-148
 
 
+def test_reference_pcr_duplicate_unit_test(orc):
+    """src/tests/build_graph_tests.c:19-148 replayed call by call through the restatement"""
+    import pcr_cases as pc
+    g = orc.Graph(pc.K, 1, 1024)
+    tot = orc.Stats()
+    dup_se = dup_pe = 0
+    for r1, r2, md, pcr, (c1, c2) in pc.STEPS:
+        b, o = orc.pack_reads([r1] if r2 is None else [r1, r2])
+        if pcr:
+            _, (dse, dpe, npe) = g.add_reads_pcr(0, b, o, fq_cutoff=pc.FQ_CUTOFF, hp_cutoff=pc.HP_CUTOFF,
+                                                 paired=r2 is not None, matedir=md, stats=tot)
+            dup_se += dse
+            dup_pe += dpe
+        else:
+            g.add_reads(0, b, o, fq_cutoff=pc.FQ_CUTOFF, hp_cutoff=pc.HP_CUTOFF, stats=tot)
+        for kmer, c in ((pc.K1, c1), (pc.K2, c2)):
+            if c is not None:
+                assert g.lookup(kmer)[0][0] == c, (r1, r2, md)
+    assert (dup_se, dup_pe) == (2, 6)  # the empty pair counts as a duplicate too (build_graph.c:78-84)
+    assert tot.total_bases_loaded == pc.TOTAL_SEQ and tot.contigs_parsed == pc.CONTIGS
+    g.update_stats(0, tot)
+    ctx = g.ctx_bytes(True)
+    mean, total = np.frombuffer(ctx[22:26], np.uint32)[0], np.frombuffer(ctx[26:34], np.uint64)[0]
+    assert total == pc.TOTAL_SEQ and abs(float(mean) - (pc.TOTAL_SEQ / pc.CONTIGS + 0.5)) <= 0.5  # :135-148
+
+
+def test_pcr_filter_order_and_reset(orc):
+    """first read at a start wins; the other strand is a different start; reset forgets (ctx_build.c:392-395)"""
+    g = orc.Graph(5, 2, 1024)
+    reads = ["ACGTTGCA", "ACGTTCCC", "TGCAACGT", "ACGTTGGG"]  # 0, 1, 3 start at ACGTT forward; 2 = revcomp of 0
+    b, o = orc.pack_reads(reads)
+    st, (dse, dpe, npe) = g.add_reads_pcr(0, b, o, matedir="FF")
+    assert (dse, dpe, npe) == (2, 0, 0) and st.num_se_reads == 4 and st.num_good_reads == 2
+    assert g.lookup("CGTTC") is None                   # read 1 was dropped
+    assert g.lookup("ACGTT")[0][0] == 2 and g.lookup("TGCAA")[0][0] == 2  # read 0 and its reverse complement
+    _, (dse, dpe, npe) = g.add_reads_pcr(0, b, o, matedir="FF")
+    assert dse == 4                                   # every start is taken now
+    g.pcr_reset()
+    _, (dse, dpe, npe) = g.add_reads_pcr(1, b, o, matedir="FF")
+    assert dse == 2 and g.lookup("ACGTT")[0][1] == 2
+
+
 def test_header_layout_kats(orc):
     g = orc.Graph(31, 1, 1024)
     g.set_sample(0, "abcde")
