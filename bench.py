@@ -214,36 +214,9 @@ def main():
     W = graph.W
 
     if sharded:
-        # Send and receive sets are double buffered: the sender kernel of step n+1 (handle's stream)
-        # overlaps with the RCCL all-to-all of step n (torch's stream) and with the owner-side
-        # kernel of step n-1.  Nothing here reads the graph, so nothing flushes it.
-        # v2: the sender bins packed tuples by (owner, region); every owner's block has a fixed
-        # size, so one all-to-all per buffer moves them with no count round trip and no host sync.
-        ntup = B * (READ_LEN - K + 1)
-        if use_v3:
-            # v3: the sender only computes minimizers and cuts the reads into per-owner records
-            # (16 bytes per run of <= 16 k-mers: ~2.3 B per occurrence on the links instead of 8.5);
-            # the owner k-merises what it receives.  Only filled parts travel, which costs one
-            # host read of the fills per step.
-            segs, seg_cap = graph.superk_layout(world, batches[0].numel())
-            send = [shard.SuperkExchange(world, segs, seg_cap, device) for _ in range(2)]
-            recv = [shard.SuperkExchange(world, segs, seg_cap, device) for _ in range(2)]
-        else:
-            segs, seg_cap, ov_cap = graph.shard_layout(ntup)
-            send = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
-            recv = [shard.BlockExchange(world, segs, seg_cap, ov_cap, W, device) for _ in range(2)]
-        filled = [torch.cuda.Event() for _ in range(2)]     # send[b] k-merised          (ext)
-        sent = [torch.cuda.Event() for _ in range(2)]       # send[b] -> recv[b] exchanged (torch)
-        consumed = [torch.cuda.Event() for _ in range(2)]   # recv[b] split by the owner  (ext)
-        cur = torch.cuda.current_stream()
-
-    def partition(i, buf, first):
-        with torch.cuda.stream(ext):
-            if not first:
-                ext.wait_event(sent[buf])       # the previous exchange out of this send set is over
-            send[buf].zero_counts()
-        send[buf].fill(graph, batches[i], batches[i].numel())
-        filled[buf].record(ext)
+        # partition -> all-to-all -> insert, double buffered (mccortex_amd/shard.py: ShardedInserter)
+        inserter = shard.ShardedInserter(graph, world, device, batches[0].numel(), use_v3,
+                                         max_tuples=B * (READ_LEN - K + 1))
 
     def run_steps(idx):
         idx = list(idx)
@@ -253,24 +226,10 @@ def main():
             for i in idx:
                 graph.add_stream_dev(0, batches[i], batches[i].numel())
             return
-        partition(idx[0], 0, True)
-        for n, i in enumerate(idx):
-            buf = n % 2
-            if n + 1 < len(idx):
-                partition(idx[n + 1], 1 - buf, n < 1)   # overlaps with the exchange below
-            cur.wait_event(filled[buf])
-            if n >= 2:
-                cur.wait_event(consumed[buf])           # recv[buf] is free again
-            got = send[buf].exchange_into(recv[buf])
-            sent[buf].record(cur)
-            ext.wait_event(sent[buf])
-            recv[buf].consume(graph, 0, got if use_v3 else ntup)
-            consumed[buf].record(ext)
-        ext.synchronize()
-        cur.synchronize()
-        for b in send:
-            if b.overflowed():
-                raise SystemExit("an exchange bin overflowed (occurrences lost): raise its capacity")
+        try:
+            inserter.insert(0, [(batches[i], batches[i].numel()) for i in idx])
+        except RuntimeError as e:
+            raise SystemExit(str(e))
 
     def fence():
         torch.cuda.synchronize()

@@ -164,6 +164,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   const uint32_t lb1_max = lbo ? std::min<uint32_t>(9, 11 - lbo) : 9;  // shards x regions <= 2048 sender bins
   while (lb1 < lb1_max && (2ull << lb1) <= nsub) lb1++;             // up to 512 regions ...
   while (lb1 < 11 && ((nsub + (1ull << lb1) - 1) >> lb1) > (uint64_t)kMaxBins) lb1++;  // ... more for huge tables
+  if (const char *e = getenv("MCX_LB1")) { const uint32_t v = (uint32_t)atoi(e); if (!lbo && v >= lb1 && v <= 11) lb1 = v; }  // experiments
   const uint64_t spb = (nsub + (1ull << lb1) - 1) >> lb1;
   nsub = spb << lb1;
   if (nsub >= (1ull << 31)) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }

@@ -178,6 +178,80 @@ class SuperkExchange:
         return bool((self.fills > self.seg_cap).any().item())
 
 
+class ShardedInserter:
+    """The N > 1 build step, shared by bench.py and the multi-GPU build tool (mgpu_build.py):
+    every rank cuts its own reads into per-owner bins (sender kernel, the graph's stream), one
+    all-to-all per step moves each bin to its owner (RCCL, torch's current stream) and the owner
+    inserts what it received (the graph's stream).  Send and receive sets are double buffered: the
+    sender kernel of step n+1 overlaps with the all-to-all of step n and with the owner-side
+    kernels of step n-1.  Nothing here reads the graph, so nothing flushes it.
+
+    Exchange format v3 (super-k-mer records, minimizer ownership, ordinary per-rank tables) when
+    `use_v3`; else v2 (packed tuples binned by (owner, region), the table sharded by quotient-hash
+    prefix: the graph must have been created with nparts = world, part = rank)."""
+
+    def __init__(self, graph, world, device, max_stream_bytes, use_v3, group=None, max_tuples=None):
+        self.graph, self.world, self.use_v3, self.group = graph, world, use_v3, group
+        self.max_stream_bytes = int(max_stream_bytes)
+        # k-mer occurrences one step can hold (<= its bytes): sizes the v2 blocks
+        self.max_tuples = int(max_tuples) if max_tuples is not None else self.max_stream_bytes
+        self.ext = torch.cuda.ExternalStream(graph.stream, device=device)
+        if use_v3:
+            # the sender only computes minimizers and cuts the reads into per-owner records (16
+            # bytes per run of <= 16 k-mers: ~2.3 B per occurrence on the links instead of 8.5);
+            # the owner k-merises what it receives.  Only filled parts travel, which costs one
+            # host read of the fills per step.
+            segs, seg_cap = graph.superk_layout(world, self.max_stream_bytes)
+            mk = lambda: SuperkExchange(world, segs, seg_cap, device)
+        else:
+            # every owner's block has a fixed size: one all-to-all per buffer, no count round trip
+            segs, seg_cap, ov_cap = graph.shard_layout(self.max_tuples)
+            mk = lambda: BlockExchange(world, segs, seg_cap, ov_cap, graph.W, device)
+        self.send = [mk() for _ in range(2)]
+        self.recv = [mk() for _ in range(2)]
+        self.filled = [torch.cuda.Event() for _ in range(2)]     # send[b] k-merised             (ext)
+        self.sent = [torch.cuda.Event() for _ in range(2)]       # send[b] -> recv[b] exchanged   (torch)
+        self.consumed = [torch.cuda.Event() for _ in range(2)]   # recv[b] split by the owner     (ext)
+        self.used = [False, False]                               # send[b] has been exchanged before
+
+    def _partition(self, stream, nbytes, buf):
+        if nbytes > self.max_stream_bytes:
+            raise ValueError("a step of %d bytes exceeds the %d the exchange buffers were sized for" % (nbytes, self.max_stream_bytes))
+        with torch.cuda.stream(self.ext):
+            if self.used[buf]:
+                self.ext.wait_event(self.sent[buf])   # the previous exchange out of this send set is over
+            self.send[buf].zero_counts()
+        self.send[buf].fill(self.graph, stream, nbytes)
+        self.filled[buf].record(self.ext)
+
+    def insert(self, colour, steps):
+        """steps: list of (device byte stream, nbytes), reads separated by a non-ACGT byte; EVERY
+        rank must pass the same number of steps (an empty one is (any tensor, 0))."""
+        steps = list(steps)
+        if not steps:
+            return
+        cur = torch.cuda.current_stream()
+        self._partition(steps[0][0], steps[0][1], 0)
+        for n, (stream, nbytes) in enumerate(steps):
+            buf = n % 2
+            if n + 1 < len(steps):
+                self._partition(steps[n + 1][0], steps[n + 1][1], 1 - buf)   # overlaps with the exchange below
+            cur.wait_event(self.filled[buf])
+            if self.used[buf]:
+                cur.wait_event(self.consumed[buf])       # recv[buf] is free again
+            got = self.send[buf].exchange_into(self.recv[buf], group=self.group)
+            self.sent[buf].record(cur)
+            self.used[buf] = True
+            self.ext.wait_event(self.sent[buf])
+            self.recv[buf].consume(self.graph, colour, got if self.use_v3 else self.max_tuples)
+            self.consumed[buf].record(self.ext)
+        self.ext.synchronize()
+        cur.synchronize()
+        for b in self.send:
+            if b.overflowed():
+                raise RuntimeError("an exchange bin overflowed (occurrences lost): raise its capacity")
+
+
 def merge_sorted_bodies(bodies, record_size, key_bytes):
     """N-way merge of per-rank sorted .ctx bodies (disjoint key sets) into one sorted body."""
     recs = [np.frombuffer(b, dtype=np.uint8).reshape(-1, record_size) for b in bodies if len(b)]
