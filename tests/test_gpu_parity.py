@@ -291,8 +291,12 @@ def test_sharded_table_compact_exchange(mcx, orc, k, nparts):
             rb.consume(graphs[o], 0, ntup // nparts)
             graphs[o].sync()
     og = orc.Graph(k, 1, 1 << 21)
+    ost = orc.Stats()
     for b, o in zip(all_b, all_o):
-        og.add_reads(0, b, o)
+        og.add_reads(0, b, o, stats=ost)
+    tot = [g.device_stats() for g in graphs]   # (v2 counts occurrences and contigs where the reads are k-merised)
+    for f in ("num_kmers_loaded", "contigs_parsed", "total_bases_loaded", "num_kmers_novel"):
+        assert sum(getattr(t, f) for t in tot) == getattr(ost, f), f
     want = og.ctx_bytes(True)[og.header_size():]
     bodies = []
     for p, g in enumerate(graphs):
@@ -339,8 +343,13 @@ def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
             st = graphs[r].device_stats()
             assert nrec * 16 < 5.0 * max(1, st.num_kmers_loaded) or nparts == 1
     og = orc.Graph(k, 1, 1 << 21)
+    ost = orc.Stats()
     for b, o in all_reads:
-        og.add_reads(0, b, o)
+        og.add_reads(0, b, o, stats=ost)
+    # the owners' counters add up to the whole input's (what the multi-GPU tool all-reduces for the header)
+    tot = [g.device_stats() for g in graphs]
+    for f in ("num_kmers_loaded", "contigs_parsed", "total_bases_loaded", "num_kmers_novel"):
+        assert sum(getattr(t, f) for t in tot) == getattr(ost, f), f
     bodies = []
     for p, g in enumerate(graphs):
         kk, cc, ee = g.records(True)
