@@ -1094,54 +1094,6 @@ extern "C" int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed)
   return MCX_OK;
 }
 
-// -Q / -H: contigs are cut on the device by the reference's own rules, written
-// out as a fresh separator stream and fed to the same front end.
-static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
-                        const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp)
-{
-  const uint64_t base0 = off[0], nb = off[nreads] - off[0];
-  uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_out = nullptr;
-  uint64_t *d_off = nullptr, *d_sizes = nullptr, *d_ooff = nullptr;
-  void *d_tmp = nullptr;
-  size_t tmp_bytes = 0;
-  std::vector<uint64_t> rel(nreads + 1);
-  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
-  HIP_TRY(hipMalloc((void **)&d_bases, nb + 16));
-  if (quals && fq > 0) HIP_TRY(hipMalloc((void **)&d_quals, nb + 16));
-  HIP_TRY(hipMalloc((void **)&d_off, (nreads + 1) * 8));
-  HIP_TRY(hipMalloc((void **)&d_sizes, (nreads + 1) * 8));
-  HIP_TRY(hipMalloc((void **)&d_ooff, (nreads + 1) * 8));
-  HIP_TRY(hipMemcpyAsync(d_bases, bases + base0, nb, hipMemcpyHostToDevice, g->stream));
-  if (d_quals) HIP_TRY(hipMemcpyAsync(d_quals, quals + base0, nb, hipMemcpyHostToDevice, g->stream));
-  HIP_TRY(hipMemcpyAsync(d_off, rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
-  HIP_TRY(hipMemsetAsync(d_sizes, 0, (nreads + 1) * 8, g->stream));
-  const unsigned blocks = (unsigned)((nreads + 127) / 128);
-  hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                     (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)fq, 0u, (uint32_t)hp, (const uint8_t *)nullptr, 0, d_sizes, (const uint64_t *)nullptr, (uint8_t *)nullptr);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
-  HIP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-  HIP_TRY(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
-  uint64_t out_bytes = 0;
-  HIP_TRY(hipMemcpyAsync(&out_bytes, d_ooff + nreads, 8, hipMemcpyDeviceToHost, g->stream));
-  HIP_TRY(hipStreamSynchronize(g->stream));
-  int rc = MCX_OK;
-  if (out_bytes) {
-    HIP_TRY(hipMalloc((void **)&d_out, out_bytes + 64));
-    HIP_TRY(hipMemsetAsync(d_out + out_bytes, '\n', 64, g->stream));
-    hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                       (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)fq, 0u, (uint32_t)hp, (const uint8_t *)nullptr, 1, d_sizes, (const uint64_t *)d_ooff, d_out);
-    HIP_TRY(hipGetLastError());
-    StreamLaunch SL{d_out, out_bytes, 0, out_bytes, nullptr};
-    rc = submit_stream(g, SL, colour);
-  }
-  hipLaunchKernelGGL(k_count_sizes, dim3(256), dim3(256), 0, g->stream, (const uint64_t *)d_sizes, (const uint8_t *)nullptr, nreads, g->d_ctr);
-  HIP_TRY(hipStreamSynchronize(g->stream));
-  (void)hipFree(d_bases); (void)hipFree(d_quals); (void)hipFree(d_off); (void)hipFree(d_sizes);
-  (void)hipFree(d_ooff); (void)hipFree(d_tmp); (void)hipFree(d_out);
-  return rc;
-}
-
 // ---------------------------------------------------------------------------
 // build --remove-pcr (build_graph_from_reads_mt with prefs.remove_pcr_dups, build_graph.c:192-231)
 // ---------------------------------------------------------------------------
@@ -1151,6 +1103,107 @@ extern "C" int mcx_graph_pcr_reset(mcx_graph *g)
   HIP_TRY(hipSetDevice(g->device));
   if (g->d_readstrt) HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
   return MCX_OK;
+}
+
+// Reads that need the reference's own contig rules (-Q / -H) and / or the duplicate filter: uploaded
+// whole (bases, qualities, offsets); the kept reads are cut into contigs on the device
+// (k_qh_contigs = seq_contig_start/end) and written out as a fresh separator stream for the
+// ordinary front end.  filter: run seq_reads_are_novel first (ndup = reads / pairs dropped).
+static int add_reads_cut(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                         uint64_t nreads, uint8_t fq_cutoff_abs1, uint8_t fq_cutoff_abs2, uint8_t hp_cutoff,
+                         bool filter, int paired, int matedir, unsigned long long *ndup)
+{
+  const uint64_t base0 = off[0], nb = off[nreads] - off[0];
+  const uint32_t pmask = paired ? 1u : 0u, fq1 = fq_cutoff_abs1, fq2 = fq_cutoff_abs2, hp = hp_cutoff;
+  const uint64_t nunits = paired ? nreads / 2 : nreads;
+  uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_out = nullptr, *d_keep = nullptr;
+  uint64_t *d_off = nullptr, *d_sizes = nullptr, *d_ooff = nullptr, *d_node = nullptr;
+  unsigned long long *d_ndup = nullptr, h_ndup = 0;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  auto cleanup = [&]() {
+    (void)hipFree(d_bases); (void)hipFree(d_quals); (void)hipFree(d_out); (void)hipFree(d_keep); (void)hipFree(d_off);
+    (void)hipFree(d_sizes); (void)hipFree(d_ooff); (void)hipFree(d_node); (void)hipFree(d_ndup); (void)hipFree(d_tmp);
+  };
+#define CUT_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      cleanup();                                                                          \
+      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    }                                                                                     \
+  } while (0)
+  std::vector<uint64_t> rel(nreads + 1);
+  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
+  const bool use_q = quals && (fq1 > 0 || fq2 > 0);
+  CUT_TRY(hipMalloc((void **)&d_bases, nb + 16));
+  if (use_q) CUT_TRY(hipMalloc((void **)&d_quals, nb + 16));
+  CUT_TRY(hipMalloc((void **)&d_off, (nreads + 1) * 8));
+  CUT_TRY(hipMalloc((void **)&d_sizes, (nreads + 1) * 8));
+  CUT_TRY(hipMalloc((void **)&d_ooff, (nreads + 1) * 8));
+  if (filter) {
+    CUT_TRY(hipMalloc((void **)&d_node, nreads * 8));
+    CUT_TRY(hipMalloc((void **)&d_keep, nreads));
+    CUT_TRY(hipMalloc((void **)&d_ndup, 8));
+  }
+  CUT_TRY(hipMemcpyAsync(d_bases, bases + base0, nb, hipMemcpyHostToDevice, g->stream));
+  if (d_quals) CUT_TRY(hipMemcpyAsync(d_quals, quals + base0, nb, hipMemcpyHostToDevice, g->stream));
+  CUT_TRY(hipMemcpyAsync(d_off, rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
+  CUT_TRY(hipMemsetAsync(d_sizes, 0, (nreads + 1) * 8, g->stream));
+  if (filter) CUT_TRY(hipMemsetAsync(d_ndup, 0, 8, g->stream));
+  const unsigned blocks = (unsigned)((nreads + 127) / 128), ublocks = (unsigned)((nunits + 255) / 256);
+  if (filter) {
+    SpanGuard sp(g, "k_pcr_filter");
+    if (matedir)
+      hipLaunchKernelGGL(k_pcr_orient, dim3(blocks), dim3(128), 0, g->stream, d_bases, d_quals, (const uint64_t *)d_off, nreads, pmask, (uint32_t)matedir);
+    if (g->W == 1)
+      hipLaunchKernelGGL((k_pcr_starts<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
+                         (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, g->d_readstrt, d_node, g->d_ctr);
+    else
+      hipLaunchKernelGGL((k_pcr_starts<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
+                         (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, g->d_readstrt, d_node, g->d_ctr);
+    hipLaunchKernelGGL(k_pcr_decide, dim3(ublocks), dim3(256), 0, g->stream, (const uint64_t *)d_node, (const uint32_t *)g->d_readstrt,
+                       nunits, pmask, d_keep, d_ndup);
+    hipLaunchKernelGGL(k_pcr_commit, dim3(blocks), dim3(128), 0, g->stream, (const uint64_t *)d_node, nreads, g->d_readstrt);
+  }
+  CUT_TRY(hipGetLastError());
+  // the kept reads, cut into contigs by the reference's rules, become a separator stream for the
+  // ordinary front end
+  hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
+                     (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, (const uint8_t *)d_keep, 0, d_sizes,
+                     (const uint64_t *)nullptr, (uint8_t *)nullptr);
+  CUT_TRY(hipGetLastError());
+  CUT_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
+  CUT_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  CUT_TRY(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
+  uint64_t out_bytes = 0;
+  CUT_TRY(hipMemcpyAsync(&out_bytes, d_ooff + nreads, 8, hipMemcpyDeviceToHost, g->stream));
+  if (filter) CUT_TRY(hipMemcpyAsync(&h_ndup, d_ndup, 8, hipMemcpyDeviceToHost, g->stream));
+  CUT_TRY(hipStreamSynchronize(g->stream));
+  int rc = MCX_OK;
+  if (out_bytes) {
+    CUT_TRY(hipMalloc((void **)&d_out, out_bytes + 64));
+    CUT_TRY(hipMemsetAsync(d_out + out_bytes, '\n', 64, g->stream));
+    hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
+                       (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, (const uint8_t *)d_keep, 1, d_sizes,
+                       (const uint64_t *)d_ooff, d_out);
+    CUT_TRY(hipGetLastError());
+    StreamLaunch SL{d_out, out_bytes, 0, out_bytes, nullptr};
+    rc = submit_stream(g, SL, colour);
+  }
+  hipLaunchKernelGGL(k_count_sizes, dim3(256), dim3(256), 0, g->stream, (const uint64_t *)d_sizes, (const uint8_t *)d_keep, nreads, g->d_ctr);
+  CUT_TRY(hipStreamSynchronize(g->stream));
+  cleanup();
+#undef CUT_TRY
+  if (ndup) *ndup = h_ndup;
+  return rc;
+}
+
+// -Q / -H without the filter
+static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
+                        const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp)
+{
+  return add_reads_cut(g, colour, bases, quals, off, nreads, fq, fq, hp, false, 0, 0, nullptr);
 }
 
 extern "C" int mcx_graph_add_reads_pcr(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
@@ -1179,88 +1232,11 @@ extern "C" int mcx_graph_add_reads_pcr(mcx_graph *g, int colour, const uint8_t *
     }
     HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
   }
-  const uint64_t base0 = off[0], nb = off[nreads] - off[0];
-  const uint32_t pmask = paired ? 1u : 0u, fq1 = fq_cutoff_abs1, fq2 = fq_cutoff_abs2, hp = hp_cutoff;
-  const uint64_t nunits = paired ? nreads / 2 : nreads;
-  uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_out = nullptr, *d_keep = nullptr;
-  uint64_t *d_off = nullptr, *d_sizes = nullptr, *d_ooff = nullptr, *d_node = nullptr;
-  unsigned long long *d_ndup = nullptr, h_ndup = 0;
-  void *d_tmp = nullptr;
-  size_t tmp_bytes = 0;
-  auto cleanup = [&]() {
-    (void)hipFree(d_bases); (void)hipFree(d_quals); (void)hipFree(d_out); (void)hipFree(d_keep); (void)hipFree(d_off);
-    (void)hipFree(d_sizes); (void)hipFree(d_ooff); (void)hipFree(d_node); (void)hipFree(d_ndup); (void)hipFree(d_tmp);
-  };
-#define PCR_TRY(expr)                                                                     \
-  do {                                                                                    \
-    hipError_t _e = (expr);                                                               \
-    if (_e != hipSuccess) {                                                               \
-      cleanup();                                                                          \
-      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
-    }                                                                                     \
-  } while (0)
-  std::vector<uint64_t> rel(nreads + 1);
-  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
-  const bool use_q = quals && (fq1 > 0 || fq2 > 0);
-  PCR_TRY(hipMalloc((void **)&d_bases, nb + 16));
-  if (use_q) PCR_TRY(hipMalloc((void **)&d_quals, nb + 16));
-  PCR_TRY(hipMalloc((void **)&d_off, (nreads + 1) * 8));
-  PCR_TRY(hipMalloc((void **)&d_sizes, (nreads + 1) * 8));
-  PCR_TRY(hipMalloc((void **)&d_ooff, (nreads + 1) * 8));
-  PCR_TRY(hipMalloc((void **)&d_node, nreads * 8));
-  PCR_TRY(hipMalloc((void **)&d_keep, nreads));
-  PCR_TRY(hipMalloc((void **)&d_ndup, 8));
-  PCR_TRY(hipMemcpyAsync(d_bases, bases + base0, nb, hipMemcpyHostToDevice, g->stream));
-  if (d_quals) PCR_TRY(hipMemcpyAsync(d_quals, quals + base0, nb, hipMemcpyHostToDevice, g->stream));
-  PCR_TRY(hipMemcpyAsync(d_off, rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
-  PCR_TRY(hipMemsetAsync(d_sizes, 0, (nreads + 1) * 8, g->stream));
-  PCR_TRY(hipMemsetAsync(d_ndup, 0, 8, g->stream));
-  const unsigned blocks = (unsigned)((nreads + 127) / 128), ublocks = (unsigned)((nunits + 255) / 256);
-  {
-    SpanGuard sp(g, "k_pcr_filter");
-    if (matedir)
-      hipLaunchKernelGGL(k_pcr_orient, dim3(blocks), dim3(128), 0, g->stream, d_bases, d_quals, (const uint64_t *)d_off, nreads, pmask, (uint32_t)matedir);
-    if (g->W == 1)
-      hipLaunchKernelGGL((k_pcr_starts<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                         (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, g->d_readstrt, d_node, g->d_ctr);
-    else
-      hipLaunchKernelGGL((k_pcr_starts<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                         (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, g->d_readstrt, d_node, g->d_ctr);
-    hipLaunchKernelGGL(k_pcr_decide, dim3(ublocks), dim3(256), 0, g->stream, (const uint64_t *)d_node, (const uint32_t *)g->d_readstrt,
-                       nunits, pmask, d_keep, d_ndup);
-    hipLaunchKernelGGL(k_pcr_commit, dim3(blocks), dim3(128), 0, g->stream, (const uint64_t *)d_node, nreads, g->d_readstrt);
-  }
-  PCR_TRY(hipGetLastError());
-  // the kept reads, cut into contigs by the reference's rules, become a separator stream for the
-  // ordinary front end (as add_reads_qh)
-  hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                     (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, (const uint8_t *)d_keep, 0, d_sizes,
-                     (const uint64_t *)nullptr, (uint8_t *)nullptr);
-  PCR_TRY(hipGetLastError());
-  PCR_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
-  PCR_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-  PCR_TRY(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
-  uint64_t out_bytes = 0;
-  PCR_TRY(hipMemcpyAsync(&out_bytes, d_ooff + nreads, 8, hipMemcpyDeviceToHost, g->stream));
-  PCR_TRY(hipMemcpyAsync(&h_ndup, d_ndup, 8, hipMemcpyDeviceToHost, g->stream));
-  PCR_TRY(hipStreamSynchronize(g->stream));
-  int rc = MCX_OK;
-  if (out_bytes) {
-    PCR_TRY(hipMalloc((void **)&d_out, out_bytes + 64));
-    PCR_TRY(hipMemsetAsync(d_out + out_bytes, '\n', 64, g->stream));
-    hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                       (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, (const uint8_t *)d_keep, 1, d_sizes,
-                       (const uint64_t *)d_ooff, d_out);
-    PCR_TRY(hipGetLastError());
-    StreamLaunch SL{d_out, out_bytes, 0, out_bytes, nullptr};
-    rc = submit_stream(g, SL, colour);
-  }
-  hipLaunchKernelGGL(k_count_sizes, dim3(256), dim3(256), 0, g->stream, (const uint64_t *)d_sizes, (const uint8_t *)d_keep, nreads, g->d_ctr);
-  PCR_TRY(hipStreamSynchronize(g->stream));
-  cleanup();
-#undef PCR_TRY
+  unsigned long long ndup = 0;
+  const int rc = add_reads_cut(g, colour, bases, quals, off, nreads, fq_cutoff_abs1, fq_cutoff_abs2, hp_cutoff, true,
+                               paired, matedir, &ndup);
   if (stats_accum) {
-    if (paired) stats_accum->num_dup_pe_pairs += h_ndup; else stats_accum->num_dup_se_reads += h_ndup;
+    if (paired) stats_accum->num_dup_pe_pairs += ndup; else stats_accum->num_dup_se_reads += ndup;
   }
   return rc;
 }
