@@ -41,6 +41,17 @@ static int fail(int code, const char *fmt, ...)
                   #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
   } while (0)
 
+// device scratch that is released on every way out of a function (HIP_TRY returns early)
+template <class T> struct DevBuf {
+  T *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void **)&p, n * sizeof(T)); }
+  operator T *() const { return p; }
+};
+
 constexpr uint64_t kCarry = 128;  // context bytes carried between chunks
 // New stream bytes per staged chunk (MCX_STAGE_BYTES overrides, for tests of the chunk seams).
 static uint64_t stage_bytes()
@@ -1081,15 +1092,15 @@ extern "C" int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed)
   HIP_TRY(hipSetDevice(g->device));
   int rc = flush_deferred(g);
   if (rc != MCX_OK) return rc;
-  unsigned long long *d_removed = nullptr, h_removed = 0;
-  HIP_TRY(hipMalloc((void **)&d_removed, 8));
+  DevBuf<unsigned long long> d_removed;
+  unsigned long long h_removed = 0;
+  HIP_TRY(d_removed.alloc(1));
   HIP_TRY(hipMemsetAsync(d_removed, 0, 8, g->stream));
   hipLaunchKernelGGL(k_intersect_finish, dim3(g->grid), dim3(256), 0, g->stream, g->t, (uint32_t)g->ncols_vis, (uint32_t)g->hidden,
-                     g->d_ctr, d_removed);
+                     g->d_ctr, d_removed.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(&h_removed, d_removed, 8, hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
-  (void)hipFree(d_removed);
   if (removed) *removed = h_removed;
   return MCX_OK;
 }
@@ -1308,14 +1319,15 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
   if (rc != MCX_OK) return rc;
   HIP_TRY(hipStreamSynchronize(g->stream));  // the staging buffers are ours now
   const uint64_t rec_bytes = 8ull * g->W + 5ull * (uint64_t)file_ncols;
-  int32_t *d_into = nullptr;  // from[nmap] then into[nmap]
-  RecordStats *d_st = nullptr, h_st;
-  HIP_TRY(hipMalloc((void **)&d_into, sizeof(int32_t) * 2 * (size_t)nmap));
-  if (hipMalloc((void **)&d_st, sizeof(RecordStats)) != hipSuccess) { (void)hipFree(d_into); return fail(MCX_ERR_NOMEM, "out of device memory"); }
+  DevBuf<int32_t> d_into;  // from[nmap] then into[nmap]
+  DevBuf<RecordStats> d_st;
+  RecordStats h_st;
+  HIP_TRY(d_into.alloc(2 * (size_t)nmap));
+  HIP_TRY(d_st.alloc(1));
   memset(&h_st, 0, sizeof(h_st));
   h_st.first_oversized = h_st.first_zero_covg = h_st.first_edges_no_covg = ~0ULL;
   HIP_TRY(hipMemcpyAsync(d_into, from_col, sizeof(int32_t) * (size_t)nmap, hipMemcpyHostToDevice, g->stream));
-  HIP_TRY(hipMemcpyAsync(d_into + nmap, into_col, sizeof(int32_t) * (size_t)nmap, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(hipMemcpyAsync(d_into.p + nmap, into_col, sizeof(int32_t) * (size_t)nmap, hipMemcpyHostToDevice, g->stream));
   HIP_TRY(hipMemcpyAsync(d_st, &h_st, sizeof(h_st), hipMemcpyHostToDevice, g->stream));
   const uint64_t per_chunk = std::max<uint64_t>(1, kStageBytes / rec_bytes);
   int cur = 0;
@@ -1328,16 +1340,15 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
     SpanGuard sp(g, "k_load_records");
     if (g->W == 1)
       hipLaunchKernelGGL((k_load_records<1>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st);
+                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p);
     else
       hipLaunchKernelGGL((k_load_records<2>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into, d_into + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st);
+                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->ev[cur], g->stream));
   }
   HIP_TRY(hipMemcpyAsync(&h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
-  (void)hipFree(d_into); (void)hipFree(d_st);
   if (stats_accum) {
     stats_accum->nkmers_read += nrecs;
     stats_accum->nkmers_loaded += h_st.loaded;
@@ -1493,23 +1504,22 @@ static int covg_scan(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov, uint64_t 
   if (rc != MCX_OK) return rc;
   const uint32_t nc = (uint32_t)g->ncols_vis;
   const uint32_t lbins = hist ? std::min<uint32_t>(nbins, 4096u) : 0;
-  unsigned long long *d_out = nullptr, *d_hist = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_out, 2 * nc * 8));
+  DevBuf<unsigned long long> d_out, d_hist;
+  HIP_TRY(d_out.alloc(2 * nc));
   HIP_TRY(hipMemsetAsync(d_out, 0, 2 * nc * 8, g->stream));
   if (hist) {
-    if (hipMalloc((void **)&d_hist, (size_t)nbins * 8) != hipSuccess) { (void)hipFree(d_out); return fail(MCX_ERR_NOMEM, "out of device memory"); }
+    HIP_TRY(d_hist.alloc(nbins));
     HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)nbins * 8, g->stream));
   }
   {
     SpanGuard sp(g, "k_covg_scan");
-    hipLaunchKernelGGL(k_covg_scan, dim3(g->grid), dim3(256), (2 * nc + lbins) * 8, g->stream, g->t, nc, d_out, d_hist, nbins, lbins);
+    hipLaunchKernelGGL(k_covg_scan, dim3(g->grid), dim3(256), (2 * nc + lbins) * 8, g->stream, g->t, nc, d_out.p, d_hist.p, nbins, lbins);
   }
   HIP_TRY(hipGetLastError());
   std::vector<unsigned long long> h(2 * nc);
   HIP_TRY(hipMemcpyAsync(h.data(), d_out, 2 * nc * 8, hipMemcpyDeviceToHost, g->stream));
   if (hist) HIP_TRY(hipMemcpyAsync(hist, d_hist, (size_t)nbins * 8, hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
-  (void)hipFree(d_out); (void)hipFree(d_hist);
   for (uint32_t c = 0; c < nc; c++) {
     if (nkmers) nkmers[c] = h[c];
     if (sumcov) sumcov[c] = h[nc + c];
@@ -1523,17 +1533,17 @@ extern "C" int mcx_graph_checksum(mcx_graph *g, uint64_t *checksum, uint64_t *nk
   HIP_TRY(hipSetDevice(g->device));
   int rc = flush_deferred(g);
   if (rc != MCX_OK) return rc;
-  unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
-  HIP_TRY(hipMalloc((void **)&d_out, 16));
+  DevBuf<unsigned long long> d_out;
+  unsigned long long h_out[2] = {0, 0};
+  HIP_TRY(d_out.alloc(2));
   HIP_TRY(hipMemsetAsync(d_out, 0, 16, g->stream));
   {
     SpanGuard sp(g, "k_checksum");
-    hipLaunchKernelGGL(k_checksum, dim3(g->grid), dim3(256), 0, g->stream, g->t, (uint32_t)g->W, (uint32_t)g->ncols_vis, d_out);
+    hipLaunchKernelGGL(k_checksum, dim3(g->grid), dim3(256), 0, g->stream, g->t, (uint32_t)g->W, (uint32_t)g->ncols_vis, d_out.p);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
-  (void)hipFree(d_out);
   *checksum = h_out[0];
   if (nkmers) *nkmers = h_out[1];
   return MCX_OK;
