@@ -136,3 +136,41 @@ def test_argument_errors(mcx, orc):
     with pytest.raises(mcx.McxError):
         g.add_reads_pcr(1, b, o)
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_arbitrary_bytes_lengths_and_cutoffs(mcx, orc, seed):
+    """reads of arbitrary bytes and lengths (0 .. 3 k), arbitrary qualities, random preferences, in several batches"""
+    rng = np.random.default_rng(300 + seed)
+    k = int(rng.choice([5, 21, 31, 33, 63]))
+    alphabet = np.concatenate([np.frombuffer(b"ACGT" * 30 + b"acgtNn-*", np.uint8), rng.integers(0, 256, 8).astype(np.uint8)])
+    n = 2 * int(rng.integers(300, 1500))
+    starts = [bytes(rng.choice(alphabet[:120], k + 3)) for _ in range(40)]     # few distinct read starts -> duplicates
+    reads = []
+    for i in range(n):
+        body = bytes(rng.choice(alphabet, int(rng.integers(0, 3 * k))))
+        r = starts[int(rng.integers(0, len(starts)))] + body if rng.random() < 0.8 else body
+        if rng.random() < 0.3:      # some as reverse complements: the other strand is another start
+            r = r[::-1].translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))
+        reads.append(r)
+    bases, offs = orc.pack_reads(reads)
+    quals = rng.integers(30, 80, len(bases)).astype(np.uint8)
+    paired = bool(rng.integers(0, 2))
+    matedir = ["FF", "FR", "RF", "RR"][int(rng.integers(0, 4))]
+    fq1, fq2, hp = (int(rng.choice([0, 35, 50])), int(rng.choice([0, 40, 60])), int(rng.choice([0, 0, 3, 5])))
+    g = mcx.Graph(k, 1, 1 << 16)
+    og = orc.Graph(k, 1, 1 << 16)
+    st, ot = mcx.LoadStats(), orc.Stats()
+    odup = [0, 0, 0]
+    nb = int(rng.integers(1, 5))
+    cuts = [2 * (n // 2 * i // nb) for i in range(nb + 1)]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        kw = dict(quals=quals, fq_cutoff=fq1, fq_cutoff2=fq2, hp_cutoff=hp, paired=paired, matedir=matedir)
+        g.add_reads_pcr(0, bases, offs[lo:hi + 1], stats=st, **kw)
+        _, d = og.add_reads_pcr(0, bases, offs[lo:hi + 1], stats=ot, **kw)
+        odup = [x + y for x, y in zip(odup, d)]
+    _dev_stats(g, st)
+    assert (st.num_dup_se_reads, st.num_dup_pe_pairs, st.num_pe_reads) == tuple(odup), (k, paired, matedir, fq1, fq2, hp)
+    assert {f: getattr(st, f) for f in FIELDS} == {f: getattr(ot, f) for f in FIELDS}
+    _same_graph(mcx, g, og, k, 1)
+    g.close()
