@@ -831,21 +831,23 @@ extern "C" int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uin
 template <int W, bool ONECOL> static void launch_superk_bin(mcx_graph *g, SuperkIn in, int colour, BinSpec bs, BinOut out)
 {
   if (W != 1) return;
-  const uint64_t ntiles = (in.seg_cap + kThreads - 1) / kThreads * in.nseg;
+  const uint64_t nunits = (in.seg_cap + kSkChunk - 1) / kSkChunk * in.nseg;  // chunks of records, one block walks one at a time
   InsertSink<1, ONECOL> is{g->t, (uint32_t)colour};
+  const size_t lds512 = ((sizeof(BinLds<1, 512, false>) + 15) & ~(size_t)15) + kSkMapBytes;
+  const size_t ldsmax = ((sizeof(BinLds<1, kMaxBins, false>) + 15) & ~(size_t)15) + kSkMapBytes;
   static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
   bool &once = once_dev[g->device & 63];
   if (!once) {
-    allow_lds(k_superk_bin<ONECOL, 512>, sizeof(BinLds<1, 512, false>));
-    allow_lds(k_superk_bin<ONECOL, kMaxBins>, sizeof(BinLds<1, kMaxBins, false>));
+    allow_lds(k_superk_bin<ONECOL, 512>, lds512);
+    allow_lds(k_superk_bin<ONECOL, kMaxBins>, ldsmax);
     once = true;
   }
   SpanGuard sp(g, "k_superk_bin");
-  const dim3 grid((unsigned)std::min<uint64_t>(ntiles, (uint64_t)g->grid * 4));
+  const dim3 grid((unsigned)std::min<uint64_t>(nunits, (uint64_t)g->grid * 4));
   if (bs.nlocal <= 512)
-    hipLaunchKernelGGL((k_superk_bin<ONECOL, 512>), grid, dim3(kThreads), sizeof(BinLds<1, 512, false>), g->stream, in, g->k, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_superk_bin<ONECOL, 512>), grid, dim3(kThreads), lds512, g->stream, in, g->k, bs, out, is, g->d_ctr);
   else
-    hipLaunchKernelGGL((k_superk_bin<ONECOL, kMaxBins>), grid, dim3(kThreads), sizeof(BinLds<1, kMaxBins, false>), g->stream, in, g->k, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_superk_bin<ONECOL, kMaxBins>), grid, dim3(kThreads), ldsmax, g->stream, in, g->k, bs, out, is, g->d_ctr);
 }
 
 extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_recs, const void *d_counts, uint32_t nseg,

@@ -83,18 +83,40 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
   const uint32_t nparts = 1u << out.lbo;
   const uint32_t rep = blockIdx.x % out.rep;
 
+  // the chunks of the NEXT tile are fetched into registers while the current one is processed
+  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+  {
+    const uint64_t t0 = a.tile0 + blockIdx.x;
+    if (t0 < a.ntiles) {
+      const int64_t r0 = (int64_t)(t0 * kTile) - 16;
+      pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
+      if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
+    }
+  }
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
-    const int64_t region0 = (int64_t)(tile * kTile) - 16;
-    for (int c = tid; c < kChunks; c += kThreads) {
+    {
       uint32_t code, inv;
-      encode_chunk(a.stream, a.nbytes, region0 + 16 * (int64_t)c, code, inv);
-      s_code[c] = code;
-      reinterpret_cast<uint16_t *>(s_inv)[c ^ 1] = (uint16_t)inv;
+      encode_words(pre0, code, inv);
+      s_code[tid] = code;
+      reinterpret_cast<uint16_t *>(s_inv)[tid ^ 1] = (uint16_t)inv;
+      if (tid < kChunks - kThreads) {
+        encode_words(pre1, code, inv);
+        s_code[tid + kThreads] = code;
+        reinterpret_cast<uint16_t *>(s_inv)[(tid + kThreads) ^ 1] = (uint16_t)inv;
+      }
     }
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     if (tid < 32) { s_cnt[tid] = 0; s_rank[tid] = 0; }
     if (tid == 0) s_total = 0;
+    {
+      const uint64_t tn = tile + gridDim.x;
+      if (tn < a.ntiles) {
+        const int64_t r0 = (int64_t)(tn * kTile) - 16;
+        pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
+        if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
+      }
+    }
     __syncthreads();
 
     const uint32_t pl = 16u * (uint32_t)(tid + 1);
@@ -205,6 +227,19 @@ struct SuperkIn {
   uint32_t nseg;
 };
 
+// Records hold 1..16 k-mers (16 when one GPU owns everything, 6-7 on average at 8 owners), and
+// a lane that walks its record's 16 positions pays for all 16 whatever the run's length.  So the
+// K-MERS -- not the records -- are dealt out to the lanes.  A block walks a chunk of a segment and
+// takes, per tile, as many records (in fours: one 64-byte load per lane) as hold <= kTile k-mers;
+// k-mer q of the tile (records in order, their k-mers in order) goes to lane q % kThreads as its
+// (q / kThreads)-th, and every lane extracts its k-mers straight from the record's 48-base
+// window.  All lanes carry the same number of k-mers (+-1) and tiles are full (>= kTile - 63
+// k-mers) except at a chunk's end, so the cost per k-mer does not depend on the run lengths.
+constexpr int kSkPerLane = 4;                      // candidate records per lane and tile
+constexpr int kSkCand = kSkPerLane * kThreads;     // 1024
+constexpr uint32_t kSkChunk = 1u << 13;            // records per unit of work (a block's walk)
+constexpr size_t kSkMapBytes = (size_t)kTile * 2;  // s_map behind the BinLds block in dynamic LDS
+
 template <bool ONECOL, int NB>
 __global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, BinSpec bs, BinOut out,
                                                             InsertSink<1, ONECOL> isink, Counters *ctr)
@@ -213,45 +248,96 @@ __global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, 
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   using LDS = BinLds<W, NB, false>;
   LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
+  // the taken records sit in the staging area (not written before bin_place); the k-mer -> (record,
+  // index in run) map has its own 8 KB
+  static_assert(sizeof(L.skey) >= (size_t)kSkCand * 16, "records fit the staging area");
+  ulonglong2 *s_rec = reinterpret_cast<ulonglong2 *>(L.skey);
+  uint16_t *s_map = reinterpret_cast<uint16_t *>(dyn_lds + ((sizeof(LDS) + 15) & ~(size_t)15));  // record | index << 10
+  __shared__ uint32_t s_incl[kThreads + 1];
+  __shared__ uint32_t s_wsum[kThreads / 64];
+  __shared__ uint32_t s_T, s_nl;
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
-  const uint64_t top_mask = ~0ULL >> (64 - 2 * k);
-  const int first_shift = 2 * k - 2;
   const uint32_t ob0 = (blockIdx.x % bs.rep) * bs.nout;
-  // a tile = kThreads records = up to 4096 k-mers: the partition machinery of mcx_defer.h as is
-  const uint64_t tiles_per_seg = (in.seg_cap + kThreads - 1) / kThreads;
-  const uint64_t ntiles = tiles_per_seg * in.nseg;
-  for (uint64_t v = blockIdx.x; v < ntiles; v += gridDim.x) {
+  const uint64_t chunks_per_seg = (in.seg_cap + kSkChunk - 1) / kSkChunk;
+  const uint64_t nunits = chunks_per_seg * in.nseg;
+  for (uint64_t v = blockIdx.x; v < nunits; v += gridDim.x) {
     const uint32_t seg = (uint32_t)(v % in.nseg);  // segment-interleaved
-    const uint64_t i0 = (v / in.nseg) * kThreads;
+    const uint64_t c0 = (v / in.nseg) * kSkChunk;
     uint64_t cnt = in.counts[seg];
     if (cnt > in.seg_cap) cnt = in.seg_cap;
-    if (i0 >= cnt) continue;  // uniform
-    __syncthreads();
-    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
-    __syncthreads();
-    Kmer<W> tk[kPosPerLane];
-    uint32_t tle[kPosPerLane];
-    uint32_t vmask = 0;
-    if (i0 + (uint64_t)tid < cnt) {
-      const ulonglong2 rec = in.recs[(uint64_t)seg * in.seg_cap + i0 + tid];
-      const uint64_t hiW = rec.x, loW = rec.y & 0xFFFFFFFF00000000ULL;
-      const uint32_t hdr = (uint32_t)rec.y;
-      const uint32_t start = hdr & kSkStartMask, len = ((hdr >> kSkLenShift) & 0xFu) + 1u;
-      const uint32_t run = ((0x10000u >> start) - 1u) & ~((0x10000u >> (start + len)) - 1u);  // bit 15 - j
-      // k-mer at position 0 = bases 0 .. k-1 = window bases 1 .. k
-      Kmer<W> fw, rc;
-      fw.w[0] = (hiW << 2) >> (64 - 2 * k);
-      rc = revcomp<W>(fw, k);
+    if (c0 >= cnt) continue;  // uniform
+    const uint64_t c1 = min(cnt, c0 + (uint64_t)kSkChunk);
+    const ulonglong2 *recs = in.recs + (uint64_t)seg * in.seg_cap;
+    for (uint64_t pos = c0; pos < c1;) {  // uniform
+      __syncthreads();
+      for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
+      // four candidate records per lane, their k-mer counts, inclusive scan over the block
+      ulonglong2 ra = make_ulonglong2(0, 0), rb = ra, rc4 = ra, rd = ra;
+      uint32_t la = 0, lb = 0, lc = 0, ld = 0;
+      {
+        const uint64_t i = pos + (uint64_t)kSkPerLane * (uint64_t)tid;
+        auto rlen = [](const ulonglong2 &r) { return (((uint32_t)r.y >> kSkLenShift) & 0xFu) + 1u; };
+        if (i + 0 < c1) { ra = recs[i + 0]; la = rlen(ra); }
+        if (i + 1 < c1) { rb = recs[i + 1]; lb = rlen(rb); }
+        if (i + 2 < c1) { rc4 = recs[i + 2]; lc = rlen(rc4); }
+        if (i + 3 < c1) { rd = recs[i + 3]; ld = rlen(rd); }
+      }
+      const uint32_t lsum = la + lb + lc + ld;
+      uint32_t x = lsum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((tid & 63) >= d) x += y;
+      }
+      if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < kThreads / 64; w++)
+        if (w < (tid >> 6)) x += s_wsum[w];
+      s_incl[tid] = x;  // inclusive
+      if (tid == 0) s_incl[kThreads] = 0xFFFFFFFFu;
+      __syncthreads();
+      // lanes are taken while the running total fits a tile: a prefix of the lanes (lane 0 always)
+      const bool take = x <= (uint32_t)kTile;
+      if (take && s_incl[tid + 1] > (uint32_t)kTile) { s_T = x; s_nl = (uint32_t)tid + 1u; }
+      if (take) {
+        uint32_t o = x - lsum;
+        const uint32_t r0 = (uint32_t)kSkPerLane * (uint32_t)tid;
+        s_rec[r0 + 0] = ra; s_rec[r0 + 1] = rb; s_rec[r0 + 2] = rc4; s_rec[r0 + 3] = rd;
+        for (uint32_t i = 0; i < la; i++) s_map[o++] = (uint16_t)((r0 + 0u) | (i << 10));
+        for (uint32_t i = 0; i < lb; i++) s_map[o++] = (uint16_t)((r0 + 1u) | (i << 10));
+        for (uint32_t i = 0; i < lc; i++) s_map[o++] = (uint16_t)((r0 + 2u) | (i << 10));
+        for (uint32_t i = 0; i < ld; i++) s_map[o++] = (uint16_t)((r0 + 3u) | (i << 10));
+      }
+      __syncthreads();
+      const uint32_t T = s_T;
+      pos += (uint64_t)kSkPerLane * s_nl;
+
+      Kmer<W> tk[kPosPerLane];
+      uint32_t tle[kPosPerLane];
+      uint32_t vmask = 0;
+      const int nj = (int)((T + kThreads - 1) / kThreads);  // uniform
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++) {
-        const uint32_t bit = 0x8000u >> j;
-        const int tn = k + j + 1;  // window index of the base after k-mer j
-        const uint32_t nuc_next = tn < 32 ? (uint32_t)(hiW >> (62 - 2 * tn)) & 3u : (uint32_t)(loW >> (126 - 2 * tn)) & 3u;
-        const uint32_t prev_nuc = (uint32_t)(hiW >> (62 - 2 * j)) & 3u;  // window index j = base j - 1
-        if (run & bit) {
-          const bool next_ok = ((uint32_t)j + 1u < start + len) || (hdr & kSkNextOk);
-          const bool prev_ok = ((uint32_t)j > start) || (hdr & kSkPrevOk);
+        const uint32_t q = (uint32_t)j * kThreads + (uint32_t)tid;
+        if (j < nj && q < T) {  // (j < nj is uniform: whole iterations are skipped)
+          const uint32_t m = s_map[q];
+          const ulonglong2 rec = s_rec[m & 0x3ffu];
+          const uint64_t hiW = rec.x, loW = rec.y & 0xFFFFFFFF00000000ULL;
+          const uint32_t hdr = (uint32_t)rec.y;
+          const uint32_t i = m >> 10, rlen = ((hdr >> kSkLenShift) & 0xFu) + 1u;
+          const uint32_t p = (hdr & kSkStartMask) + i;       // the k-mer is bases p+1 .. p+k of the window
+          const uint32_t sft = 2u * (p + 1u);                // 2 .. 32
+          const uint64_t X = (hiW << sft) | (loW >> (64u - sft));  // bases p+1 .. p+32 on top
+          Kmer<W> fw, rc;
+          fw.w[0] = X >> (64 - 2 * k);
+          rc = revcomp<W>(fw, k);
+          // base after the k-mer = the one below the top k bases of X (k <= 31); base before it = window base p
+          const uint32_t nuc_next = (uint32_t)(X >> (62 - 2 * k)) & 3u;
+          const uint32_t prev_nuc = (uint32_t)(hiW >> (62u - 2u * p)) & 3u;
+          const bool next_ok = (i + 1u < rlen) || (hdr & kSkNextOk);
+          const bool prev_ok = (i > 0u) || (hdr & kSkPrevOk);
           uint32_t o;
           const Kmer<W> key = canonical<W>(fw, rc, o);
           uint32_t e = 0;
@@ -259,30 +345,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, 
           if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
           uint32_t r;
           const uint32_t lbq = lbq_of(isink.t);
-          const Kmer<W> q = key_quot<W>(key, lbq, r);
-          const uint32_t G = r ^ (region_mix<W>(q) & ((1u << lbq) - 1u));
+          const Kmer<W> qq = key_quot<W>(key, lbq, r);
+          const uint32_t G = r ^ (region_mix<W>(qq) & ((1u << lbq) - 1u));
           const uint32_t local = G & ((1u << isink.t.lb1) - 1u);
-          tk[j] = tuple_pack<W>(q, e);
+          tk[j] = tuple_pack<W>(qq, e);
           tle[j] = local << 8;
           vmask |= 1u << j;
           atomicAdd(&L.cnt[local], 1u);
         }
-        fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
-        rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
       }
-    }
-    BinRes<NB> res;
-    bin_reserve<LDS, NB>(L, bs, out, ob0, res);
-#pragma unroll
-    for (int j = 0; j < kPosPerLane; j++)
-      if (vmask & (1u << j)) tle[j] |= bin_rank<LDS>(L, (tle[j] >> 8) & 0x7ffu) << 19;
-    bin_commit<LDS, NB>(L, bs, out, ob0, res);
-    for (int round = 0; round < kRounds; round++) {
+      BinRes<NB> res;
+      bin_reserve<LDS, NB>(L, bs, out, ob0, res);   // (its first barrier also ends the reads of s_rec / s_map)
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
-        if (vmask & (1u << j))
-          bin_place<W, false, LDS>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], 0);
-      bin_writeout<W, ONECOL, false, 0, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
+        if (j < nj && (vmask & (1u << j))) tle[j] |= bin_rank<LDS>(L, (tle[j] >> 8) & 0x7ffu) << 19;
+      bin_commit<LDS, NB>(L, bs, out, ob0, res);
+      for (int round = 0; round < kRounds; round++) {
+        if ((uint32_t)round * kStage < T) {  // uniform
+#pragma unroll
+          for (int j = 0; j < kPosPerLane; j++)
+            if (j < nj && (vmask & (1u << j)))
+              bin_place<W, false, LDS>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], 0);
+        }
+        bin_writeout<W, ONECOL, false, 0, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
+      }
     }
   }
   block_add(&ctr->novel, n_novel);
