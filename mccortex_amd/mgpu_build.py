@@ -10,9 +10,9 @@ k-mer, the owners insert; the shards hold disjoint key sets, so the graph file i
 The output is byte-identical to the single-GPU `mccortex<K> build` of the same command line.
 
 Options are `build`'s (src/commands/ctx_build.c:13-77) where they make sense here:
--k -n -f -s/--sample -1/--seq -S/--sort; -n is the capacity of the whole graph.  Not offered:
---seq2/--seqi pairing and --remove-pcr (need the reads of a pair on one rank), -Q/-H, --graph,
---intersect, gzip input: the single-GPU command has them."""
+-k -n -f -s/--sample -1/--seq -2/--seq2 -i/--seqi -S/--sort; -n is the capacity of the whole graph.
+Not offered: --remove-pcr (needs the reads of a pair on one rank), -Q/-H, --graph, --intersect,
+gzip input: the single-GPU command has them."""
 import argparse
 import os
 import sys
@@ -41,6 +41,8 @@ def parse_args(argv):
     ap.add_argument("-S", "--sort", action="store_true")
     ap.add_argument("-s", "--sample", action="append", default=[])
     ap.add_argument("-1", "--seq", action="append", default=[])
+    ap.add_argument("-2", "--seq2", action="append", default=[])
+    ap.add_argument("-i", "--seqi", action="append", default=[])
     ap.add_argument("--step-bytes", type=parse_size, default=STEP_BYTES)
     ap.add_argument("out")
     # sample / seq order matters (a --seq belongs to the --sample before it): walk argv ourselves
@@ -51,10 +53,17 @@ def parse_args(argv):
         if a in ("-s", "--sample"):
             colour += 1
             names.append(argv[i + 1]); next(it)
-        elif a in ("-1", "--seq"):
+        elif a in ("-1", "--seq", "-i", "--seqi", "-2", "--seq2"):
             if colour < 0:
                 raise SystemExit("Please give sample name first [-s,--sample <name>]")
-            tasks.append((argv[i + 1], colour)); next(it)
+            val = argv[i + 1]; next(it)
+            if a in ("-2", "--seq2"):   # <in1>:<in2>: without --remove-pcr mates are loaded as two files (ctx_build.c:108-116)
+                sep = ":" if ":" in val else ","
+                if val.count(sep) != 1:
+                    raise SystemExit("Expected -2 <in1>:<in2>")
+                tasks.extend((f, colour) for f in val.split(sep))
+            else:
+                tasks.append((val, colour))
     args = ap.parse_args(argv)
     if not names:
         raise SystemExit("No inputs given")

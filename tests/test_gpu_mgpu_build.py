@@ -37,12 +37,12 @@ def test_tool_matches_oracle(mcx, orc, tmp_path, k, exchange):
         sets.append((_write(d, reads, fmt, width), reads))
     out = str(tmp_path / "out.ctx")
     args = ["-k", str(k), "-n", "1M", "--sort", "--step-bytes", "100K", "--sample", "alice", "--seq", sets[0][0], "--seq", sets[1][0],
-            "--sample", "bob", "--seq", sets[2][0], out]
+            "--sample", "bob", "--seq2", sets[2][0] + ":" + sets[0][0], out]
     rc, err = _run(args, 29600 + k, env={"MCX_EXCHANGE": exchange})
     assert rc == 0, err[-3000:]
     og = orc.Graph(k, 2, 1 << 20)
     og.set_sample(0, "alice"); og.set_sample(1, "bob")
-    for col, (path, reads) in zip((0, 0, 1), sets):
+    for col, (path, reads) in zip((0, 0, 1, 1), sets + [sets[0]]):
         b, o = orc.pack_reads(reads)
         st = og.add_reads(col, b, o)
         og.update_stats(col, st)
