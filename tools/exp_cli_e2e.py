@@ -27,7 +27,11 @@ fq = os.path.join(out, "reads.fq")
 rec.tofile(fq)
 print("wrote %s: %.2f GB, %d reads" % (fq, os.path.getsize(fq) / 1e9, NR), flush=True)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mccortex_amd", "bin", "mccortex31")
-for args in (["--sort", "-t", "1"], ["--sort", "-t", "2"], ["--sort", "-t", "8"], ["--sort", "-t", "32"], ["-t", "32"]):
+VARIANTS = (["--sort", "-t", "1"], ["--sort", "-t", "2"], ["--sort", "-t", "8"], ["--sort", "-t", "32"], ["-t", "32"])
+if os.environ.get("PREFS"):   # e.g. PREFS=1: the read preferences that take the reads through the cutting kernels
+    VARIANTS = (["--sort", "-t", "8"], ["--sort", "-t", "8", "-Q", "10"], ["--sort", "-t", "8", "-H", "8"],
+                ["--sort", "-t", "8", "--remove-pcr"], ["--sort", "-t", "8", "-Q", "10", "--remove-pcr"])
+for args in VARIANTS:
     t0 = time.perf_counter()
     p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp"] + args + ["--seq", fq, os.environ.get("OUT", os.path.join(out, "o.ctx"))],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
