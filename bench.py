@@ -302,8 +302,12 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_kernel_ms": avg_ms, "launches": calls, "alg_bytes_per_launch": alg_bytes,
-                           "kernels": {n: {"launches": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4)}
-                                       for n, (c, t) in prof.items()},
+                           # every kernel of the path: its own algorithmic bytes per occurrence (tuples and bases
+                           # only; k_lds_insert also streams the table once per flush) over its time
+                           "kernels": {n: {"launches": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4),
+                                           "achieved": round(KERNEL_ALG_BYTES.get(n, 0.0) * kmers_local / (t * 1e-3) / 1e9, 1),
+                                           "frac": round(KERNEL_ALG_BYTES.get(n, 0.0) * kmers_local / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                       for n, (c, t) in prof.items() if t > 0},
                            "pipeline": {"gpu_ms": gpu_ms, "alg_bytes": pipe_bytes,
                                         "achieved": pipe_bytes / (gpu_ms * 1e-3) / 1e9,
                                         "frac": pipe_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
