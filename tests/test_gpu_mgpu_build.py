@@ -53,3 +53,48 @@ def test_tool_matches_oracle(mcx, orc, tmp_path, k, exchange):
     # refuses to overwrite without -f
     rc, err = _run(args, 29700 + k)
     assert rc != 0 and "already exists" in err
+
+
+@pytest.mark.parametrize("use_v3", [True, False])
+def test_sharded_inserter_empty_and_ragged_steps(mcx, orc, use_v3):
+    """the step runner itself (1-rank RCCL group): steps of different sizes, empty steps (what a rank with a
+    shorter share of a file submits), several insert() calls, two colours"""
+    import torch
+    import torch.distributed as dist
+    from mccortex_amd import shard
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = "29811" if use_v3 else "29812"
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=0, world_size=1)
+    try:
+        k = 31
+        dev = torch.device("cuda", 0)
+        g = mcx.Graph(k, 2, 1 << 20) if use_v3 else mcx.Graph(k, 2, 1 << 20, nparts=1, part=0)
+        og = orc.Graph(k, 2, 1 << 20)
+        ins = shard.ShardedInserter(g, 1, dev, 400_000, use_v3)
+        empty = torch.zeros(16, dtype=torch.uint8, device=dev)
+        gen = synth.genome(20000, 3)
+        plan = [(0, [1500, 0, 700, 0, 0, 2000]), (1, [0]), (1, [300, 2500]), (0, [50])]
+        seed = 0
+        for col, sizes in plan:
+            steps = []
+            for n in sizes:
+                if n == 0:
+                    steps.append((empty, 0))
+                    continue
+                seed += 1
+                b, o = synth.reads(n, 120, seed=seed, g=gen, n_frac=0.05, var_len=True)
+                og.add_reads(col, b, o)
+                s = torch.from_numpy(synth.to_stream(b, o)).to(dev)
+                steps.append((s, s.numel()))
+            ins.insert(col, steps)
+        assert g.nkmers == og.nkmers
+        assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+        with pytest.raises(ValueError):
+            big = torch.zeros(500_000, dtype=torch.uint8, device=dev)
+            ins.insert(0, [(big, big.numel())])
+        g.close()
+    finally:
+        if own_group:
+            dist.destroy_process_group()
