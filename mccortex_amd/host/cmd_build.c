@@ -219,6 +219,77 @@ static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
   submit_calls++;
 }
 
+/* ---- read-ahead for gzip'd inputs -------------------------------------------------------------
+ * One thread inflates and parses ONE file (as the reference's reader thread per file does,
+ * src/basic/async_read_io.c:145-175); zlib gives ~0.3 GB/s per stream, so with several .gz inputs
+ * the files after the current one are inflated ahead, up to -t of them at a time.  Batches still
+ * reach the GPU file by file in task order (the per-file statistics are counter deltas around a file). */
+#define RA_DEPTH 3
+typedef struct {
+  build_task *bt;
+  pthread_t th;
+  bool started, joined;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  struct { read_batch *b; int fq_guess; } q[RA_DEPTH];
+  int qh, qn;
+  bool done, open_failed, use_q;
+} reader_job;
+
+static bool is_gzip_file(const char *path)
+{
+  if (file_size(path) < 2) return false;
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  unsigned char m[2] = {0, 0};
+  const bool gz = fread(m, 1, 2, f) == 2 && m[0] == 0x1f && m[1] == 0x8b;
+  fclose(f);
+  return gz;
+}
+
+static void *reader_main(void *arg)
+{
+  reader_job *j = arg;
+  seq_in *in = seq_in_open(j->bt->path);
+  if (!in) {
+    pthread_mutex_lock(&j->mu); j->open_failed = j->done = true; pthread_cond_broadcast(&j->cv); pthread_mutex_unlock(&j->mu);
+    return NULL;
+  }
+  j->use_q = j->bt->fq_cutoff > 0 && seq_in_format(in) == SEQ_FMT_FASTQ; /* (read by the consumer after its first pop) */
+  for (;;) {
+    read_batch *b = malloc(sizeof(*b));
+    if (!b) die("Out of memory");
+    read_batch_init(b, j->use_q);
+    const size_t got = seq_in_fill(in, b, BATCH_BASES);
+    if (!got && !b->nreads) { read_batch_free(b); free(b); break; }
+    pthread_mutex_lock(&j->mu);
+    while (j->qn == RA_DEPTH) pthread_cond_wait(&j->cv, &j->mu);
+    const int at = (j->qh + j->qn) % RA_DEPTH;
+    j->q[at].b = b; j->q[at].fq_guess = seq_in_guess_fq_offset(in);
+    j->qn++;
+    pthread_cond_broadcast(&j->cv);
+    pthread_mutex_unlock(&j->mu);
+  }
+  seq_in_close(in);
+  pthread_mutex_lock(&j->mu); j->done = true; pthread_cond_broadcast(&j->cv); pthread_mutex_unlock(&j->mu);
+  return NULL;
+}
+
+/* next batch of the file, NULL at its end */
+static read_batch *reader_pop(reader_job *j, int *fq_guess)
+{
+  read_batch *b = NULL;
+  pthread_mutex_lock(&j->mu);
+  while (j->qn == 0 && !j->done) pthread_cond_wait(&j->cv, &j->mu);
+  if (j->qn) {
+    b = j->q[j->qh].b; *fq_guess = j->q[j->qh].fq_guess;
+    j->qh = (j->qh + 1) % RA_DEPTH; j->qn--;
+    pthread_cond_broadcast(&j->cv);
+  }
+  pthread_mutex_unlock(&j->mu);
+  return b;
+}
+
 /* --remove-pcr task: reads go to the GPU in input order, mates side by side
  * (build_graph_from_reads_mt with prefs.remove_pcr_dups, build_graph.c:192-231) */
 static uint8_t fq_abs_of(const build_task *bt, seq_in *in)
@@ -589,6 +660,14 @@ int ctx_build(int argc, char **argv)
 
   /* ---- load every input in task order (build_graph(): build_graph.c:257-300) ---- */
   read_batch batch;
+  /* gzip'd files not under --remove-pcr get a read-ahead thread each, at most -t running at a time */
+  reader_job *readers = calloc(ntasks ? ntasks : 1, sizeof(reader_job));
+  size_t next_reader = 0, readers_live = 0;
+  for (size_t t = 0; t < ntasks; t++) {
+    readers[t].bt = &tasks[t];
+    pthread_mutex_init(&readers[t].mu, NULL);
+    pthread_cond_init(&readers[t].cv, NULL);
+  }
   mcx_load_stats prev;
   mcx_check(mcx_graph_device_stats(g, &prev), "device stats"); /* k-mers created by --graph are not a file's */
   for (size_t t = 0; t < ntasks; t++) {
@@ -599,7 +678,34 @@ int ctx_build(int argc, char **argv)
     int prc = 1;
     /* the read-start bits are wiped when the colour changes (ctx_build.c:389-395) */
     if (remove_pcr_used && t > 0 && bt->colour != tasks[t - 1].colour) mcx_check(mcx_graph_pcr_reset(g), "pcr reset");
-    if (bt->remove_pcr) { load_task_pcr(g, bt); prc = 0; }
+    /* start read-ahead threads for this and the following gzip'd files */
+    if (next_reader < t) next_reader = t;
+    while (next_reader < ntasks && readers_live < nthreads && nthreads > 1) {
+      reader_job *rj = &readers[next_reader];
+      if (!rj->bt->remove_pcr && is_gzip_file(rj->bt->path)) {
+        if (pthread_create(&rj->th, NULL, reader_main, rj) != 0) die("Cannot start a reader thread");
+        rj->started = true;
+        readers_live++;
+      }
+      next_reader++;   /* (files that take another path do not hold the look-ahead up) */
+    }
+    if (readers[t].started) {
+      reader_job *rj = &readers[t];
+      int guess = 0;
+      read_batch *b;
+      bool first = true;
+      while ((b = reader_pop(rj, &guess)) != NULL) {
+        if (first) { sc.use_q = rj->use_q; first = false; }
+        submit_batch(&sc, b, guess);
+        read_batch_free(b); free(b);
+      }
+      pthread_join(rj->th, NULL);
+      rj->joined = true;
+      readers_live--;
+      if (rj->open_failed) die("Cannot open -1 file: %s", bt->path);
+      prc = 0;
+    }
+    else if (bt->remove_pcr) { load_task_pcr(g, bt); prc = 0; }
     else if (nthreads > 1 && strcmp(bt->path, "-") != 0)
       prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, getenv("MCX_PAR_BATCH") ? (size_t)atol(getenv("MCX_PAR_BATCH")) : PAR_BATCH_BASES, submit_batch, &sc);
     if (prc == 2) die("Irregular %s record in %s (multi-line FASTQ?): rerun with -t 1", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
@@ -672,6 +778,8 @@ int ctx_build(int argc, char **argv)
   if (fout != stdout) fclose(fout);
   mcx_graph_destroy(g);
   stage_time("device released");
+  for (size_t t = 0; t < ntasks; t++) { pthread_mutex_destroy(&readers[t].mu); pthread_cond_destroy(&readers[t].cv); }
+  free(readers);
   for (size_t t = 0; t < ntasks; t++) { free(tasks[t].path); free(tasks[t].path2); }
   for (size_t i = 0; i < ncols; i++) col_info_free(&cols[i]);
   free(tasks); free(cols); free(sample_names); free(sample_cols); free(gfiles); free(gisec);

@@ -300,3 +300,38 @@ def test_build_remove_pcr(built, orc, tmp_path):
     short = _write_inputs(tmp_path, b1[:int(o1[10])], o1[:11], "short", "fa")
     rc, _, err = run(31, "build", "-f", "-k", str(k), "-n", "64K", "-s", "a", "-p", "--seq2", f1 + ":" + short, out)
     assert rc == 1 and "Different number of reads" in err
+
+
+@pytest.mark.gpu
+def test_gzip_inputs_are_read_ahead(built, orc, tmp_path):
+    """several .gz files (inflated ahead by reader threads, -t 4) mixed with plain ones, two colours, -Q:
+    same file as the restatement; -t 1 (no read-ahead) gives the same bytes"""
+    g = synth.genome(30000, 9)
+    sets = []
+    for i in range(5):
+        b, o = synth.reads(1500 + 300 * i, 90 + 10 * i, seed=20 + i, g=g, n_frac=0.05, lower_frac=0.1)
+        q = np.random.default_rng(i).integers(35, 74, len(b)).astype(np.uint8)
+        fmt, gz = [("fq", True), ("fa", True), ("fq", False), ("fq", True), ("fa", True)][i]
+        sets.append((b, o, q if fmt == "fq" else None, _write_inputs(tmp_path, b, o, "in%d" % i, fmt, gz=gz, qual=q if fmt == "fq" else None)))
+    empty = tmp_path / "empty.fa.gz"
+    with gzip.open(empty, "wb") as f:
+        f.write(b"")
+    out = str(tmp_path / "ra.ctx")
+    args = ["build", "-k", "31", "-n", "1M", "--sort", "-Q", "12", "-O", "33", "-s", "a", "--seq", sets[0][3], "--seq", sets[1][3],
+            "--seq", sets[2][3], "--seq", str(empty), "-s", "b", "--seq", sets[3][3], "--seq", sets[4][3]]
+    rc, _, err = run(31, *(args[:1] + ["-t", "4"] + args[1:] + [out]))
+    assert rc == 0, err
+    og = orc.Graph(31, 2, 1 << 20)
+    og.set_sample(0, "a"); og.set_sample(1, "b")
+    for col, (b, o, q, _) in zip((0, 0, 0, 1, 1), sets):
+        st = og.add_reads(col, b, o, quals=q, fq_cutoff=45 if q is not None else 0)
+        og.update_stats(col, st)
+        if col == 0 and q is not None and _ == sets[2][3]:
+            og.update_stats(0, orc.Stats())     # the empty file: a file with no reads still updates the colour's statistics
+    want = og.ctx_bytes(True)
+    got = open(out, "rb").read()
+    assert got == want
+    out1 = str(tmp_path / "ra1.ctx")
+    rc, _, err = run(31, *(args[:1] + ["-t", "1"] + args[1:] + [out1]))
+    assert rc == 0, err
+    assert open(out1, "rb").read() == want

@@ -27,6 +27,23 @@ fq = os.path.join(out, "reads.fq")
 rec.tofile(fq)
 print("wrote %s: %.2f GB, %d reads" % (fq, os.path.getsize(fq) / 1e9, NR), flush=True)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mccortex_amd", "bin", "mccortex31")
+if os.environ.get("GZ"):   # GZ=1: the same reads as four .gz files: do the reader threads inflate them side by side?
+    parts = []
+    for i in range(4):
+        pth = os.path.join(out, "part%d.fq" % i)
+        rec[i * NR // 4:(i + 1) * NR // 4].tofile(pth)
+        subprocess.run(["gzip", "-1", "-f", pth], check=True)
+        parts.append(pth + ".gz")
+    print("wrote 4 x %.2f GB .gz" % (os.path.getsize(parts[0]) / 1e9), flush=True)
+    for t in ("1", "2", "4", "8"):
+        t0 = time.perf_counter()
+        a = [exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp", "--sort", "-t", t]
+        for pth in parts:
+            a += ["--seq", pth]
+        p = subprocess.run(a + [os.path.join(out, "o.ctx")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dt = time.perf_counter() - t0
+        print("build of 4 .gz files, -t %s: rc=%d wall %.2f s (%.2f G bases/s)" % (t, p.returncode, dt, NR * 150 / dt / 1e9), flush=True)
+    sys.exit(0)
 VARIANTS = (["--sort", "-t", "1"], ["--sort", "-t", "2"], ["--sort", "-t", "8"], ["--sort", "-t", "32"], ["-t", "32"])
 if os.environ.get("PREFS"):   # e.g. PREFS=1: the read preferences that take the reads through the cutting kernels
     VARIANTS = (["--sort", "-t", "8"], ["--sort", "-t", "8", "-Q", "10"], ["--sort", "-t", "8", "-H", "8"],
