@@ -179,7 +179,13 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   const uint64_t spb = (nsub + (1ull << lb1) - 1) >> lb1;
   nsub = spb << lb1;
   if (nsub >= (1ull << 31)) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }
-  const uint64_t slots = nsub * sub_slots;
+  // overflow area behind the hash-addressed slots (mcx_kernels.h, ovf_start): 1/32 of the table,
+  // at least one sub-table's worth
+  uint64_t novf = std::max<uint64_t>(sub_slots, (nsub * sub_slots / 32 + sub_slots - 1) / sub_slots * sub_slots);
+  if (const char *e = getenv("MCX_OVERFLOW_SLOTS")) novf = strtoull(e, nullptr, 10) / kBucket * kBucket;  // tests
+  if (novf / kBucket >= (1ull << 32)) novf = ((1ull << 32) - 1) * kBucket;
+  const uint64_t slots = nsub * sub_slots + novf;
+  g->t.nmain = nsub * sub_slots;
   g->t.nslots = slots;
   g->t.lb1 = lb1;
   g->t.lbo = lbo;
@@ -390,7 +396,7 @@ template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, Tupl
 
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour, uint32_t sub0, uint32_t nsub)
 {
-  const size_t lds = Sub<W>::kSlots * (W + 1) * 8;
+  const size_t lds = Sub<W>::kSlots * (W + 1) * 8 + (MCX_LDS_QUEUE ? LdsQueue<W>::kTuples * 8 * W : 0);
   static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
   bool &once = once_dev[g->device & 63];
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
@@ -465,7 +471,7 @@ static uint32_t flush_group(const mcx_graph *g)
 static int ensure_defer(mcx_graph *g)
 {
   if (g->l1_keys) return MCX_OK;
-  g->nsub = (uint32_t)(g->t.nslots >> sub_shift_for_words(g->W));
+  g->nsub = (uint32_t)(g->t.nmain >> sub_shift_for_words(g->W));
   g->b1 = 1u << g->t.lb1;        // L1 bins = regions of the quotient hash
   g->subs_per_bin = g->t.spb;
   // packed tuples need 2k - lb1 <= 56 quotient bits in the top word, and the histograms must fit
@@ -482,6 +488,8 @@ static int ensure_defer(mcx_graph *g)
     g->defer_tuples = tcap;
     g->cap1 = (uint64_t)((double)tcap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + 8192;
     g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
+    g->cap1 = (g->cap1 + 1) & ~1ull;  // even: every segment starts 16-byte aligned (vector loads)
+    g->cap2 = (g->cap2 + 1) & ~1ull;
     if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) continue;
     const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1;
     const bool ok = hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W) == hipSuccess &&

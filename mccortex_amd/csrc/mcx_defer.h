@@ -69,6 +69,10 @@ struct BinOut {
   uint64_t ov_cap;
 };
 
+#ifndef MCX_VEC16
+#define MCX_VEC16 1    // 1: tuple segments are read with 16-byte loads where their alignment allows
+#endif
+#define MCX_LDS_AS __attribute__((address_space(3)))
 constexpr int kMaxBins = 2048;
 constexpr uint64_t kQMask = (1ull << 56) - 1;  // quotient bits of the top tuple word
 
@@ -516,6 +520,30 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
     Kmer<W> tk[PER];
     uint32_t ev[IN_FULL ? PER : 1], loc[PER];
     uint32_t okm = 0;  // tuples of this lane that are binned
+    // 16-byte loads when the segments are 16-byte aligned (one-word tuples: a lane takes two
+    // neighbours; which lane holds which tuple of the tile is irrelevant to the partition)
+    const bool vec16 = MCX_VEC16 && !IN_FULL && (((uintptr_t)in.keys & 15u) == 0) && (W == 2 || (in.seg_cap & 1u) == 0);
+    if (vec16) {
+      const ulonglong2 *kin2 = reinterpret_cast<const ulonglong2 *>(kin);
+#pragma unroll
+      for (int q = 0; q < PER; q += (W == 1 ? 2 : 1)) {
+        const uint32_t p = (uint32_t)(q / (W == 1 ? 2 : 1)) * kThreads + tid;
+        const uint32_t i = W == 1 ? 2 * p : p;
+        tk[q].w[0] = 0; tk[q + (W == 1 ? 1 : 0)].w[W - 1] = 0;
+        if (i < n) {
+          const ulonglong2 x = kin2[p];
+          okm |= 1u << q;
+          if (W == 1) {
+            tk[q].w[0] = x.x;
+            tk[q + (W == 1 ? 1 : 0)].w[0] = x.y;
+            if (i + 1 < n) okm |= 2u << q;
+          } else {
+            tk[q].w[0] = x.x;
+            tk[q].w[W - 1] = x.y;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       const uint32_t i = (uint32_t)q * kThreads + tid;
@@ -527,6 +555,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
         if (W == 2) tk[q].w[W - 1] = kin[(uint64_t)i * W + 1];
         if (IN_FULL) ev[q] = ein[i];
       }
+    }
     }
 #pragma unroll
     for (int q = 0; q < PER; q++) {
@@ -588,79 +617,197 @@ template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? MCX_LD
 #define MCX_LDS_BATCH 4
 #endif
 constexpr int kLdsBatch = MCX_LDS_BATCH;
+#ifndef MCX_LDS_VEC16
+#define MCX_LDS_VEC16 0  // the same for the tuple loads of the LDS insert
+#endif
+#ifndef MCX_LDS_QUEUE
+#define MCX_LDS_QUEUE 1  // 1: one straight-line probe per occurrence; what it cannot finish is queued in LDS
+#endif
+// tuples of the LDS queue: what is left of a CU's 160 KiB beside two 64 KiB (three 48 KiB) slices
+template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : 288; };
+#ifndef MCX_LDS_PIPE
+#define MCX_LDS_PIPE 1   // 1: the tuple loads of batch i + 1 are in flight while batch i is applied
+#endif
 
-// find-or-insert one occurrence in the LDS-resident sub-table.  A whole bucket (kBucket slots) is
-// examined per step: the four key words are loaded together and compared in registers, so nearly
-// every lane is done after one step (walking slot by slot made the wave run as many iterations as
-// its unluckiest lane).  Slots fill in probe order and never empty, so "first empty slot of the
-// snapshot" + CAS keeps a key from ever being stored twice: a failed CAS re-reads the bucket.
+// LDS image of a sub-table.
+// One-word keys: the keys of all slots first (32 KiB), then the values (32 KiB).  A bucket's four
+// keys are 32 contiguous bytes; its two halves (slots 0-1, slots 2-3) are swapped in buckets with
+// bit 3 set, so that the 16-byte read of "slots 0-1" of a random bucket can land on any of the 16
+// positions of a 256-byte LDS row (tools/ubench_lds.hip: both halves of a random bucket cost 23.6
+// LDS cycles per wave this way, 47.3 with the 64-byte bucket image keys | values that was here
+// before -- its key reads could only start at 4 positions -- and 6.6 for a single 8-byte read).
+// Slots fill in probe order, so at the load factors a graph is built with (<= 0.75) most keys sit in
+// slots 0-1 of their bucket: the second half is only read by the lanes that need it.
+// Two-word keys: slot after slot (key word 0, key word 1, value).
+__device__ __forceinline__ uint32_t lds_phys1(uint32_t slot)  // position of logical slot `slot` (one-word keys)
+{
+  return slot ^ ((slot >> 4) & 2u);  // bit 1 (which half) ^= bit 5 of the slot (= bit 3 of the bucket)
+}
+constexpr uint32_t kLdsVal1 = 4096;  // word offset of the values in the one-word image
+
+// find-or-insert one occurrence in the LDS-resident sub-table.  Half a bucket (one-word keys) or a
+// whole one (two-word keys) is examined per step: the key words are loaded together and compared
+// in registers, so nearly every lane is done after one step (walking slot by slot made the wave run
+// as many iterations as its unluckiest lane).  Slots fill in probe order and never empty, so "first
+// empty slot of the snapshot" + CAS keeps a key from ever being stored twice: a failed CAS re-reads.
+// Returns false when the sub-table is full and does not hold the key: the occurrence then belongs
+// to the overflow area (mcx_kernels.h, ovf_start), which the caller updates in HBM.
+// (LDS-typed pointers: through a generic pointer a volatile vector load becomes a FLAT load followed
+// by s_waitcnt vmcnt(0), which also waits for every global load in flight.)
 template <int W>
-__device__ __forceinline__ void lds_apply(unsigned long long *lds, const Kmer<W> &key, uint32_t bucket, uint32_t e,
+__device__ __forceinline__ bool lds_apply(unsigned long long *lds, const Kmer<W> &key, uint32_t bucket, uint32_t e,
                                           uint32_t &n_novel, uint32_t &full)
 {
-  // LDS image of a bucket.  One-word keys: the four keys first, then the four values
-  // (k0 k1 k2 k3 | v0 v1 v2 v3), so that a probe reads the keys with two 16-byte loads.  Two-word
-  // keys: slot after slot (key word 0, key word 1, value).
-  constexpr int R = W + 1;
-  constexpr int KS = W == 1 ? 1 : R;              // words between the first key words of two slots
   const unsigned long long want = key.w[0] | kFlag;
-  uint32_t b = bucket, steps = 0;
-  for (;;) {
-    unsigned long long *bp = lds + (size_t)b * (kBucket * R);
-    unsigned long long k[kBucket];
-    if (W == 1) {
-      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-      const u64x2 k01 = *reinterpret_cast<const volatile u64x2 *>(bp);      // (volatile: re-read on every step)
-      const u64x2 k23 = *reinterpret_cast<const volatile u64x2 *>(bp + 2);
-      k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
-    } else {
-#pragma unroll
-      for (int j = 0; j < kBucket; j++) k[j] = __hip_atomic_load(bp + j * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    int hit = -1, empty = -1;
-    bool retry = false;
-#pragma unroll
-    for (int j = kBucket - 1; j >= 0; j--) {
-      if (k[j] == 0) empty = j;
-      if (W == 1) {  // (no pending state for one-word keys: compare as is)
-        if (k[j] == want) hit = j;
-      } else if ((k[j] & ~kPending) == want) {
-        if (k[j] & kPending) retry = true;  // its owner has not published word 1 yet
-        else if (__hip_atomic_load(bp + j * R + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1]) hit = j;
+  uint32_t steps = 0;
+  if constexpr (W == 1) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef MCX_LDS_AS const volatile u64x2 lds_cv;  // (volatile: re-read on every step)
+    uint32_t s = bucket * kBucket;                  // logical slot of the pair being examined
+    for (;;) {
+      const uint32_t p = lds_phys1(s);
+      const u64x2 kk = *(lds_cv *)(lds + p);
+      int hit = -1, empty = -1;
+      if (kk.y == 0) empty = 1;
+      if (kk.x == 0) empty = 0;
+      if (kk.y == want) hit = 1;
+      if (kk.x == want) hit = 0;
+      if (hit >= 0) {
+        unsigned long long *val = lds + kLdsVal1 + p + hit;
+        const unsigned long long old = atomicAdd(val, 256ULL);
+        if (e & ~(uint32_t)old) atomicOr(val, (unsigned long long)e);
+        return true;
       }
+      if (empty >= 0) {
+        if (atomicCAS(lds + p + empty, 0ULL, want) == 0) {
+          unsigned long long *val = lds + kLdsVal1 + p + empty;
+          n_novel++;
+          atomicAdd(val, 256ULL);
+          if (e) atomicOr(val, (unsigned long long)e);
+          return true;
+        }
+        if (++steps > (1u << 22)) { full = 1; return true; }
+        continue;  // somebody took the slot: look at the pair again
+      }
+      s = (s + 2) & (uint32_t)(Sub<W>::kSlots - 1);
+      if (s == bucket * kBucket) return false;  // a full sub-table: every slot seen without a hit or a free one
     }
-    if (hit >= 0) {
-      unsigned long long *val = W == 1 ? bp + kBucket + hit : bp + hit * R + W;
-      const unsigned long long old = atomicAdd(val, 256ULL);
-      if (e & ~(uint32_t)old) atomicOr(val, (unsigned long long)e);
-      return;
-    }
-    if (retry) {
-      if (++steps > (1u << 22)) { full = 1; return; }
-      continue;
-    }
-    if (empty >= 0) {
-      unsigned long long *r = bp + empty * KS;
-      unsigned long long *val = W == 1 ? bp + kBucket + empty : r + W;
-      const unsigned long long desired = (W == 1) ? want : (want | kPending);
-      if (atomicCAS(r, 0ULL, desired) == 0) {
-        if (W == 2) {
+  } else {
+    constexpr int R = W + 1;
+    uint32_t b = bucket;
+    for (;;) {
+      unsigned long long *bp = lds + (size_t)b * (kBucket * R);
+      unsigned long long k[kBucket];
+#pragma unroll
+      for (int j = 0; j < kBucket; j++)
+        k[j] = __hip_atomic_load((MCX_LDS_AS unsigned long long *)(bp + j * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int hit = -1, empty = -1;
+      bool retry = false;
+#pragma unroll
+      for (int j = kBucket - 1; j >= 0; j--) {
+        if (k[j] == 0) empty = j;
+        if ((k[j] & ~kPending) == want) {
+          if (k[j] & kPending) retry = true;  // its owner has not published word 1 yet
+          else if (__hip_atomic_load((MCX_LDS_AS unsigned long long *)(bp + j * R + 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1]) hit = j;
+        }
+      }
+      if (hit >= 0) {
+        unsigned long long *val = bp + hit * R + W;
+        const unsigned long long old = atomicAdd(val, 256ULL);
+        if (e & ~(uint32_t)old) atomicOr(val, (unsigned long long)e);
+        return true;
+      }
+      if (retry) {
+        if (++steps > (1u << 22)) { full = 1; return true; }
+        continue;
+      }
+      if (empty >= 0) {
+        unsigned long long *r = bp + empty * R;
+        if (atomicCAS(r, 0ULL, want | kPending) == 0) {
           __hip_atomic_store(r + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_store(r, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          n_novel++;
+          atomicAdd(r + W, 256ULL);
+          if (e) atomicOr(r + W, (unsigned long long)e);
+          return true;
         }
-        n_novel++;
-        atomicAdd(val, 256ULL);
-        if (e) atomicOr(val, (unsigned long long)e);
-        return;
+        if (++steps > (1u << 22)) { full = 1; return true; }
+        continue;  // somebody took the slot: look at the bucket again
       }
-      if (++steps > (1u << 22)) { full = 1; return; }
-      continue;  // somebody took the slot: look at the bucket again
+      if (++steps > Sub<W>::kBuckets + (1u << 22)) { full = 1; return true; }
+      b = (b + 1) & (Sub<W>::kBuckets - 1);
+      if (b == bucket) return false;  // a full sub-table: every bucket seen without a hit or a free slot
     }
-    if (++steps > Sub<W>::kBuckets + (1u << 22)) { full = 1; return; }
-    b = (b + 1) & (Sub<W>::kBuckets - 1);
-    // a full sub-table: every bucket seen without a hit or a free slot
-    if (b == bucket) { full = 1; return; }
   }
+}
+
+// One straight-line probe of the start bucket: the common cases -- the key is there, or it is new
+// and the bucket has a free slot -- without a loop.  Returns false for everything else (bucket full
+// of other keys, slot lost to another lane, two-word key still pending): those occurrences are set
+// aside and finished with lds_apply by densely packed lanes.  Why: the insert kernel is bound by
+// instruction issue (~150 instructions per occurrence), and in a loop a wave pays a whole extra
+// iteration whenever ONE of its 64 lanes has to move on to the next bucket (3 % of the lanes at
+// load 0.3: 86 % of the waves).
+template <int W>
+__device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &key, uint32_t bucket, uint32_t e, uint32_t &n_novel)
+{
+  const unsigned long long want = key.w[0] | kFlag;
+  unsigned long long k[kBucket];
+  unsigned long long *kp[kBucket], *vp[kBucket];  // key word 0 / value of logical slot j
+  if constexpr (W == 1) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef MCX_LDS_AS const u64x2 lds_c;
+    const uint32_t sw = (bucket >> 3) & 1u;
+    unsigned long long *b0 = lds + bucket * kBucket;
+    unsigned long long *h0 = b0 + 2 * sw, *h1 = b0 + 2 * (sw ^ 1u);
+    const u64x2 a = *(lds_c *)h0;
+    const u64x2 b = *(lds_c *)h1;
+    k[0] = a.x; k[1] = a.y; k[2] = b.x; k[3] = b.y;
+    kp[0] = h0; kp[1] = h0 + 1; kp[2] = h1; kp[3] = h1 + 1;
+#pragma unroll
+    for (int j = 0; j < kBucket; j++) vp[j] = kp[j] + kLdsVal1;
+  } else {
+    constexpr int R = W + 1;
+    unsigned long long *bp = lds + (size_t)bucket * (kBucket * R);
+#pragma unroll
+    for (int j = 0; j < kBucket; j++) {
+      kp[j] = bp + j * R;
+      vp[j] = kp[j] + W;
+      k[j] = __hip_atomic_load((MCX_LDS_AS unsigned long long *)kp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  unsigned long long *hk = nullptr, *hv = nullptr, *ek = nullptr, *evp = nullptr;
+#pragma unroll
+  for (int j = kBucket - 1; j >= 0; j--) {
+    if (k[j] == 0) { ek = kp[j]; evp = vp[j]; }
+    if (k[j] == want) { hk = kp[j]; hv = vp[j]; }  // (a pending two-word key differs in kPending: no hit)
+  }
+  if (W == 2 && hk) {
+    if (__hip_atomic_load((MCX_LDS_AS unsigned long long *)(hk + 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != key.w[W - 1]) {
+      // same first word, other second word: the key may still sit further down this bucket
+      return false;
+    }
+  }
+  if (hk) {
+    const unsigned long long old = atomicAdd(hv, 256ULL);
+    if (e & ~(uint32_t)old) atomicOr(hv, (unsigned long long)e);
+    return true;
+  }
+  if (W == 2) {  // any slot of the bucket that shares the first key word could be this key (or be pending)
+#pragma unroll
+    for (int j = 0; j < kBucket; j++)
+      if ((k[j] & ~kPending) == want) return false;
+  }
+  if (!ek) return false;
+  if (atomicCAS(ek, 0ULL, W == 1 ? want : (want | kPending)) != 0) return false;
+  if (W == 2) {
+    __hip_atomic_store(ek + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(ek, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  n_novel++;
+  atomicAdd(evp, 256ULL);
+  if (e) atomicOr(evp, (unsigned long long)e);
+  return true;
 }
 
 // The slice of one sub-table in flight between HBM and LDS: up to 8 16-byte vectors per thread,
@@ -707,16 +854,16 @@ template <int W, bool ONECOL, int T>
 __device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, const SliceRegs &v)
 {
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(lds);
-  if (ONECOL && W == 1) {  // vector q * T + tid = slot s = (key, value) -> bucket image k0..k3 | v0..v3
-#define MCX_ST(m, q) { const uint32_t sl = (uint32_t)(q * T + tid); unsigned long long *bp = lds + (size_t)(sl >> 2) * 8 + (sl & 3u); bp[0] = v.m.x; bp[4] = v.m.y; }
+  if (ONECOL && W == 1) {  // vector q * T + tid = slot (key, value) -> keys | values
+#define MCX_ST(m, q) { const uint32_t ph = lds_phys1((uint32_t)(q * T + tid)); lds[ph] = v.m.x; lds[kLdsVal1 + ph] = v.m.y; }
     MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5) MCX_ST(g, 6) MCX_ST(h, 7)
 #undef MCX_ST
   } else if (ONECOL) {
 #define MCX_ST(m, q) dst[q * T + tid] = make_ulonglong2(v.m.x, v.m.y);
     MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5)
 #undef MCX_ST
-  } else if (W == 1) {  // slots 2p, 2p + 1 share a bucket: their keys are one vector, their values another
-#define MCX_PUT1(q, kv, vv) { const uint32_t p = (uint32_t)(q * T + tid); ulonglong2 *bq = dst + (size_t)(p >> 1) * 4 + (p & 1u); bq[0] = make_ulonglong2(kv.x, kv.y); bq[2] = make_ulonglong2(vv.x, vv.y); }
+  } else if (W == 1) {  // slots 2p, 2p + 1 are one half of a bucket: their keys are one vector, their values another
+#define MCX_PUT1(q, kv, vv) { const uint32_t ph = lds_phys1(2u * (uint32_t)(q * T + tid)) >> 1; dst[ph] = make_ulonglong2(kv.x, kv.y); dst[kLdsVal1 / 2 + ph] = make_ulonglong2(vv.x, vv.y); }
     MCX_PUT1(0, v.a, v.e) MCX_PUT1(1, v.b, v.f) MCX_PUT1(2, v.c, v.g) MCX_PUT1(3, v.d, v.h)
 #undef MCX_PUT1
   } else {              // slots 2p, 2p + 1 = 6 words = vectors 3p .. 3p + 2: k0a k0b | v0 k1a | k1b v1
@@ -736,9 +883,8 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
     ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(t.rec + s0 * 2);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      const uint32_t sl = (uint32_t)(q * T + tid);
-      const unsigned long long *bp = lds + (size_t)(sl >> 2) * 8 + (sl & 3u);
-      dst[sl] = make_ulonglong2(bp[0], bp[4]);
+      const uint32_t sl = (uint32_t)(q * T + tid), ph = lds_phys1(sl);
+      dst[sl] = make_ulonglong2(lds[ph], lds[kLdsVal1 + ph]);
     }
   } else if (ONECOL) {
     ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(t.rec + s0 * (W + 1));
@@ -750,10 +896,9 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
     ulonglong2 *V = reinterpret_cast<ulonglong2 *>(t.val + (uint64_t)col * t.VC + s0);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const uint32_t p = (uint32_t)(q * T + tid);
-      const ulonglong2 *bq = src + (size_t)(p >> 1) * 4 + (p & 1u);
-      K[p] = bq[0];
-      V[p] = bq[2];
+      const uint32_t p = (uint32_t)(q * T + tid), ph = lds_phys1(2u * p) >> 1;
+      K[p] = src[ph];
+      V[p] = src[kLdsVal1 / 2 + ph];
     }
   } else {
     ulonglong2 *K = reinterpret_cast<ulonglong2 *>(t.rec + s0 * 2);
@@ -778,6 +923,13 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
   unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
+#if MCX_LDS_QUEUE
+  // occurrences that lds_try could not finish (packed tuples, as they came): behind the slice
+  unsigned long long *queue = lds + Sub<W>::kSlots * (W + 1);
+  constexpr uint32_t kQueueCap = LdsQueue<W>::kTuples;
+  __shared__ uint32_t s_nq;
+  if (tid == 0) s_nq = 0;
+#endif
 
   // sub-tables sub0 .. sub0 + nsub - 1; bin i of `bins` belongs to sub-table sub0 + i and is handed
   // back empty (fill reset) for the next group of regions.
@@ -804,40 +956,119 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
     __syncthreads();
 
     const uint64_t *kin = bins.keys + (uint64_t)bi * bins.cap * W;
-    auto load_batch = [&](uint64_t i0, Kmer<W> (&tk)[kLdsBatch]) {
+    // tuple j0 + idx(q) is the q-th of this thread's batch; with 16-byte loads (aligned bins) a
+    // one-word thread takes pairs of neighbours
+    const bool vec16 = MCX_LDS_VEC16 && (((uintptr_t)bins.keys & 15u) == 0) && (W == 2 || (bins.cap & 1u) == 0);
+    auto idx = [&](int q) -> uint32_t {
+      return (W == 1 && vec16) ? 2u * ((uint32_t)(q >> 1) * kLdsThreads + tid) + (uint32_t)(q & 1)
+                               : (uint32_t)q * kLdsThreads + tid;
+    };
+    // Loads are unconditional (an index past the fill reads tuple 0 of the bin, which is then not
+    // applied): without branches between them the compiler can count the loads in flight and wait
+    // for exactly the batch it is about to apply (s_waitcnt vmcnt(n)) instead of for all of them.
+    auto load_batch = [&](uint64_t j0, Kmer<W> (&tk)[kLdsBatch]) {
+      if (vec16) {
+        const ulonglong2 *kin2 = reinterpret_cast<const ulonglong2 *>(kin);
 #pragma unroll
-      for (int q = 0; q < kLdsBatch; q++) {
-        const uint64_t i = i0 + (uint64_t)q * kLdsThreads;
-        if (i < n) {
+        for (int q = 0; q < kLdsBatch; q += (W == 1 ? 2 : 1)) {
+          uint64_t i = j0 + idx(q);
+          i = i < n ? i : 0;  // (the pair's second word may lie past n: inside the bin, never applied)
+          const ulonglong2 x = kin2[W == 1 ? i / 2 : i];
+          tk[q].w[0] = x.x;
+          if (W == 1) tk[q + (W == 1 ? 1 : 0)].w[0] = x.y; else tk[q].w[W - 1] = x.y;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kLdsBatch; q++) {
+          uint64_t i = j0 + idx(q);
+          i = i < n ? i : 0;
           tk[q].w[0] = kin[i * W];
           if (W == 2) tk[q].w[W - 1] = kin[i * W + 1];
         }
       }
     };
-    auto apply_batch = [&](uint64_t i0, const Kmer<W> (&tk)[kLdsBatch]) {
+    // packed tuple + region -> full key, start bucket, edge byte
+    auto unpack = [&](const Kmer<W> &tp, Kmer<W> &key, uint32_t &bucket, uint32_t &e) {
+      e = (uint32_t)(tp.w[0] >> 56);
+      const Kmer<W> qq = tuple_q<W>(tp);
+      const uint32_t m = region_mix<W>(qq);
+      key = key_unquot<W>(qq, lbq_of(t), ((t.part << t.lb1) | region) ^ (m & ((1u << lbq_of(t)) - 1u)));
+      bucket = (m >> lbq_of(t)) & (Sub<W>::kBuckets - 1);
+    };
+    auto apply_slow = [&](const Kmer<W> &key, uint32_t bucket, uint32_t e) {
+      if (!lds_apply<W>(lds, key, bucket, e, n_novel, full))  // sub-table full: overflow area, in HBM
+        probe_insert<W, ONECOL>(t, key, ovf_start<W>(t, key), 0, 0, e, col, n_novel, full, true);
+    };
+    auto apply_batch = [&](uint64_t j0, const Kmer<W> (&tk)[kLdsBatch]) {
 #pragma unroll
       for (int q = 0; q < kLdsBatch; q++)
-        if (i0 + (uint64_t)q * kLdsThreads < n) {  // packed tuple + region -> full key, start bucket
-          const uint32_t e = (uint32_t)(tk[q].w[0] >> 56);
-          const Kmer<W> qq = tuple_q<W>(tk[q]);
-          const uint32_t m = region_mix<W>(qq);
-          const Kmer<W> key = key_unquot<W>(qq, lbq_of(t), ((t.part << t.lb1) | region) ^ (m & ((1u << lbq_of(t)) - 1u)));
-          lds_apply<W>(lds, key, (m >> lbq_of(t)) & (Sub<W>::kBuckets - 1), e, n_novel, full);
+        if (j0 + idx(q) < n) {
+          Kmer<W> key;
+          uint32_t bucket, e;
+          unpack(tk[q], key, bucket, e);
+#if MCX_LDS_QUEUE
+          if (!lds_try<W>(lds, key, bucket, e, n_novel)) {
+            const uint32_t qi = atomicAdd(&s_nq, 1u);
+            if (qi < kQueueCap) {
+              queue[qi * W] = tk[q].w[0];
+              if (W == 2) queue[qi * W + 1] = tk[q].w[W - 1];
+            } else {
+              apply_slow(key, bucket, e);
+            }
+          }
+#else
+          apply_slow(key, bucket, e);
+#endif
         }
     };
+    constexpr uint64_t kStep = (uint64_t)kLdsThreads * kLdsBatch;
+#if MCX_LDS_PIPE
+    // Two batches in flight: while one is applied (LDS only) the loads of the next are on their way.
+    // The next slice is requested after the first two batches (loads return in order, so those do
+    // not queue behind its 64 KiB).  Both variants of "is there a next slice" are straight-line code.
+    auto run = [&](auto has_next) {
+      Kmer<W> ta[kLdsBatch], tb[kLdsBatch];
+      load_batch(0, ta);
+      load_batch(kStep, tb);
+      if (decltype(has_next)::value) slice_load<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v);
+      for (uint64_t j0 = 0; j0 < n; j0 += 2 * kStep) {
+        apply_batch(j0, ta);
+        load_batch(j0 + 2 * kStep, ta);
+        apply_batch(j0 + kStep, tb);
+        load_batch(j0 + 3 * kStep, tb);
+      }
+    };
+    if (nb < nsub) run(std::true_type{}); else run(std::false_type{});
+#else
     {  // first batch of tuple loads, THEN the next slice: loads return in order, so the first
        // batch does not wait for the 64 KiB behind it
       Kmer<W> tk[kLdsBatch];
-      load_batch(tid, tk);
+      load_batch(0, tk);
       if (nb < nsub) slice_load<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v);
-      apply_batch(tid, tk);
+      apply_batch(0, tk);
     }
-    for (uint64_t i0 = (uint64_t)tid + (uint64_t)kLdsThreads * kLdsBatch; i0 < n; i0 += (uint64_t)kLdsThreads * kLdsBatch) {
+    for (uint64_t j0 = kStep; j0 < n; j0 += kStep) {
       Kmer<W> tk[kLdsBatch];
-      load_batch(i0, tk);
-      apply_batch(i0, tk);
+      load_batch(j0, tk);
+      apply_batch(j0, tk);
     }
+#endif
     __syncthreads();
+#if MCX_LDS_QUEUE
+    {  // the occurrences set aside: every lane takes one, all of them run the general probe loop
+      const uint32_t nq = min(s_nq, kQueueCap);
+      for (uint32_t i = tid; i < nq; i += kLdsThreads) {
+        Kmer<W> tp, key;
+        uint32_t bucket, e;
+        tp.w[0] = queue[i * W];
+        if (W == 2) tp.w[W - 1] = queue[i * W + 1];
+        unpack(tp, key, bucket, e);
+        apply_slow(key, bucket, e);
+      }
+      __syncthreads();
+      if (tid == 0) s_nq = 0;
+    }
+#endif
     slice_store<W, ONECOL, kLdsThreads>(t, sub, col, tid, lds);
     bi = nb;
   }

@@ -40,7 +40,8 @@ __host__ __device__ constexpr int sub_shift_for_words(int W) { return W == 1 ? 1
 
 struct TableView {
   uint64_t *rec;
-  uint64_t nslots;   // = (spb << lb1) sub-tables of Sub<W>::kSlots slots
+  uint64_t nslots;   // all slots: nmain hash-addressed ones, then the overflow area
+  uint64_t nmain;    // = (spb << lb1) sub-tables of Sub<W>::kSlots slots
   uint32_t lb1;      // log2 of the number of top-level regions ("L1 bins") of the table
   uint32_t lbo;      // log2 of the number of shards (GPUs) the global table is split over
   uint32_t part;     // which shard this table is (0 when lbo == 0)
@@ -193,14 +194,32 @@ __device__ __forceinline__ void update_value(uint64_t *val, uint64_t hint, uint3
   if (e & ~(uint32_t)hint & 0xffu) __hip_atomic_fetch_or(val, (uint64_t)e, MCX_RLX, MCX_AGENT);
 }
 
+// Overflow area.  A probe sequence never leaves its sub-table (that is what lets one workgroup own
+// a sub-table in LDS), so a sub-table can fill up while the table as a whole has room: at 95 % load
+// about one sub-table in 2000 does.  The reference keeps going until 20 buckets in a row are full
+// (hash_table.c:250-281, REHASH_LIMIT hash_table.h:10), i.e. far beyond that load.  Keys that find
+// their sub-table full therefore go to a small common area behind the hash-addressed slots
+// ([nmain, nslots), 1/32 of the table), addressed by Lookup3 and probed linearly over the whole
+// area.  "A key is in the overflow area only if its sub-table is full" is stable -- sub-tables
+// never empty -- so find-or-insert stays well defined: scan the sub-table; no hit and no free slot
+// -> same protocol in the overflow area; that one full as well -> "Hash table is full".
+template <int W> __device__ __forceinline__ uint64_t ovf_start(const TableView &t, const Kmer<W> &key)
+{
+  const uint32_t h = kmer_hash<W>(key, 0, nullptr);
+  const uint64_t nb = (t.nslots - t.nmain) / kBucket;
+  return t.nmain + (uint64_t)__umulhi(h, (uint32_t)nb) * kBucket;
+}
+
+// `ovf`: start in the overflow area (the caller has seen the key's sub-table full)
 template <int W, bool ONECOL>
 __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &key, uint64_t slot,
                                              uint64_t cur, uint64_t hint, uint32_t e, uint32_t col,
-                                             uint32_t &novel, uint32_t &full)
+                                             uint32_t &novel, uint32_t &full, bool ovf = false)
 {
   const uint64_t want = key.w[0] | kFlag;
   uint32_t probes = 0;
-  bool fresh = true;  // `cur`/`hint` were preloaded for this slot
+  uint64_t limit = ovf ? t.nslots - t.nmain : t.max_probe;
+  bool fresh = !ovf;  // `cur`/`hint` were preloaded for this slot
   for (;;) {
     uint64_t *r = key_ptr_t<W, ONECOL>(t, slot);
     uint64_t *v = val_ptr_t<W, ONECOL>(t, slot, col);
@@ -235,7 +254,7 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
         if (cur & kPending) {  // owner has not published word 1 yet: re-read at agent scope
           cur = __hip_atomic_load(r, MCX_RLX, MCX_AGENT);
           fresh = true; hint = 0;
-          if (++probes > t.max_probe * 64u) { full = 1; return; }
+          if (++probes > limit * 64u) { full = 1; return; }
           continue;
         }
         const uint64_t w1 = __hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT);
@@ -246,9 +265,17 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
         return;
       }
     }
-    if (++probes > t.max_probe) { full = 1; return; }
+    if (++probes >= limit) {
+      if (ovf || t.nslots == t.nmain) { full = 1; return; }
+      ovf = true;  // the whole sub-table was seen without a hit or a free slot
+      probes = 0;
+      limit = t.nslots - t.nmain;
+      slot = ovf_start<W>(t, key);
+      continue;
+    }
     slot++;
-    if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots;  // wrap inside the sub-table
+    if (!ovf) { if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots; }  // wrap inside the sub-table
+    else if (slot == t.nslots) slot = t.nmain;
   }
 }
 
@@ -264,6 +291,8 @@ __device__ __forceinline__ uint64_t find_or_insert_rec(const TableView &t, const
   const uint64_t want = key.w[0] | kFlag;
   uint64_t slot = key_slot<W>(t, key);
   uint32_t probes = 0;
+  uint64_t limit = t.max_probe;
+  bool ovf = false;
   for (;;) {
     uint64_t *r = key_ptr(t, slot);
     uint64_t cur = __hip_atomic_load(r, MCX_RLX, MCX_AGENT);
@@ -285,14 +314,22 @@ __device__ __forceinline__ uint64_t find_or_insert_rec(const TableView &t, const
     if ((cur & ~kPending) == want) {
       if (W == 1) return slot;
       if (cur & kPending) {  // owner has not published word 1 yet
-        if (++probes > t.max_probe * 64u) { full = 1; return kNoSlot; }
+        if (++probes > limit * 64u) { full = 1; return kNoSlot; }
         continue;
       }
       if (__hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT) == key.w[W - 1]) return slot;
     }
-    if (++probes > t.max_probe) { full = 1; return kNoSlot; }
+    if (++probes >= limit) {  // sub-table full: the key is in the overflow area or nowhere (see ovf_start)
+      if (ovf || t.nslots == t.nmain) { if (!must_exist) full = 1; return kNoSlot; }
+      ovf = true;
+      probes = 0;
+      limit = t.nslots - t.nmain;
+      slot = ovf_start<W>(t, key);
+      continue;
+    }
     slot++;
-    if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots;
+    if (!ovf) { if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots; }
+    else if (slot == t.nslots) slot = t.nmain;
   }
 }
 

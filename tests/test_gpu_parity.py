@@ -361,3 +361,53 @@ def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
     if nparts > 1:
         sizes = [len(b) for b in bodies]
         assert min(sizes) > 0.5 * max(sizes)   # minimizer ownership is reasonably balanced
+
+
+def _distinct_kmer_reads(n_kmers, k, seed):
+    """One long random read: ~n_kmers distinct k-mers (plus their edges)."""
+    rng = np.random.default_rng(seed)
+    n = n_kmers + k - 1
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+    # cut into reads of 1000 bases that overlap by k - 1: the same k-mer set, more contigs
+    step = 1000 - (k - 1)
+    starts = np.arange(0, n - k + 1, step)
+    lens = np.minimum(1000, n - starts)
+    offs = np.zeros(len(starts) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    idx = np.repeat(starts - offs[:-1].astype(np.int64), lens) + np.arange(int(offs[-1]))
+    return np.ascontiguousarray(bases[idx]), offs
+
+
+@pytest.mark.parametrize("k,defer", [(31, 1), (31, 0), (63, 1)])
+def test_high_load_factor_spills_to_overflow_area(mcx, orc, k, defer):
+    """hash_table.c:250-281 keeps inserting far beyond 90 % load; here a sub-table that fills up
+    spills into the overflow area instead of ending the build.  95 % of a 2^20-slot table."""
+    cap = 1 << 20
+    bases, offs = _distinct_kmer_reads(int(0.95 * cap), k, seed=5)
+    og = orc.Graph(k, 1, 4 * cap)
+    og.add_reads(0, bases, offs)
+    g = mcx.Graph(k, 1, cap)
+    slots, _ = g.capacity()
+    assert slots <= cap + cap // 32 + 4096
+    g.configure("defer", defer)
+    g.add_reads(0, bases, offs)
+    g.sync()
+    assert g.nkmers == og.nkmers > 0.94 * cap
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    # a second pass finds every key again (sub-table or overflow area): coverage doubles, no new node
+    g.add_reads(0, bases, offs)
+    g.sync()
+    assert g.nkmers == og.nkmers
+    og.add_reads(0, bases, offs)
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    g.close()
+
+
+def test_really_full_table_is_still_reported(mcx):
+    bases, offs = _distinct_kmer_reads(int(1.2 * (1 << 16)), 31, seed=6)
+    g = mcx.Graph(31, 1, 1 << 16)
+    g.add_reads(0, bases, offs)
+    with pytest.raises(mcx.McxError) as ei:
+        g.sync()
+    assert ei.value.code == mcx.MCX_ERR_FULL and "Hash table is full" in str(ei.value)
+    g.close()
