@@ -753,7 +753,8 @@ __device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &
 {
   const unsigned long long want = key.w[0] | kFlag;
   unsigned long long k[kBucket];
-  unsigned long long *kp[kBucket], *vp[kBucket];  // key word 0 / value of logical slot j
+  unsigned long long *kp[kBucket];  // key word 0 of logical slot j; its value is kVal words further on
+  constexpr uint32_t kVal = W == 1 ? kLdsVal1 : (uint32_t)W;
   if constexpr (W == 1) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef MCX_LDS_AS const u64x2 lds_c;
@@ -764,39 +765,31 @@ __device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &
     const u64x2 b = *(lds_c *)h1;
     k[0] = a.x; k[1] = a.y; k[2] = b.x; k[3] = b.y;
     kp[0] = h0; kp[1] = h0 + 1; kp[2] = h1; kp[3] = h1 + 1;
-#pragma unroll
-    for (int j = 0; j < kBucket; j++) vp[j] = kp[j] + kLdsVal1;
   } else {
     constexpr int R = W + 1;
     unsigned long long *bp = lds + (size_t)bucket * (kBucket * R);
 #pragma unroll
     for (int j = 0; j < kBucket; j++) {
       kp[j] = bp + j * R;
-      vp[j] = kp[j] + W;
       k[j] = __hip_atomic_load((MCX_LDS_AS unsigned long long *)kp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  unsigned long long *hk = nullptr, *hv = nullptr, *ek = nullptr, *evp = nullptr;
+  unsigned long long *hk = nullptr;
 #pragma unroll
-  for (int j = kBucket - 1; j >= 0; j--) {
-    if (k[j] == 0) { ek = kp[j]; evp = vp[j]; }
-    if (k[j] == want) { hk = kp[j]; hv = vp[j]; }  // (a pending two-word key differs in kPending: no hit)
-  }
-  if (W == 2 && hk) {
-    if (__hip_atomic_load((MCX_LDS_AS unsigned long long *)(hk + 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != key.w[W - 1]) {
-      // same first word, other second word: the key may still sit further down this bucket
-      return false;
-    }
-  }
+  for (int j = kBucket - 1; j >= 0; j--)
+    if (k[j] == want) hk = kp[j];  // (a pending two-word key differs in kPending: no hit)
   if (hk) {
-    const unsigned long long old = atomicAdd(hv, 256ULL);
-    if (e & ~(uint32_t)old) atomicOr(hv, (unsigned long long)e);
+    if (W == 2 && __hip_atomic_load((MCX_LDS_AS unsigned long long *)(hk + 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != key.w[W - 1])
+      return false;  // same first word, other second word: the key may still sit further down
+    const unsigned long long old = atomicAdd(hk + kVal, 256ULL);
+    if (e & ~(uint32_t)old) atomicOr(hk + kVal, (unsigned long long)e);
     return true;
   }
-  if (W == 2) {  // any slot of the bucket that shares the first key word could be this key (or be pending)
+  unsigned long long *ek = nullptr;
 #pragma unroll
-    for (int j = 0; j < kBucket; j++)
-      if ((k[j] & ~kPending) == want) return false;
+  for (int j = kBucket - 1; j >= 0; j--) {
+    if (k[j] == 0) ek = kp[j];
+    if (W == 2 && (k[j] & ~kPending) == want) return false;  // could be this key, not yet published
   }
   if (!ek) return false;
   if (atomicCAS(ek, 0ULL, W == 1 ? want : (want | kPending)) != 0) return false;
@@ -805,8 +798,8 @@ __device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &
     __hip_atomic_store(ek, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   n_novel++;
-  atomicAdd(evp, 256ULL);
-  if (e) atomicOr(evp, (unsigned long long)e);
+  atomicAdd(ek + kVal, 256ULL);
+  if (e) atomicOr(ek + kVal, (unsigned long long)e);
   return true;
 }
 
