@@ -102,6 +102,22 @@ int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value);
 /* "kernel calls total_ms" per line for the launches recorded since "profile" was set. */
 int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen);
 
+/* One table over several GPUs of a node, driven by one host process: what the reference's batch
+ * loop (src/commands/ctx_build.c:384-407) becomes when the hash table it feeds is split by hash
+ * prefix across `ndevices` devices (a power of two <= 32; a device may be named more than once).
+ * SURVEY.md 8(b) sketched this as the devices / ndevices arguments of mcx_graph_create.  The handle
+ * that comes back is used like any other: mcx_graph_add_reads (the batch is dealt out to the
+ * shards, each k-merises its piece and sends every other shard its occurrences with peer copies
+ * over xGMI), mcx_graph_add_reads_pcr, mcx_graph_add_records, sync / statistics / scans / checksum,
+ * mcx_graph_export (sorted: one device sort merges the shards).  mcx_graph_add_stream_dev takes a
+ * stream on any of the devices.  Not available on such a handle: intersect / must-exist mode and
+ * the device-pointer exchange calls below (those take a single shard).  ndevices == 1 is
+ * mcx_graph_create. */
+int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers,
+                           const int *devices, int ndevices);
+/* Devices the handle spans (1 for an ordinary graph). */
+int mcx_graph_ndevices(const mcx_graph *g);
+
 /* Slots actually allocated (>= capacity_kmers) and bytes of HBM held. */
 int mcx_graph_capacity(const mcx_graph *g, uint64_t *slots, uint64_t *bytes);
 

@@ -12,6 +12,9 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <array>
+#include <cmath>
+#include <memory>
 #include <vector>
 #include <thread>
 #include <chrono>
@@ -67,6 +70,7 @@ static uint64_t stage_bytes()
 }
 #define kStageBytes stage_bytes()
 
+struct mcx_group;
 struct mcx_graph {
   int k = 0, W = 0, ncols = 0, device = 0;
   hipStream_t stream = nullptr;
@@ -105,10 +109,33 @@ struct mcx_graph {
   bool profile = false;
   struct Span { const char *name; hipEvent_t a, b; };
   std::vector<Span> spans;
+  // ---- multi-GPU table (mcx_multi.h): a shard knows its group; the handle the caller holds is a
+  // facade (as_group) whose calls are dealt out to the shards ----
+  mcx_group *group = nullptr;
+  int gidx = 0;
+  mcx_group *as_group = nullptr;
 };
 
 static int flush_deferred(mcx_graph *g);
 static void free_defer(mcx_graph *g);
+struct StreamLaunch;
+static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int colour);
+static void group_destroy(mcx_group *G);
+static int grp_drain(mcx_group *G);
+static int grp_sync(mcx_group *G);
+static int grp_device_stats(mcx_group *G, mcx_load_stats *out);
+static int grp_add_reads(mcx_group *G, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                         uint64_t nreads, uint8_t fq, uint8_t hp, mcx_load_stats *stats_accum);
+static int grp_add_reads_pcr(mcx_group *G, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                             uint64_t nreads, uint8_t fq1, uint8_t fq2, uint8_t hp, int paired, int matedir,
+                             mcx_load_stats *stats_accum);
+static int grp_add_records(mcx_group *G, const void *recs, uint64_t nrecs, int file_ncols, const int32_t *from_col,
+                           const int32_t *into_col, int nmap, uint32_t flags, mcx_records_stats *stats_accum);
+static int grp_export(mcx_group *G, mcx_graph *f, int sorted, mcx_sink_fn sink, void *ctx);
+static int grp_part_of_pointer(mcx_group *G, const void *d_ptr, mcx_graph **part);
+static mcx_graph *grp_part(mcx_group *G, int i);
+static int grp_n(mcx_group *G);
+#define NO_GROUP(g, what) do { if ((g) && (g)->as_group) return fail(MCX_ERR_ARG, what " takes a shard, not the multi-GPU handle"); } while (0)
 
 extern "C" const char *mcx_last_error(void) { return g_err; }
 extern "C" const char *mcx_version(void) { return "mccortex_amd 0.1 (gfx950)"; }
@@ -234,6 +261,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
 
 extern "C" void mcx_graph_destroy(mcx_graph *g)
 {
+  if (g && g->as_group) { group_destroy(g->as_group); delete g; return; }
   if (!g) return;
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
@@ -254,6 +282,11 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
 
 extern "C" int mcx_graph_reset(mcx_graph *g)
 {
+  if (g && g->as_group) {
+    int rc = grp_drain(g->as_group);
+    for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) rc = mcx_graph_reset(grp_part(g->as_group, i));
+    return rc;
+  }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
@@ -267,13 +300,20 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
 
 extern "C" int mcx_graph_capacity(const mcx_graph *g, uint64_t *slots, uint64_t *bytes)
 {
+  if (g && g->as_group) {
+    uint64_t s_ = 0, b_ = 0;
+    for (int i = 0; i < grp_n(g->as_group); i++) { uint64_t s1 = 0, b1 = 0; mcx_graph_capacity(grp_part(g->as_group, i), &s1, &b1); s_ += s1; b_ += b1; }
+    if (slots) *slots = s_;
+    if (bytes) *bytes = b_;
+    return MCX_OK;
+  }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (slots) *slots = g->t.nslots;
   if (bytes) *bytes = g->table_bytes;
   return MCX_OK;
 }
 
-extern "C" void *mcx_graph_stream(mcx_graph *g) { return g ? (void *)g->stream : nullptr; }
+extern "C" void *mcx_graph_stream(mcx_graph *g) { return !g ? nullptr : g->as_group ? (void *)grp_part(g->as_group, 0)->stream : (void *)g->stream; }
 
 // ---------------------------------------------------------------------------
 // kernel dispatch
@@ -546,6 +586,7 @@ static int defer_reserve(mcx_graph *g, int colour, uint64_t ub)
 
 static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
 {
+  if (g->group) return group_submit_stream(g->group, g->gidx, L, colour);  // shard of a multi-GPU table
   if (g->defer) { int rc = ensure_defer(g); if (rc != MCX_OK) return rc; }
   if (!g->defer) {
     DISPATCH_WC(g, launch_direct_t, g, L, colour);
@@ -571,6 +612,13 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
 
 extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value)
 {
+  if (g && key && g->as_group) {
+    if (!strcmp(key, "intersect") || !strcmp(key, "must_exist")) return fail(MCX_ERR_ARG, "--intersect needs the whole table on one device");
+    if (!strcmp(key, "defer") && !value) return fail(MCX_ERR_ARG, "a multi-GPU table always uses the partitioned insert");
+    int rc = grp_drain(g->as_group);
+    for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) rc = mcx_graph_configure(grp_part(g->as_group, i), key, value);
+    return rc;
+  }
   if (!g || !key) return fail(MCX_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(g->device));
   if (!strcmp(key, "defer")) {
@@ -623,6 +671,21 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
 // Text report "kernel calls total_ms" per line of the spans recorded since profiling was enabled.
 extern "C" int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen)
 {
+  if (g && buf && buflen && g->as_group) {  // one report per shard, each line prefixed with its index
+    size_t o = 0;
+    buf[0] = '\0';
+    std::vector<char> tmp(buflen);
+    for (int i = 0; i < grp_n(g->as_group); i++) {
+      int rc = mcx_graph_profile(grp_part(g->as_group, i), tmp.data(), tmp.size());
+      if (rc != MCX_OK) return rc;
+      for (char *ln = strtok(tmp.data(), "\n"); ln; ln = strtok(nullptr, "\n")) {
+        int n = snprintf(buf + o, buflen - o, "%s@%d%s\n", std::string(ln, strcspn(ln, " ")).c_str(), i, ln + strcspn(ln, " "));
+        if (n < 0 || (size_t)n >= buflen - o) return MCX_OK;
+        o += (size_t)n;
+      }
+    }
+    return MCX_OK;
+  }
   if (!g || !buf || !buflen) return fail(MCX_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipStreamSynchronize(g->stream));
@@ -647,6 +710,12 @@ extern "C" int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen)
 
 extern "C" int mcx_graph_add_stream_dev(mcx_graph *g, int colour, const void *d_stream, uint64_t nbytes)
 {
+  if (g && g->as_group) {  // the shard on whose device the stream lives k-merises it
+    mcx_graph *part = nullptr;
+    int rc = grp_part_of_pointer(g->as_group, d_stream, &part);
+    if (rc != MCX_OK) return rc;
+    return mcx_graph_add_stream_dev(part, colour, d_stream, nbytes);
+  }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
@@ -659,6 +728,7 @@ extern "C" int mcx_graph_add_stream_dev(mcx_graph *g, int colour, const void *d_
 extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, int nparts,
                                               uint64_t bin_capacity, void *d_keys, void *d_edges, void *d_counts)
 {
+  NO_GROUP(g, "mcx_graph_partition_stream_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (nparts < 1 || nparts > kMaxBins) return fail(MCX_ERR_ARG, "nparts must be 1..%d", kMaxBins);
   if (bin_capacity >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "bin capacity must be below 2^32 tuples");
@@ -676,6 +746,7 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
 
 extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_edges, uint64_t n)
 {
+  NO_GROUP(g, "mcx_graph_insert_tuples_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (!n) return MCX_OK;
@@ -704,6 +775,7 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
 extern "C" int mcx_graph_insert_tuple_segments_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_edges,
                                                    const void *d_counts, uint32_t nseg, uint64_t seg_cap)
 {
+  NO_GROUP(g, "mcx_graph_insert_tuple_segments_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (!nseg || !seg_cap) return MCX_OK;
@@ -732,6 +804,7 @@ static const uint32_t kShardRep = 8;
 extern "C" int mcx_graph_shard_layout(mcx_graph *g, uint64_t tuples_per_call, uint32_t *segs_per_owner,
                                       uint64_t *seg_cap, uint64_t *ov_cap)
 {
+  NO_GROUP(g, "mcx_graph_shard_layout");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   const uint32_t nparts = 1u << g->t.lbo, b1 = 1u << g->t.lb1;
   const uint64_t nseg = (uint64_t)nparts * kShardRep * b1;
@@ -743,18 +816,28 @@ extern "C" int mcx_graph_shard_layout(mcx_graph *g, uint64_t tuples_per_call, ui
   return MCX_OK;
 }
 
+static int shard_bins_launch(mcx_graph *g, const StreamLaunch &L, void *d_keys, void *d_counts, uint64_t seg_cap,
+                             void *d_ov_keys, void *d_ov_edges, void *d_ov_counts, uint64_t ov_cap);
+
 extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, void *d_keys,
                                         void *d_counts, uint64_t seg_cap, void *d_ov_keys, void *d_ov_edges,
                                         void *d_ov_counts, uint64_t ov_cap)
 {
   if (!g) return fail(MCX_ERR_ARG, "null graph");
-  if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  if (g->as_group) return fail(MCX_ERR_ARG, "device-pointer exchange calls take a shard, not the multi-GPU handle");
+  if (!nbytes) return MCX_OK;
+  StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
+  return shard_bins_launch(g, L, d_keys, d_counts, seg_cap, d_ov_keys, d_ov_edges, d_ov_counts, ov_cap);
+}
+
+static int shard_bins_launch(mcx_graph *g, const StreamLaunch &L, void *d_keys, void *d_counts, uint64_t seg_cap,
+                             void *d_ov_keys, void *d_ov_edges, void *d_ov_counts, uint64_t ov_cap)
+{
+  if (((uintptr_t)L.stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
   if (g->t.lb1 + g->t.lbo > 11) return fail(MCX_ERR_ARG, "too many (owner, region) bins");
   if (seg_cap >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "segment capacity must be below 2^32 tuples");
-  if (!nbytes) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
   const uint32_t nparts = 1u << g->t.lbo, b1 = 1u << g->t.lb1;
-  StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
   BinSpec bs{BIN_GLOBAL, nparts, nparts * b1, kShardRep, b1, 1, g->t.lb1, 0};
   BinOut out{(uint64_t *)d_keys, nullptr, (unsigned long long *)d_counts, seg_cap,
              (uint64_t *)d_ov_keys, (uint8_t *)d_ov_edges, (unsigned long long *)d_ov_counts, ov_cap};
@@ -767,6 +850,7 @@ extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint
 extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_counts,
                                           uint32_t nseg, uint64_t seg_cap, uint64_t ntuples)
 {
+  NO_GROUP(g, "mcx_graph_add_segments_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (!nseg) return MCX_OK;
@@ -805,6 +889,7 @@ extern "C" uint32_t mcx_superk_owner(const uint64_t *key_words, int kmer_size, i
 extern "C" int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positions_per_call, uint32_t *segs_per_owner,
                                        uint64_t *seg_cap)
 {
+  NO_GROUP(g, "mcx_graph_superk_layout");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1))) return fail(MCX_ERR_ARG, "shards must be a power of two <= 32");
   if (segs_per_owner) *segs_per_owner = kSuperkRep;
@@ -817,6 +902,7 @@ extern "C" int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positi
 extern "C" int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, int nparts, void *d_recs,
                                          void *d_counts, uint64_t seg_cap)
 {
+  NO_GROUP(g, "mcx_graph_superk_bins_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..31 (got %d)", kSuperkMinK, g->k);
   if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1))) return fail(MCX_ERR_ARG, "shards must be a power of two <= 32");
@@ -861,6 +947,7 @@ template <int W, bool ONECOL> static void launch_superk_bin(mcx_graph *g, Superk
 extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_recs, const void *d_counts, uint32_t nseg,
                                         uint64_t seg_cap, uint64_t kmers_upper_bound)
 {
+  NO_GROUP(g, "mcx_graph_add_superk_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols_vis) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..31 (got %d)", kSuperkMinK, g->k);
@@ -885,6 +972,7 @@ extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_
 extern "C" uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_words)
 {
   if (!g) return 0;
+  if (g->as_group) g = grp_part(g->as_group, 0);
   const uint32_t lbq = g->t.lb1 + g->t.lbo;
   uint32_t r = 0, m;
   if (g->W == 1) {
@@ -947,6 +1035,11 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
                                    const uint64_t *off, uint64_t nreads, uint8_t fq_cutoff_abs,
                                    uint8_t hp_cutoff, mcx_load_stats *stats_accum)
 {
+  if (g && g->as_group) {
+    if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+    if (nreads && (!bases || !off)) return fail(MCX_ERR_ARG, "null read buffers");
+    return grp_add_reads(g->as_group, colour, bases, quals, off, nreads, fq_cutoff_abs, hp_cutoff, stats_accum);
+  }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (nreads && (!bases || !off)) return fail(MCX_ERR_ARG, "null read buffers");
@@ -1097,6 +1190,7 @@ static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, 
 
 extern "C" int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed)
 {
+  NO_GROUP(g, "mcx_graph_intersect_finish");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (g->hidden < 0) return fail(MCX_ERR_ARG, "the graph is not in intersect mode");
   HIP_TRY(hipSetDevice(g->device));
@@ -1120,6 +1214,11 @@ extern "C" int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed)
 // ---------------------------------------------------------------------------
 extern "C" int mcx_graph_pcr_reset(mcx_graph *g)
 {
+  if (g && g->as_group) {
+    int rc = MCX_OK;
+    for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) rc = mcx_graph_pcr_reset(grp_part(g->as_group, i));
+    return rc;
+  }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   HIP_TRY(hipSetDevice(g->device));
   if (g->d_readstrt) HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
@@ -1130,92 +1229,151 @@ extern "C" int mcx_graph_pcr_reset(mcx_graph *g)
 // whole (bases, qualities, offsets); the kept reads are cut into contigs on the device
 // (k_qh_contigs = seq_contig_start/end) and written out as a fresh separator stream for the
 // ordinary front end.  filter: run seq_reads_are_novel first (ndup = reads / pairs dropped).
+// The steps are separate functions because a multi-GPU table interleaves them across its shards
+// (mcx_multi.h).
+struct CutJob {  // one batch of whole reads on one device
+  mcx_graph *g = nullptr;
+  uint64_t nreads = 0, nunits = 0, nb = 0;
+  uint32_t pmask = 0, fq1 = 0, fq2 = 0, hp = 0;
+  uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_keep = nullptr;
+  uint64_t *d_off = nullptr, *d_node = nullptr;
+  unsigned long long *d_ndup = nullptr;
+  CutJob() = default;
+  CutJob(const CutJob &) = delete;
+  CutJob &operator=(const CutJob &) = delete;
+  ~CutJob()
+  {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    (void)hipFree(d_bases); (void)hipFree(d_quals); (void)hipFree(d_keep); (void)hipFree(d_off); (void)hipFree(d_node); (void)hipFree(d_ndup);
+  }
+};
+#define CUT_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+// reads -> device (asynchronous on the handle's stream); mates turned to FF when the filter runs
+static int cut_upload(CutJob &J, mcx_graph *g, const uint8_t *bases, const uint8_t *quals, const uint64_t *off, uint64_t nreads,
+                      uint8_t fq1, uint8_t fq2, uint8_t hp, bool filter, int paired, int matedir)
+{
+  J.g = g;
+  J.nreads = nreads;
+  J.nunits = paired ? nreads / 2 : nreads;
+  J.pmask = paired ? 1u : 0u; J.fq1 = fq1; J.fq2 = fq2; J.hp = hp;
+  const uint64_t base0 = off[0];
+  J.nb = off[nreads] - off[0];
+  CUT_TRY(hipSetDevice(g->device));
+  std::vector<uint64_t> rel(nreads + 1);
+  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
+  const bool use_q = quals && (fq1 > 0 || fq2 > 0);
+  CUT_TRY(hipMalloc((void **)&J.d_bases, J.nb + 16));
+  if (use_q) CUT_TRY(hipMalloc((void **)&J.d_quals, J.nb + 16));
+  CUT_TRY(hipMalloc((void **)&J.d_off, (nreads + 1) * 8));
+  if (filter) {
+    CUT_TRY(hipMalloc((void **)&J.d_node, nreads * 8));
+    CUT_TRY(hipMalloc((void **)&J.d_keep, nreads));
+    CUT_TRY(hipMalloc((void **)&J.d_ndup, 8));
+    CUT_TRY(hipMemsetAsync(J.d_ndup, 0, 8, g->stream));
+  }
+  CUT_TRY(hipMemcpyAsync(J.d_bases, bases + base0, J.nb, hipMemcpyHostToDevice, g->stream));
+  if (J.d_quals) CUT_TRY(hipMemcpyAsync(J.d_quals, quals + base0, J.nb, hipMemcpyHostToDevice, g->stream));
+  CUT_TRY(hipMemcpyAsync(J.d_off, rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
+  CUT_TRY(hipStreamSynchronize(g->stream));  // `rel` is a local
+  const unsigned blocks = (unsigned)((nreads + 127) / 128);
+  if (filter && matedir)
+    hipLaunchKernelGGL(k_pcr_orient, dim3(blocks), dim3(128), 0, g->stream, J.d_bases, J.d_quals, (const uint64_t *)J.d_off, nreads, J.pmask, (uint32_t)matedir);
+  CUT_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+// start node of every read (created if new) and T(node) = min over the reads that start there
+static int cut_starts(CutJob &J)
+{
+  mcx_graph *g = J.g;
+  CUT_TRY(hipSetDevice(g->device));
+  if (!g->d_readstrt) {  // 2 x u32 per slot, only ever allocated for --remove-pcr
+    if (hipMalloc((void **)&g->d_readstrt, g->t.nslots * 8) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(MCX_ERR_NOMEM, "out of device memory for the read-start table");
+    }
+    CUT_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
+  }
+  const unsigned blocks = (unsigned)((J.nreads + 127) / 128);
+  if (g->W == 1)
+    hipLaunchKernelGGL((k_pcr_starts<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
+                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr);
+  else
+    hipLaunchKernelGGL((k_pcr_starts<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
+                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr);
+  CUT_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+// the kept reads (d_keep, or all), cut into contigs by the reference's rules, become a separator
+// stream for the ordinary front end.  Synchronous.
+static int cut_finish(CutJob &J, int colour)
+{
+  mcx_graph *g = J.g;
+  CUT_TRY(hipSetDevice(g->device));
+  const uint64_t nreads = J.nreads;
+  const unsigned blocks = (unsigned)((nreads + 127) / 128);
+  DevBuf<uint64_t> d_sizes, d_ooff;
+  DevBuf<uint8_t> d_out, d_tmp;
+  size_t tmp_bytes = 0;
+  CUT_TRY(d_sizes.alloc(nreads + 1));
+  CUT_TRY(d_ooff.alloc(nreads + 1));
+  CUT_TRY(hipMemsetAsync(d_sizes, 0, (nreads + 1) * 8, g->stream));
+  hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
+                     (const uint64_t *)J.d_off, nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, (const uint8_t *)J.d_keep, 0, d_sizes.p,
+                     (const uint64_t *)nullptr, (uint8_t *)nullptr);
+  CUT_TRY(hipGetLastError());
+  CUT_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, d_sizes.p, d_ooff.p, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
+  CUT_TRY(d_tmp.alloc(tmp_bytes ? tmp_bytes : 16));
+  CUT_TRY(rocprim::exclusive_scan((void *)d_tmp.p, tmp_bytes, d_sizes.p, d_ooff.p, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
+  uint64_t out_bytes = 0;
+  CUT_TRY(hipMemcpyAsync(&out_bytes, d_ooff.p + nreads, 8, hipMemcpyDeviceToHost, g->stream));
+  CUT_TRY(hipStreamSynchronize(g->stream));
+  int rc = MCX_OK;
+  if (out_bytes) {
+    CUT_TRY(d_out.alloc(out_bytes + 64));
+    CUT_TRY(hipMemsetAsync(d_out.p + out_bytes, '\n', 64, g->stream));
+    hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
+                       (const uint64_t *)J.d_off, nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, (const uint8_t *)J.d_keep, 1, d_sizes.p,
+                       (const uint64_t *)d_ooff.p, d_out.p);
+    CUT_TRY(hipGetLastError());
+    StreamLaunch SL{d_out.p, out_bytes, 0, out_bytes, nullptr};
+    rc = submit_stream(g, SL, colour);
+    CUT_TRY(hipSetDevice(g->device));
+  }
+  hipLaunchKernelGGL(k_count_sizes, dim3(256), dim3(256), 0, g->stream, (const uint64_t *)d_sizes.p, (const uint8_t *)J.d_keep, nreads, g->d_ctr);
+  CUT_TRY(hipGetLastError());
+  CUT_TRY(hipStreamSynchronize(g->stream));  // d_out is read by the kernels submit_stream launched
+  return rc;
+}
+
 static int add_reads_cut(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
                          uint64_t nreads, uint8_t fq_cutoff_abs1, uint8_t fq_cutoff_abs2, uint8_t hp_cutoff,
                          bool filter, int paired, int matedir, unsigned long long *ndup)
 {
-  const uint64_t base0 = off[0], nb = off[nreads] - off[0];
-  const uint32_t pmask = paired ? 1u : 0u, fq1 = fq_cutoff_abs1, fq2 = fq_cutoff_abs2, hp = hp_cutoff;
-  const uint64_t nunits = paired ? nreads / 2 : nreads;
-  uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_out = nullptr, *d_keep = nullptr;
-  uint64_t *d_off = nullptr, *d_sizes = nullptr, *d_ooff = nullptr, *d_node = nullptr;
-  unsigned long long *d_ndup = nullptr, h_ndup = 0;
-  void *d_tmp = nullptr;
-  size_t tmp_bytes = 0;
-  auto cleanup = [&]() {
-    (void)hipFree(d_bases); (void)hipFree(d_quals); (void)hipFree(d_out); (void)hipFree(d_keep); (void)hipFree(d_off);
-    (void)hipFree(d_sizes); (void)hipFree(d_ooff); (void)hipFree(d_node); (void)hipFree(d_ndup); (void)hipFree(d_tmp);
-  };
-#define CUT_TRY(expr)                                                                     \
-  do {                                                                                    \
-    hipError_t _e = (expr);                                                               \
-    if (_e != hipSuccess) {                                                               \
-      cleanup();                                                                          \
-      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
-    }                                                                                     \
-  } while (0)
-  std::vector<uint64_t> rel(nreads + 1);
-  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
-  const bool use_q = quals && (fq1 > 0 || fq2 > 0);
-  CUT_TRY(hipMalloc((void **)&d_bases, nb + 16));
-  if (use_q) CUT_TRY(hipMalloc((void **)&d_quals, nb + 16));
-  CUT_TRY(hipMalloc((void **)&d_off, (nreads + 1) * 8));
-  CUT_TRY(hipMalloc((void **)&d_sizes, (nreads + 1) * 8));
-  CUT_TRY(hipMalloc((void **)&d_ooff, (nreads + 1) * 8));
-  if (filter) {
-    CUT_TRY(hipMalloc((void **)&d_node, nreads * 8));
-    CUT_TRY(hipMalloc((void **)&d_keep, nreads));
-    CUT_TRY(hipMalloc((void **)&d_ndup, 8));
-  }
-  CUT_TRY(hipMemcpyAsync(d_bases, bases + base0, nb, hipMemcpyHostToDevice, g->stream));
-  if (d_quals) CUT_TRY(hipMemcpyAsync(d_quals, quals + base0, nb, hipMemcpyHostToDevice, g->stream));
-  CUT_TRY(hipMemcpyAsync(d_off, rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
-  CUT_TRY(hipMemsetAsync(d_sizes, 0, (nreads + 1) * 8, g->stream));
-  if (filter) CUT_TRY(hipMemsetAsync(d_ndup, 0, 8, g->stream));
-  const unsigned blocks = (unsigned)((nreads + 127) / 128), ublocks = (unsigned)((nunits + 255) / 256);
+  CutJob J;
+  int rc = cut_upload(J, g, bases, quals, off, nreads, fq_cutoff_abs1, fq_cutoff_abs2, hp_cutoff, filter, paired, matedir);
+  if (rc != MCX_OK) return rc;
+  unsigned long long h_ndup = 0;
   if (filter) {
     SpanGuard sp(g, "k_pcr_filter");
-    if (matedir)
-      hipLaunchKernelGGL(k_pcr_orient, dim3(blocks), dim3(128), 0, g->stream, d_bases, d_quals, (const uint64_t *)d_off, nreads, pmask, (uint32_t)matedir);
-    if (g->W == 1)
-      hipLaunchKernelGGL((k_pcr_starts<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                         (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, g->d_readstrt, d_node, g->d_ctr);
-    else
-      hipLaunchKernelGGL((k_pcr_starts<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                         (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, g->d_readstrt, d_node, g->d_ctr);
-    hipLaunchKernelGGL(k_pcr_decide, dim3(ublocks), dim3(256), 0, g->stream, (const uint64_t *)d_node, (const uint32_t *)g->d_readstrt,
-                       nunits, pmask, d_keep, d_ndup);
-    hipLaunchKernelGGL(k_pcr_commit, dim3(blocks), dim3(128), 0, g->stream, (const uint64_t *)d_node, nreads, g->d_readstrt);
-  }
-  CUT_TRY(hipGetLastError());
-  // the kept reads, cut into contigs by the reference's rules, become a separator stream for the
-  // ordinary front end
-  hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                     (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, (const uint8_t *)d_keep, 0, d_sizes,
-                     (const uint64_t *)nullptr, (uint8_t *)nullptr);
-  CUT_TRY(hipGetLastError());
-  CUT_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
-  CUT_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-  CUT_TRY(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_sizes, d_ooff, (uint64_t)0, nreads + 1, rocprim::plus<uint64_t>(), g->stream));
-  uint64_t out_bytes = 0;
-  CUT_TRY(hipMemcpyAsync(&out_bytes, d_ooff + nreads, 8, hipMemcpyDeviceToHost, g->stream));
-  if (filter) CUT_TRY(hipMemcpyAsync(&h_ndup, d_ndup, 8, hipMemcpyDeviceToHost, g->stream));
-  CUT_TRY(hipStreamSynchronize(g->stream));
-  int rc = MCX_OK;
-  if (out_bytes) {
-    CUT_TRY(hipMalloc((void **)&d_out, out_bytes + 64));
-    CUT_TRY(hipMemsetAsync(d_out + out_bytes, '\n', 64, g->stream));
-    hipLaunchKernelGGL(k_qh_contigs, dim3(blocks), dim3(128), 0, g->stream, (const uint8_t *)d_bases, (const uint8_t *)d_quals,
-                       (const uint64_t *)d_off, nreads, g->k, fq1, fq2, pmask, hp, (const uint8_t *)d_keep, 1, d_sizes,
-                       (const uint64_t *)d_ooff, d_out);
+    rc = cut_starts(J);
+    if (rc != MCX_OK) return rc;
+    const unsigned blocks = (unsigned)((nreads + 127) / 128), ublocks = (unsigned)((J.nunits + 255) / 256);
+    hipLaunchKernelGGL(k_pcr_decide, dim3(ublocks), dim3(256), 0, g->stream, (const uint64_t *)J.d_node, (const uint32_t *)g->d_readstrt,
+                       J.nunits, J.pmask, J.d_keep, J.d_ndup);
+    hipLaunchKernelGGL(k_pcr_commit, dim3(blocks), dim3(128), 0, g->stream, (const uint64_t *)J.d_node, nreads, g->d_readstrt);
     CUT_TRY(hipGetLastError());
-    StreamLaunch SL{d_out, out_bytes, 0, out_bytes, nullptr};
-    rc = submit_stream(g, SL, colour);
+    CUT_TRY(hipMemcpyAsync(&h_ndup, J.d_ndup, 8, hipMemcpyDeviceToHost, g->stream));
   }
-  hipLaunchKernelGGL(k_count_sizes, dim3(256), dim3(256), 0, g->stream, (const uint64_t *)d_sizes, (const uint8_t *)d_keep, nreads, g->d_ctr);
-  CUT_TRY(hipStreamSynchronize(g->stream));
-  cleanup();
-#undef CUT_TRY
+  rc = cut_finish(J, colour);  // (synchronises the stream: h_ndup has arrived)
   if (ndup) *ndup = h_ndup;
   return rc;
 }
@@ -1232,6 +1390,11 @@ extern "C" int mcx_graph_add_reads_pcr(mcx_graph *g, int colour, const uint8_t *
                                        uint8_t fq_cutoff_abs2, uint8_t hp_cutoff, int paired, int matedir,
                                        mcx_load_stats *stats_accum)
 {
+  if (g && g->as_group) {
+    if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+    if (nreads && (!bases || !off)) return fail(MCX_ERR_ARG, "null read buffers");
+    return grp_add_reads_pcr(g->as_group, colour, bases, quals, off, nreads, fq_cutoff_abs1, fq_cutoff_abs2, hp_cutoff, paired, matedir, stats_accum);
+  }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols_vis) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (nreads && (!bases || !off)) return fail(MCX_ERR_ARG, "null read buffers");
@@ -1239,20 +1402,13 @@ extern "C" int mcx_graph_add_reads_pcr(mcx_graph *g, int colour, const uint8_t *
   if (matedir < 0 || matedir > 3) return fail(MCX_ERR_ARG, "mate pair orientation %d: 0 FF, 1 FR, 2 RF, 3 RR", matedir);
   if (nreads >= (1ull << 32)) return fail(MCX_ERR_ARG, "too many reads in one batch");
   if (g->must_exist || g->hidden >= 0) return fail(MCX_ERR_ARG, "Cannot use --remove-pcr and --intersect");  // build_graph.c:198
-  if (g->t.lbo) return fail(MCX_ERR_ARG, "duplicate removal needs the whole table on one device");
+  if (g->t.lbo) return fail(MCX_ERR_ARG, "duplicate removal on a sharded table goes through the multi-GPU handle");
   HIP_TRY(hipSetDevice(g->device));
   if (stats_accum) {
     if (paired) stats_accum->num_pe_reads += nreads; else stats_accum->num_se_reads += nreads;  // build_graph.c:211-212
     stats_accum->total_bases_read += nreads ? off[nreads] - off[0] : 0;
   }
   if (!nreads) return MCX_OK;
-  if (!g->d_readstrt) {  // 2 x u32 per slot, only ever allocated for --remove-pcr
-    if (hipMalloc((void **)&g->d_readstrt, g->t.nslots * 8) != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(MCX_ERR_NOMEM, "out of device memory for the read-start table");
-    }
-    HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
-  }
   unsigned long long ndup = 0;
   const int rc = add_reads_cut(g, colour, bases, quals, off, nreads, fq_cutoff_abs1, fq_cutoff_abs2, hp_cutoff, true,
                                paired, matedir, &ndup);
@@ -1278,12 +1434,19 @@ static int fetch_counters(mcx_graph *g)
 
 extern "C" int mcx_graph_sync(mcx_graph *g)
 {
+  if (g && g->as_group) return grp_sync(g->as_group);
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   return fetch_counters(g);
 }
 
 extern "C" int mcx_graph_nkmers(mcx_graph *g, uint64_t *n)
 {
+  if (g && n && g->as_group) {
+    mcx_load_stats st;
+    int rc = grp_device_stats(g->as_group, &st);
+    *n = st.num_kmers_novel;
+    return rc;
+  }
   if (!g || !n) return fail(MCX_ERR_ARG, "null argument");
   int rc = fetch_counters(g);
   *n = g->h_ctr->novel;
@@ -1292,6 +1455,7 @@ extern "C" int mcx_graph_nkmers(mcx_graph *g, uint64_t *n)
 
 extern "C" int mcx_graph_device_stats(mcx_graph *g, mcx_load_stats *out)
 {
+  if (g && out && g->as_group) return grp_device_stats(g->as_group, out);
   if (!g || !out) return fail(MCX_ERR_ARG, "null argument");
   int rc = fetch_counters(g);
   memset(out, 0, sizeof(*out));
@@ -1313,6 +1477,7 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
                                      const int32_t *from_col, const int32_t *into_col, int nmap, uint32_t flags,
                                      mcx_records_stats *stats_accum)
 {
+  if (g && g->as_group) return grp_add_records(g->as_group, recs, nrecs, file_ncols, from_col, into_col, nmap, flags, stats_accum);
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (file_ncols < 1 || file_ncols > 10000) return fail(MCX_ERR_ARG, "bad number of file colours: %d", file_ncols);
   if (nmap < 1 || !from_col || !into_col) return fail(MCX_ERR_ARG, "empty colour filter");
@@ -1499,6 +1664,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
 
 extern "C" int mcx_graph_export(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
 {
+  if (g && sink && g->as_group) return grp_export(g->as_group, g, sorted, sink, ctx);
   if (!g || !sink) return fail(MCX_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(g->device));
   return g->W == 1 ? export_t<1>(g, sorted, sink, ctx) : export_t<2>(g, sorted, sink, ctx);
@@ -1539,6 +1705,18 @@ static int covg_scan(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov, uint64_t 
 
 extern "C" int mcx_graph_checksum(mcx_graph *g, uint64_t *checksum, uint64_t *nkmers)
 {
+  if (g && checksum && g->as_group) {  // an order-independent sum: the shards' sums add up
+    int rc = grp_sync(g->as_group);
+    uint64_t cs = 0, nk = 0;
+    for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) {
+      uint64_t c1 = 0, n1 = 0;
+      rc = mcx_graph_checksum(grp_part(g->as_group, i), &c1, &n1);
+      cs += c1; nk += n1;
+    }
+    *checksum = cs;
+    if (nkmers) *nkmers = nk;
+    return rc;
+  }
   if (!g || !checksum) return fail(MCX_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(g->device));
   int rc = flush_deferred(g);
@@ -1577,6 +1755,16 @@ extern "C" uint64_t mcx_records_checksum(const void *recs, uint64_t nrecs, int k
 
 extern "C" int mcx_graph_kmer_covg(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov)
 {
+  if (g && g->as_group) {
+    int rc = grp_sync(g->as_group);
+    std::vector<uint64_t> a((size_t)g->ncols), b((size_t)g->ncols);
+    for (int c = 0; c < g->ncols; c++) { if (nkmers) nkmers[c] = 0; if (sumcov) sumcov[c] = 0; }
+    for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) {
+      rc = mcx_graph_kmer_covg(grp_part(g->as_group, i), a.data(), b.data());
+      for (int c = 0; c < g->ncols; c++) { if (nkmers) nkmers[c] += a[c]; if (sumcov) sumcov[c] += b[c]; }
+    }
+    return rc;
+  }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (g->ncols > 2048) return fail(MCX_ERR_ARG, "too many colours for the scan");
   return covg_scan(g, nkmers, sumcov, nullptr, 0);
@@ -1584,6 +1772,16 @@ extern "C" int mcx_graph_kmer_covg(mcx_graph *g, uint64_t *nkmers, uint64_t *sum
 
 extern "C" int mcx_graph_covg_histogram(mcx_graph *g, uint64_t *hist, uint32_t nbins)
 {
+  if (g && hist && g->as_group) {
+    int rc = grp_sync(g->as_group);
+    std::vector<uint64_t> h(nbins);
+    for (uint32_t b = 0; b < nbins; b++) hist[b] = 0;
+    for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) {
+      rc = mcx_graph_covg_histogram(grp_part(g->as_group, i), h.data(), nbins);
+      for (uint32_t b = 0; b < nbins; b++) hist[b] += h[b];
+    }
+    return rc;
+  }
   if (!g || !hist) return fail(MCX_ERR_ARG, "null argument");
   if (nbins < 2) return fail(MCX_ERR_ARG, "the histogram needs at least two bins");
   if (g->ncols > 2048) return fail(MCX_ERR_ARG, "too many colours for the scan");
@@ -1729,4 +1927,21 @@ extern "C" uint32_t mcx_kmer_hash(const uint64_t *key, int k, uint32_t initval)
   if (words_for_k(k) == 1) { Kmer<1> x{{key[0]}}; return kmer_hash<1>(x, initval, nullptr); }
   Kmer<2> x{{key[0], key[1]}};
   return kmer_hash<2>(x, initval, nullptr);
+}
+
+#include "mcx_multi.h"
+
+static mcx_graph *grp_part(mcx_group *G, int i) { return G->part[i]; }
+static int grp_n(mcx_group *G) { return G->n; }
+// the shard on whose device `d_ptr` lives (shards that share a device take turns)
+static int grp_part_of_pointer(mcx_group *G, const void *d_ptr, mcx_graph **part)
+{
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, d_ptr) != hipSuccess) { (void)hipGetLastError(); return fail(MCX_ERR_ARG, "not a device pointer"); }
+  static unsigned turn = 0;
+  std::vector<int> on;
+  for (int i = 0; i < G->n; i++) if (G->part[i]->device == at.device) on.push_back(i);
+  if (on.empty()) return fail(MCX_ERR_ARG, "the stream lives on device %d, which holds no shard of this table", at.device);
+  *part = G->part[on[turn++ % on.size()]];
+  return MCX_OK;
 }

@@ -133,6 +133,13 @@ template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t
   a.bucket = (m >> lbq) & (Sub<W>::kBuckets - 1);
   return a;
 }
+// shard (GPU) that holds `key` in a table split over 2^lbo shards
+template <int W> __device__ __forceinline__ uint32_t key_owner(const TableView &t, const Kmer<W> &key)
+{
+  uint32_t r;
+  const Kmer<W> q = key_quot<W>(key, lbq_of(t), r);
+  return (r ^ (region_mix<W>(q) & ((1u << lbq_of(t)) - 1u))) >> t.lb1;
+}
 // remainder of a key of THIS shard from its quotient and its region
 template <int W> __device__ __forceinline__ uint32_t r_of(const TableView &t, uint32_t region, const Kmer<W> &q)
 {
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t
     if (!any_file) atomicMin(&st->first_zero_covg, (unsigned long long)(rec0 + i));
     if (edges_no_covg) atomicMin(&st->first_edges_no_covg, (unsigned long long)(rec0 + i));
     if (!any_loaded) continue;
+    if (t.lbo && key_owner<W>(t, key) != t.part) continue;  // a shard of a multi-GPU table only loads its own keys
     const uint64_t slot = find_or_insert_rec<W>(t, key, must_exist != 0, novel, full);
     if (slot == kNoSlot) continue;
     // must_exist_in_edges (graphs_load.c:166-167): only edges the intersection graph has
@@ -889,6 +897,7 @@ __global__ void k_pcr_orient(uint8_t *bases, uint8_t *quals, const uint64_t *off
 }
 
 constexpr uint64_t kNoNode = ~0ULL;
+constexpr uint64_t kForeignNode = ~0ULL - 1;  // the read's start k-mer belongs to another shard of a multi-GPU table
 // one lane per read: first k-mer of its first contig -> node (created if new, coverage untouched:
 // db_graph_find_or_add_node_mt, build_graph.c:66-76) and T(node) = min(T(node), 1 + read (pair) index)
 template <int W>
@@ -916,6 +925,7 @@ __global__ void k_pcr_starts(TableView t, const uint8_t *bases, const uint8_t *q
     const Kmer<W> rc = revcomp<W>(fw, k);
     uint32_t o, novel = 0, full = 0;
     const Kmer<W> key = canonical<W>(fw, rc, o);
+    if (t.lbo && key_owner<W>(t, key) != t.part) { node_of[r] = kForeignNode; return; }
     const uint64_t slot = find_or_insert_rec<W>(t, key, false, novel, full);
     if (novel) atomicAdd(&ctr->novel, 1ULL);
     if (full) atomicAdd(&ctr->full, 1ULL);
@@ -949,8 +959,44 @@ __global__ void k_pcr_decide(const uint64_t *node_of, const uint32_t *first, uin
 __global__ void k_pcr_commit(const uint64_t *node_of, uint64_t nreads, uint32_t *first)
 {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nreads && node_of[r] != kNoNode) first[node_of[r]] = 0;
+  if (r < nreads && node_of[r] < kForeignNode) first[node_of[r]] = 0;
 }
+
+// Multi-GPU table: every shard runs k_pcr_starts over ALL reads of the batch and answers for the
+// start nodes it owns: claim[r] = 1 "read r's start node was claimed by an earlier read (pair), or
+// r has no k-mer", 0 "r is the first to start there", 2 "not my node".  Exactly one shard answers
+// 0 / 1 for a read with a k-mer; a read without one gets 1 from all of them.
+__global__ void k_pcr_claim(const uint64_t *node_of, const uint32_t *first, uint64_t nreads, uint32_t pmask, uint8_t *claim)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  const uint32_t me = (uint32_t)(r >> (pmask ? 1 : 0)) + 1u;
+  const uint64_t n = node_of[r];
+  claim[r] = n == kForeignNode ? 2 : (uint8_t)(n == kNoNode || first[n] < me);
+}
+// ... and, with the claims of all shards side by side (claims[shard * nreads + r]), decides like
+// k_pcr_decide.  Every shard reaches the same verdict; it KEEPS the units [u_lo, u_hi) only: the
+// kept reads of a batch are dealt out to the shards for the ordinary (sharded) insert.
+__global__ void k_pcr_decide_claims(const uint8_t *claims, uint32_t nshards, uint64_t nreads, uint64_t nunits, uint32_t pmask,
+                                    uint64_t u_lo, uint64_t u_hi, uint8_t *keep, unsigned long long *ndup)
+{
+  const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long dup = 0;
+  if (u < nunits) {
+    const uint64_t r0 = pmask ? 2 * u : u;
+    uint32_t c1 = 2, c2 = pmask ? 2 : 1;
+    for (uint32_t s = 0; s < nshards; s++) {
+      c1 = min(c1, (uint32_t)claims[(uint64_t)s * nreads + r0]);
+      if (pmask) c2 = min(c2, (uint32_t)claims[(uint64_t)s * nreads + r0 + 1]);
+    }
+    dup = c1 && c2;
+    const uint8_t k = (uint8_t)(!dup && u >= u_lo && u < u_hi);
+    keep[r0] = k;
+    if (pmask) keep[r0 + 1] = k;
+  }
+  block_add(ndup, dup);
+}
+
 
 // ---------------------------------------------------------------------------
 // Order-independent checksum of the graph: sum over nodes of a 64-bit mix of the exported record

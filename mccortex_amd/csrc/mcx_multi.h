@@ -1,0 +1,488 @@
+// mcx_multi.h -- one table over several GPUs, driven by ONE host process (included by mcx_api.hip).
+//
+// What it replaces: the batch loop of `build` (src/commands/ctx_build.c:384-407) feeding ONE hash
+// table from -t worker threads.  Here the table is split by quotient-hash prefix into one shard per
+// GPU (mcx_graph_create_shard: owner = top bits of the address word G) and
+// mcx_graph_create_multi() returns an ordinary mcx_graph handle -- a facade -- whose calls are dealt
+// out to the shards, so that the host program (host/cmd_build.c) is the same for one GPU and for
+// eight: reads, -Q / -H, --remove-pcr, --graph loads, statistics and the export all go through it.
+//
+// Data path of a batch of reads (exchange format v2, the same kernels bench.py drives through
+// torch.distributed / RCCL with one process per GPU):
+//   1. the batch is cut into one contiguous piece per shard; shard i stages its piece and k-merises
+//      it with the sender kernel (k_stream_bin, BIN_GLOBAL): packed occurrences binned by
+//      (owner, region) into fixed-size blocks, one block per owner                     [stream i]
+//   2. block j of shard i goes to shard j's receive slot for sender i: hipMemcpyPeerAsync over
+//      xGMI, a direct copy per pair (every pair of GPUs of a node is one hop)      [copy stream i]
+//   3. shard j splits what it received by sub-table (k_tuples_bin); its LDS insert applies it at
+//      the next flush                                                                   [stream j]
+// Send and receive sets are double buffered and the three steps are ordered with HIP events only,
+// so the sender kernel of piece n + 1 overlaps with the copies of piece n and the owners' split of
+// piece n - 1.  Nothing here reads a table, so nothing flushes one.  The same device may be named
+// more than once (-D 0,0): the peer copy then is a device-local copy, which is how the path is
+// tested on a one-GPU box.
+#pragma once
+
+namespace {
+
+struct XBuf {  // one block set: packed tuples by (owner, region) + per-owner overflow bins (full tuples)
+  uint64_t *keys = nullptr;
+  unsigned long long *counts = nullptr;
+  uint64_t *ov_keys = nullptr;
+  uint8_t *ov_edges = nullptr;
+  unsigned long long *ov_counts = nullptr;
+};
+
+}  // namespace
+
+struct mcx_group {
+  int n = 0;
+  std::vector<mcx_graph *> part;
+  // geometry of one exchange piece (at most max_pos k-mer start positions)
+  uint32_t segs = 0;
+  uint64_t seg_cap = 0, ov_cap = 0, max_pos = 0;
+  // send[i][b]: blocks for all owners on shard i's device; recv[j][i][b]: shard i's block on shard j's device
+  std::vector<std::array<XBuf, 2>> send;
+  std::vector<std::vector<std::array<XBuf, 2>>> recv;
+  std::vector<hipStream_t> cs;                                     // copy stream of sender i (its device)
+  std::vector<std::array<hipEvent_t, 2>> filled, sent;             // [i][b]
+  std::vector<std::vector<std::array<hipEvent_t, 2>>> arrived;     // [j][i][b], recorded on cs[i]
+  std::vector<std::vector<std::array<hipEvent_t, 2>>> consumed;    // [j][i][b], recorded on shard j's stream
+  std::vector<int> cur;
+  std::vector<std::array<bool, 2>> used;
+  bool buffers = false;
+};
+
+#define GRP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                  hipGetErrorString(_e), __FILE__, __LINE__);                                      \
+  } while (0)
+
+static void group_free_buffers(mcx_group *G)
+{
+  for (int i = 0; i < G->n; i++) {
+    (void)hipSetDevice(G->part[i]->device);
+    for (int b = 0; b < 2; b++) {
+      if ((size_t)i < G->send.size()) {
+        XBuf &x = G->send[i][b];
+        (void)hipFree(x.keys); (void)hipFree(x.counts); (void)hipFree(x.ov_keys); (void)hipFree(x.ov_edges); (void)hipFree(x.ov_counts);
+        x = XBuf();
+      }
+      if ((size_t)i < G->recv.size())
+        for (auto &r : G->recv[i]) {
+          XBuf &x = r[b];
+          (void)hipFree(x.keys); (void)hipFree(x.counts); (void)hipFree(x.ov_keys); (void)hipFree(x.ov_edges); (void)hipFree(x.ov_counts);
+          x = XBuf();
+        }
+    }
+  }
+  G->buffers = false;
+}
+
+// Exchange buffers, allocated on first use.  A piece covers at most max_pos start positions: the
+// staged chunks of mcx_graph_add_reads are 32 MiB, device streams are cut to this size.
+static int group_ensure_buffers(mcx_group *G)
+{
+  if (G->buffers) return MCX_OK;
+  mcx_graph *g0 = G->part[0];
+  const int N = G->n, W = g0->W;
+  G->max_pos = std::max<uint64_t>(kStageBytes + kCarry, 32ull << 20);
+  if (const char *e = getenv("MCX_MULTI_PIECE")) G->max_pos = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));  // tests
+  const uint32_t b1 = 1u << g0->t.lb1;
+  G->segs = kShardRep * b1;
+  const double mean = (double)G->max_pos / ((double)N * G->segs);
+  // mean + 8 sigma of the Poisson fill + room for a short run of one k-mer; what does not fit goes
+  // to the owner's overflow bin (hot k-mers), and beyond that raises MCX_ERR_FULL on the sender
+  G->seg_cap = ((uint64_t)(mean + 8.0 * sqrt(mean + 1.0)) + 64 + 1) & ~1ull;
+  G->ov_cap = std::max<uint64_t>(1u << 16, G->max_pos / (uint64_t)N / 16);
+  G->send.resize(N);
+  G->recv.assign(N, std::vector<std::array<XBuf, 2>>(N));
+  const uint64_t blk = (uint64_t)G->segs * G->seg_cap;  // tuples of one owner's block
+  for (int i = 0; i < N; i++) {
+    GRP_TRY(hipSetDevice(G->part[i]->device));
+    for (int b = 0; b < 2; b++) {
+      XBuf &s = G->send[i][b];
+      GRP_TRY(hipMalloc((void **)&s.keys, (uint64_t)N * blk * 8 * W));
+      GRP_TRY(hipMalloc((void **)&s.counts, (uint64_t)N * G->segs * 8));
+      GRP_TRY(hipMalloc((void **)&s.ov_keys, (uint64_t)N * G->ov_cap * 8 * W));
+      GRP_TRY(hipMalloc((void **)&s.ov_edges, (uint64_t)N * G->ov_cap));
+      GRP_TRY(hipMalloc((void **)&s.ov_counts, (uint64_t)N * 8));
+      for (int src = 0; src < N; src++) {
+        XBuf &r = G->recv[i][src][b];
+        GRP_TRY(hipMalloc((void **)&r.keys, blk * 8 * W));
+        GRP_TRY(hipMalloc((void **)&r.counts, (uint64_t)G->segs * 8));
+        GRP_TRY(hipMalloc((void **)&r.ov_keys, G->ov_cap * 8 * W));
+        GRP_TRY(hipMalloc((void **)&r.ov_edges, G->ov_cap));
+        GRP_TRY(hipMalloc((void **)&r.ov_counts, 8));
+      }
+    }
+  }
+  G->buffers = true;
+  return MCX_OK;
+}
+
+// Steps 1-3 for the start positions [L.pos_lo, L.pos_hi) of a stream that is resident on shard
+// idx's device (the sharded counterpart of submit_stream).
+static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int colour)
+{
+  int rc = group_ensure_buffers(G);
+  if (rc != MCX_OK) return rc;
+  const int N = G->n;
+  mcx_graph *me = G->part[idx];
+  const int W = me->W;
+  const uint64_t blk = (uint64_t)G->segs * G->seg_cap;
+  for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
+    const uint64_t hi = std::min(L.pos_hi, lo + G->max_pos);
+    const int b = G->cur[idx];
+    G->cur[idx] ^= 1;
+    XBuf &s = G->send[idx][b];
+    // 1. sender
+    GRP_TRY(hipSetDevice(me->device));
+    if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(me->stream, G->sent[idx][b], 0));  // its last copies have left
+    GRP_TRY(hipMemsetAsync(s.counts, 0, (uint64_t)N * G->segs * 8, me->stream));
+    GRP_TRY(hipMemsetAsync(s.ov_counts, 0, (uint64_t)N * 8, me->stream));
+    StreamLaunch P = L;
+    P.pos_lo = lo; P.pos_hi = hi;
+    rc = shard_bins_launch(me, P, s.keys, s.counts, G->seg_cap, s.ov_keys, s.ov_edges, s.ov_counts, G->ov_cap);
+    if (rc != MCX_OK) return rc;
+    GRP_TRY(hipEventRecord(G->filled[idx][b], me->stream));
+    // 2. one copy per (owner, buffer): fixed sizes, so the fills travel with the blocks and the host
+    // never has to read them
+    GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->filled[idx][b], 0));
+    for (int j = 0; j < N; j++) {
+      mcx_graph *own = G->part[j];
+      XBuf &r = G->recv[j][idx][b];
+      if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->consumed[j][idx][b], 0));  // the slot is free again
+      GRP_TRY(hipMemcpyPeerAsync(r.counts, own->device, s.counts + (uint64_t)j * G->segs, me->device, (uint64_t)G->segs * 8, G->cs[idx]));
+      GRP_TRY(hipMemcpyPeerAsync(r.ov_counts, own->device, s.ov_counts + j, me->device, 8, G->cs[idx]));
+      GRP_TRY(hipMemcpyPeerAsync(r.keys, own->device, s.keys + (uint64_t)j * blk * W, me->device, blk * 8 * W, G->cs[idx]));
+      GRP_TRY(hipMemcpyPeerAsync(r.ov_keys, own->device, s.ov_keys + (uint64_t)j * G->ov_cap * W, me->device, G->ov_cap * 8 * W, G->cs[idx]));
+      GRP_TRY(hipMemcpyPeerAsync(r.ov_edges, own->device, s.ov_edges + (uint64_t)j * G->ov_cap, me->device, G->ov_cap, G->cs[idx]));
+      GRP_TRY(hipEventRecord(G->arrived[j][idx][b], G->cs[idx]));
+    }
+    GRP_TRY(hipEventRecord(G->sent[idx][b], G->cs[idx]));
+    // 3. owners: split by sub-table; the overflow bins take the full-tuple path
+    const uint64_t share = (hi - lo) / (uint64_t)N + (hi - lo) / (uint64_t)(4 * N) + 4096;  // estimate for the flush clock
+    for (int j = 0; j < N; j++) {
+      mcx_graph *own = G->part[j];
+      XBuf &r = G->recv[j][idx][b];
+      GRP_TRY(hipSetDevice(own->device));
+      GRP_TRY(hipStreamWaitEvent(own->stream, G->arrived[j][idx][b], 0));
+      rc = mcx_graph_add_segments_dev(own, colour, r.keys, r.counts, G->segs, G->seg_cap, std::min(share, blk));
+      if (rc != MCX_OK) return rc;
+      rc = mcx_graph_insert_tuple_segments_dev(own, colour, r.ov_keys, r.ov_edges, r.ov_counts, 1, G->ov_cap);
+      if (rc != MCX_OK) return rc;
+      GRP_TRY(hipEventRecord(G->consumed[j][idx][b], own->stream));
+    }
+    G->used[idx][b] = true;
+    lo = hi;
+  }
+  GRP_TRY(hipSetDevice(me->device));
+  return MCX_OK;
+}
+
+static void group_destroy(mcx_group *G)
+{
+  if (!G) return;
+  for (int i = 0; i < G->n; i++) {
+    if (!G->part[i]) continue;
+    (void)hipSetDevice(G->part[i]->device);
+    if (G->part[i]->stream) (void)hipStreamSynchronize(G->part[i]->stream);
+    if ((size_t)i < G->cs.size() && G->cs[i]) (void)hipStreamSynchronize(G->cs[i]);
+  }
+  group_free_buffers(G);
+  for (int i = 0; i < G->n; i++) {
+    if (!G->part[i]) continue;
+    (void)hipSetDevice(G->part[i]->device);
+    if ((size_t)i < G->cs.size() && G->cs[i]) (void)hipStreamDestroy(G->cs[i]);
+    for (int b = 0; b < 2; b++) {
+      if ((size_t)i < G->filled.size() && G->filled[i][b]) (void)hipEventDestroy(G->filled[i][b]);
+      if ((size_t)i < G->sent.size() && G->sent[i][b]) (void)hipEventDestroy(G->sent[i][b]);
+    }
+  }
+  for (auto &row : G->arrived) for (auto &e : row) for (int b = 0; b < 2; b++) if (e[b]) (void)hipEventDestroy(e[b]);
+  for (auto &row : G->consumed) for (auto &e : row) for (int b = 0; b < 2; b++) if (e[b]) (void)hipEventDestroy(e[b]);
+  for (int j = 0; j < G->n; j++) {
+    if (!G->part[j]) continue;
+    G->part[j]->group = nullptr;
+    mcx_graph_destroy(G->part[j]);
+  }
+  delete G;
+}
+
+extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers,
+                                      const int *devices, int ndevices)
+{
+  if (!out) return fail(MCX_ERR_ARG, "null handle pointer");
+  *out = nullptr;
+  if (!devices || ndevices < 1) return fail(MCX_ERR_ARG, "no devices given");
+  if (ndevices == 1) return mcx_graph_create(out, kmer_size, ncols, capacity_kmers, devices[0]);
+  if (ndevices > 32 || (ndevices & (ndevices - 1)))
+    return fail(MCX_ERR_ARG, "the table is split by hash prefix: the number of devices must be a power of two <= 32 (got %d)", ndevices);
+  if (check_k(kmer_size) != MCX_OK) return MCX_ERR_ARG;
+  const int W = words_for_k(kmer_size);
+  // every shard needs the partitioned insert path (>= 64 regions of one sub-table each)
+  const uint64_t min_shard = 64ull << sub_shift_for_words(W);
+  const uint64_t per = std::max<uint64_t>((capacity_kmers + (uint64_t)ndevices - 1) / (uint64_t)ndevices, min_shard);
+  mcx_group *G = new mcx_group();
+  G->n = ndevices;
+  G->part.assign(ndevices, nullptr);
+  for (int i = 0; i < ndevices; i++) {
+    int rc = mcx_graph_create_shard(&G->part[i], kmer_size, ncols, per, devices[i], ndevices, i);
+    if (rc != MCX_OK) { group_destroy(G); return rc; }
+    G->part[i]->group = G;
+    G->part[i]->gidx = i;
+  }
+  G->cs.assign(ndevices, nullptr);
+  G->filled.assign(ndevices, {nullptr, nullptr});
+  G->sent.assign(ndevices, {nullptr, nullptr});
+  G->arrived.assign(ndevices, std::vector<std::array<hipEvent_t, 2>>(ndevices, {nullptr, nullptr}));
+  G->consumed.assign(ndevices, std::vector<std::array<hipEvent_t, 2>>(ndevices, {nullptr, nullptr}));
+  G->cur.assign(ndevices, 0);
+  G->used.assign(ndevices, {false, false});
+#define MK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc_ = fail(MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); group_destroy(G); return rc_; } } while (0)
+  for (int i = 0; i < ndevices; i++) {
+    MK_TRY(hipSetDevice(devices[i]));
+    for (int j = 0; j < ndevices; j++)  // direct xGMI copies instead of staging through the host
+      if (devices[j] != devices[i]) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+          const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+          if (e != hipSuccess) (void)hipGetLastError();  // already enabled
+        }
+      }
+    MK_TRY(hipStreamCreateWithFlags(&G->cs[i], hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+      MK_TRY(hipEventCreateWithFlags(&G->filled[i][b], hipEventDisableTiming));
+      MK_TRY(hipEventCreateWithFlags(&G->sent[i][b], hipEventDisableTiming));
+      for (int j = 0; j < ndevices; j++) MK_TRY(hipEventCreateWithFlags(&G->arrived[j][i][b], hipEventDisableTiming));
+    }
+  }
+  for (int j = 0; j < ndevices; j++) {
+    MK_TRY(hipSetDevice(devices[j]));
+    for (int i = 0; i < ndevices; i++)
+      for (int b = 0; b < 2; b++) MK_TRY(hipEventCreateWithFlags(&G->consumed[j][i][b], hipEventDisableTiming));
+  }
+#undef MK_TRY
+  mcx_graph *f = new mcx_graph();  // the facade: no device state of its own
+  f->k = kmer_size; f->W = W; f->ncols = ncols; f->ncols_vis = ncols;
+  f->device = devices[0];
+  f->as_group = G;
+  *out = f;
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_ndevices(const mcx_graph *g) { return !g ? 0 : g->as_group ? g->as_group->n : 1; }
+
+// ---- the facade's calls -----------------------------------------------------------------------
+// everything in flight between the shards has landed and been handed to its owner
+static int grp_drain(mcx_group *G)
+{
+  for (int i = 0; i < G->n; i++) {
+    GRP_TRY(hipSetDevice(G->part[i]->device));
+    GRP_TRY(hipStreamSynchronize(G->part[i]->stream));
+    GRP_TRY(hipStreamSynchronize(G->cs[i]));
+  }
+  return MCX_OK;
+}
+
+static int grp_sync(mcx_group *G)
+{
+  int rc = grp_drain(G), first = MCX_OK;
+  if (rc != MCX_OK) return rc;
+  for (int i = 0; i < G->n; i++) {
+    rc = mcx_graph_sync(G->part[i]);
+    if (rc != MCX_OK && first == MCX_OK) first = rc;
+  }
+  return first;
+}
+
+static int grp_device_stats(mcx_group *G, mcx_load_stats *out)
+{
+  int rc = grp_drain(G), first = MCX_OK;
+  if (rc != MCX_OK) return rc;
+  memset(out, 0, sizeof(*out));
+  for (int i = 0; i < G->n; i++) {
+    mcx_load_stats s;
+    rc = mcx_graph_device_stats(G->part[i], &s);
+    if (rc != MCX_OK && first == MCX_OK) first = rc;
+    out->num_good_reads += s.num_good_reads; out->num_bad_reads += s.num_bad_reads;
+    out->contigs_parsed += s.contigs_parsed; out->num_kmers_loaded += s.num_kmers_loaded;
+    out->num_kmers_novel += s.num_kmers_novel; out->total_bases_loaded += s.total_bases_loaded;
+  }
+  return first;
+}
+
+static int grp_add_reads(mcx_group *G, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                         uint64_t nreads, uint8_t fq, uint8_t hp, mcx_load_stats *stats_accum)
+{
+  if (stats_accum) {
+    stats_accum->num_se_reads += nreads;
+    stats_accum->total_bases_read += nreads ? off[nreads] - off[0] : 0;
+  }
+  for (int i = 0; i < G->n; i++) {  // one contiguous piece of the batch per shard
+    const uint64_t lo = nreads * (uint64_t)i / (uint64_t)G->n, hi = nreads * (uint64_t)(i + 1) / (uint64_t)G->n;
+    if (hi == lo) continue;
+    int rc = mcx_graph_add_reads(G->part[i], colour, bases, quals, off + lo, hi - lo, fq, hp, nullptr);
+    if (rc != MCX_OK) return rc;
+  }
+  return MCX_OK;
+}
+
+// --remove-pcr on a sharded table: every shard sees the whole batch and answers for the start
+// nodes it owns (k_pcr_claim); the answers are copied to every shard, each reaches the same
+// verdict (k_pcr_decide_claims) and loads its share of the kept reads.
+static int grp_add_reads_pcr(mcx_group *G, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                             uint64_t nreads, uint8_t fq1, uint8_t fq2, uint8_t hp, int paired, int matedir,
+                             mcx_load_stats *stats_accum)
+{
+  if (paired && (nreads & 1)) return fail(MCX_ERR_ARG, "paired reads come in twos (%llu reads)", (unsigned long long)nreads);
+  if (matedir < 0 || matedir > 3) return fail(MCX_ERR_ARG, "mate pair orientation %d: 0 FF, 1 FR, 2 RF, 3 RR", matedir);
+  if (nreads >= (1ull << 32)) return fail(MCX_ERR_ARG, "too many reads in one batch");
+  if (stats_accum) {
+    if (paired) stats_accum->num_pe_reads += nreads; else stats_accum->num_se_reads += nreads;
+    stats_accum->total_bases_read += nreads ? off[nreads] - off[0] : 0;
+  }
+  if (!nreads) return MCX_OK;
+  const int N = G->n;
+  std::vector<std::unique_ptr<CutJob>> J;
+  std::vector<uint8_t *> claims(N, nullptr);     // on shard j: claims of all shards, [N][nreads]
+  std::vector<hipEvent_t> claimed(N, nullptr);   // shard i's own claims are ready
+  auto cleanup = [&]() {
+    for (int i = 0; i < N; i++) {
+      (void)hipSetDevice(G->part[i]->device);
+      (void)hipStreamSynchronize(G->part[i]->stream);
+      (void)hipFree(claims[i]);
+      if (claimed[i]) (void)hipEventDestroy(claimed[i]);
+    }
+  };
+#define PCR_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc_ = fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); cleanup(); return rc_; } } while (0)
+  const unsigned blocks = (unsigned)((nreads + 127) / 128);
+  int rc = MCX_OK;
+  for (int i = 0; i < N && rc == MCX_OK; i++) {
+    mcx_graph *g = G->part[i];
+    J.emplace_back(new CutJob());
+    rc = cut_upload(*J[i], g, bases, quals, off, nreads, fq1, fq2, hp, true, paired, matedir);
+    if (rc == MCX_OK) rc = cut_starts(*J[i]);
+    if (rc != MCX_OK) break;
+    PCR_TRY(hipSetDevice(g->device));
+    PCR_TRY(hipMalloc((void **)&claims[i], (uint64_t)N * nreads));
+    PCR_TRY(hipEventCreateWithFlags(&claimed[i], hipEventDisableTiming));
+    hipLaunchKernelGGL(k_pcr_claim, dim3(blocks), dim3(128), 0, g->stream, (const uint64_t *)J[i]->d_node, (const uint32_t *)g->d_readstrt,
+                       nreads, J[i]->pmask, claims[i] + (uint64_t)i * nreads);
+    PCR_TRY(hipGetLastError());
+    PCR_TRY(hipEventRecord(claimed[i], g->stream));
+  }
+  if (rc != MCX_OK) { cleanup(); return rc; }
+  unsigned long long h_ndup = 0;
+  const uint64_t nunits = J[0]->nunits;
+  for (int j = 0; j < N; j++) {  // gather the claims, decide, commit
+    mcx_graph *g = G->part[j];
+    PCR_TRY(hipSetDevice(g->device));
+    for (int i = 0; i < N; i++)
+      if (i != j) {
+        PCR_TRY(hipStreamWaitEvent(g->stream, claimed[i], 0));
+        PCR_TRY(hipMemcpyPeerAsync(claims[j] + (uint64_t)i * nreads, g->device, claims[i] + (uint64_t)i * nreads, G->part[i]->device, nreads, g->stream));
+      }
+    const uint64_t u_lo = nunits * (uint64_t)j / (uint64_t)N, u_hi = nunits * (uint64_t)(j + 1) / (uint64_t)N;
+    hipLaunchKernelGGL(k_pcr_decide_claims, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, g->stream, (const uint8_t *)claims[j],
+                       (uint32_t)N, nreads, nunits, J[j]->pmask, u_lo, u_hi, J[j]->d_keep, J[j]->d_ndup);
+    hipLaunchKernelGGL(k_pcr_commit, dim3(blocks), dim3(128), 0, g->stream, (const uint64_t *)J[j]->d_node, nreads, g->d_readstrt);
+    PCR_TRY(hipGetLastError());
+    if (j == 0) PCR_TRY(hipMemcpyAsync(&h_ndup, J[0]->d_ndup, 8, hipMemcpyDeviceToHost, g->stream));
+  }
+  for (int j = 0; j < N; j++) {  // (a shard's own claims must not be freed while another still copies them)
+    PCR_TRY(hipSetDevice(G->part[j]->device));
+    PCR_TRY(hipStreamSynchronize(G->part[j]->stream));
+  }
+  for (int j = 0; j < N && rc == MCX_OK; j++) rc = cut_finish(*J[j], colour);
+  cleanup();
+#undef PCR_TRY
+  if (stats_accum) {
+    if (paired) stats_accum->num_dup_pe_pairs += h_ndup; else stats_accum->num_dup_se_reads += h_ndup;
+  }
+  return rc;
+}
+
+static int grp_add_records(mcx_group *G, const void *recs, uint64_t nrecs, int file_ncols, const int32_t *from_col,
+                           const int32_t *into_col, int nmap, uint32_t flags, mcx_records_stats *stats_accum)
+{
+  if (flags) return fail(MCX_ERR_ARG, "must-exist / intersect loads are not available on a multi-GPU table");
+  int rc = grp_drain(G);
+  if (rc != MCX_OK) return rc;
+  mcx_records_stats tot;
+  memset(&tot, 0, sizeof(tot));
+  tot.first_oversized = tot.first_zero_covg = tot.first_edges_no_covg = -1;
+  const uint64_t base = stats_accum ? stats_accum->nkmers_read : 0;
+  for (int i = 0; i < G->n; i++) {  // every shard scans all records and keeps the keys it owns (k_load_records)
+    mcx_records_stats s;
+    memset(&s, 0, sizeof(s));
+    s.first_oversized = s.first_zero_covg = s.first_edges_no_covg = -1;
+    s.nkmers_read = base;
+    rc = mcx_graph_add_records(G->part[i], recs, nrecs, file_ncols, from_col, into_col, nmap, flags, &s);
+    if (rc != MCX_OK) return rc;
+    tot.nkmers_loaded += s.nkmers_loaded;
+    tot.nkmers_novel += s.nkmers_novel;
+    auto first = [](int64_t &d, int64_t v) { if (v >= 0 && (d < 0 || v < d)) d = v; };
+    first(tot.first_oversized, s.first_oversized);
+    first(tot.first_zero_covg, s.first_zero_covg);
+    first(tot.first_edges_no_covg, s.first_edges_no_covg);
+  }
+  if (stats_accum) {
+    stats_accum->nkmers_read += nrecs;
+    stats_accum->nkmers_loaded += tot.nkmers_loaded;
+    stats_accum->nkmers_novel += tot.nkmers_novel;
+    if (stats_accum->first_oversized < 0) stats_accum->first_oversized = tot.first_oversized;
+    if (stats_accum->first_zero_covg < 0) stats_accum->first_zero_covg = tot.first_zero_covg;
+    if (stats_accum->first_edges_no_covg < 0) stats_accum->first_edges_no_covg = tot.first_edges_no_covg;
+  }
+  return MCX_OK;
+}
+
+// The shards hold disjoint key sets.  Unsorted: one shard after the other.  Sorted: the shards'
+// records are gathered on the host and ordered by one device sort (mcx_sort_records), then streamed
+// to the sink in 64 MiB pieces.
+static int grp_export(mcx_group *G, mcx_graph *f, int sorted, mcx_sink_fn sink, void *ctx)
+{
+  int rc = grp_sync(G);
+  if (rc != MCX_OK) return rc;
+  if (!sorted) {
+    for (int i = 0; i < G->n; i++) {
+      rc = mcx_graph_export(G->part[i], 0, sink, ctx);
+      if (rc != MCX_OK) return rc;
+    }
+    return MCX_OK;
+  }
+  std::vector<uint8_t> all;
+  uint64_t total = 0;
+  for (int i = 0; i < G->n; i++) {
+    uint64_t n = 0;
+    rc = mcx_graph_nkmers(G->part[i], &n);
+    if (rc != MCX_OK) return rc;
+    total += n;
+  }
+  const uint64_t recsz = 8ull * f->W + 5ull * (uint64_t)f->ncols;
+  try { all.reserve(total * recsz); } catch (...) { return fail(MCX_ERR_NOMEM, "out of host memory for %llu records", (unsigned long long)total); }
+  struct Collect { std::vector<uint8_t> *v; };
+  Collect c{&all};
+  auto collect = [](void *p, const void *r, size_t nb) -> int {
+    Collect *cc = (Collect *)p;
+    const uint8_t *b = (const uint8_t *)r;
+    cc->v->insert(cc->v->end(), b, b + nb);
+    return 0;
+  };
+  for (int i = 0; i < G->n; i++) {
+    rc = mcx_graph_export(G->part[i], 0, collect, &c);
+    if (rc != MCX_OK) return rc;
+  }
+  const uint64_t n = all.size() / recsz;
+  rc = mcx_sort_records(all.data(), n, f->k, f->ncols, G->part[0]->device);
+  if (rc != MCX_OK) return rc;
+  const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz) * recsz;
+  for (uint64_t o = 0; o < all.size(); o += chunk)
+    if (sink(ctx, all.data() + o, (size_t)std::min<uint64_t>(chunk, all.size() - o)) != 0) return fail(MCX_ERR_SINK, "export sink failed");
+  return MCX_OK;
+}

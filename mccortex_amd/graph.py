@@ -11,7 +11,7 @@ MCX_OK, MCX_ERR_ARG, MCX_ERR_NODEVICE, MCX_ERR_NOMEM, MCX_ERR_FULL, MCX_ERR_HIP,
 _LIB = None
 
 SYMBOLS = [
-    "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create",
+    "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create", "mcx_graph_create_multi", "mcx_graph_ndevices",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
     "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_kmer_covg", "mcx_graph_covg_histogram", "mcx_sort_records",
     "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_superk_supported", "mcx_superk_owner", "mcx_graph_checksum", "mcx_records_checksum",
@@ -78,6 +78,8 @@ def lib():
     L.mcx_device_count.restype = C.c_int
     L.mcx_graph_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint64, C.c_int]
     L.mcx_graph_create_shard.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    L.mcx_graph_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.c_int]
+    L.mcx_graph_ndevices.argtypes = [vp]
     L.mcx_graph_shard_layout.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), u64p, u64p]
     L.mcx_graph_shard_bins_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64]
     L.mcx_graph_add_segments_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]
@@ -187,13 +189,23 @@ def _ptr(x):
 class Graph:
     """One coloured de Bruijn graph resident in the HBM of one GPU."""
 
-    def __init__(self, kmer_size, ncols=1, capacity=1 << 20, device=0, nparts=1, part=0):
+    def __init__(self, kmer_size, ncols=1, capacity=1 << 20, device=0, nparts=1, part=0, devices=None):
+        """devices: list of device ordinals -> one table split over them (mcx_graph_create_multi);
+        the same ordinal may repeat (several shards on one GPU: how the path is tested on one)."""
         self.L = lib()
         self.k, self.ncols, self.W = kmer_size, ncols, _words(kmer_size)
         self.nparts, self.part = nparts, part
         h = C.c_void_p()
-        _check(self.L.mcx_graph_create_shard(C.byref(h), kmer_size, ncols, capacity, device, nparts, part))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(self.L.mcx_graph_create_multi(C.byref(h), kmer_size, ncols, capacity, arr, len(devices)))
+        else:
+            _check(self.L.mcx_graph_create_shard(C.byref(h), kmer_size, ncols, capacity, device, nparts, part))
         self.h = h
+
+    @property
+    def ndevices(self):
+        return int(self.L.mcx_graph_ndevices(self.h))
 
     def close(self):
         if getattr(self, "h", None):

@@ -51,7 +51,7 @@ static const char build_usage[] =
 "                           graphs will be merged, not intersected. Treated as\n"
 "                           single colour graphs.\n"
 "  -S, --sort               Output a graph file ordered by kmer\n"
-"  -D, --device <N>         GPU to build on [default: 0]\n"
+"  -D, --device <N[,N..]>   GPU(s) to build on: one table split over 1, 2, 4, 8.. devices [default: 0]\n"
 "\n"
 "  Note: Argument must come before input file\n"
 "  --sample <name> is required before sequence input can be loaded.\n"
@@ -435,6 +435,7 @@ int ctx_build(int argc, char **argv)
   bool sample_named = false, pref_unused = false, remove_pcr = false;
   uint8_t fq_offset = 0, fq_cutoff = 0, hp_cutoff = 0;
   int intocolour = -1, device = 0, c, matedir = 1 /* FR: build_graph.h:38-42 */;
+  int devices[32] = {0}, ndevices = 1;
   char cmd[100];
 
   /* '+': stop at the first non-option; single-dash long options accepted (cmd.c:87-102, ctx_build.c:149) */
@@ -526,8 +527,19 @@ int ctx_build(int argc, char **argv)
         gisec[ngisec].into_ncols = 1;
         ngisec++;
         break;
-      case 'D': if (!parse_entire_uint(optarg, &u)) usage_die("%s requires an int x >= 0: %s", cmd, optarg);
-        device = (int)u; break;
+      case 'D': { /* one device, or a comma-separated list: the table is split over them (mcx_graph_create_multi) */
+        ndevices = 0;
+        char *list = strdup(optarg), *save = NULL;
+        for (char *tok = strtok_r(list, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) {
+          if (!parse_entire_uint(tok, &u)) usage_die("%s requires ints x >= 0, comma separated: %s", cmd, optarg);
+          if (ndevices == 32) usage_die("%s takes at most 32 devices: %s", cmd, optarg);
+          devices[ndevices++] = (int)u;
+        }
+        free(list);
+        if (ndevices == 0 || (ndevices & (ndevices - 1))) usage_die("%s: the number of devices must be a power of two: %s", cmd, optarg);
+        device = devices[0];
+        break;
+      }
       case ':': case '?':
         die("`" CMD_NAME " build -h` for help. Bad option: %s", argv[optind - 1]);
       default: die("Bad option: %s", cmd);
@@ -612,14 +624,18 @@ int ctx_build(int argc, char **argv)
   stage_time("arguments parsed");
   if (mcx_device_count() < 1) die("No MI355X / HIP device found: %s has no CPU build path", CMD_NAME);
   stage_time("HIP runtime up");
-  uint64_t hbm_free = 0, hbm_total = 0;
-  mcx_check(mcx_device_memory(device, &hbm_free, &hbm_total), "device query");
+  if (ndevices > 1 && ngisec > 0) die("--intersect needs the whole table on one device (-D takes a single device with it)");
   const size_t dev_cols = ncols + (ngisec > 0 ? 1 : 0); /* + the hidden colour of the intersection edges */
-  const uint64_t dev_bytes = kmers_in_hash * 8 * (W + dev_cols + (remove_pcr_used ? 1 : 0)); /* + the read-start table */
-  if (dev_bytes > hbm_free)
-    die("Requesting more memory than is available [ Reqeusted: %s HBM free: %s ]",
-        bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_free, 1, s2));
-  status("[memory] device %d: table %s of %s HBM\n", device, bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_total, 1, s2));
+  /* per device: its share of the table (+ the read-start table of --remove-pcr, + the overflow area) */
+  const uint64_t dev_bytes = (kmers_in_hash / (uint64_t)ndevices + kmers_in_hash / (uint64_t)ndevices / 32) * 8 * (W + dev_cols + (remove_pcr_used ? 1 : 0));
+  for (int d = 0; d < ndevices; d++) {
+    uint64_t hbm_free = 0, hbm_total = 0;
+    mcx_check(mcx_device_memory(devices[d], &hbm_free, &hbm_total), "device query");
+    if (dev_bytes > hbm_free)
+      die("Requesting more memory than is available [ Reqeusted: %s HBM free: %s ]",
+          bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_free, 1, s2));
+    status("[memory] device %d: table %s of %s HBM\n", devices[d], bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_total, 1, s2));
+  }
 
   /* ---- output path (futil_create_output: file_util.c:164-186) ---- */
   FILE *fout = stdout;
@@ -631,7 +647,8 @@ int ctx_build(int argc, char **argv)
   status("Writing %zu colour graph to %s\n", ncols, strcmp(out_path, "-") ? out_path : "STDOUT");
 
   mcx_graph *g = NULL;
-  mcx_check(mcx_graph_create(&g, (int)kmer_size, (int)dev_cols, kmers_in_hash, device), "Cannot allocate graph");
+  if (ndevices == 1) devices[0] = device;
+  mcx_check(mcx_graph_create_multi(&g, (int)kmer_size, (int)dev_cols, kmers_in_hash, devices, ndevices), "Cannot allocate graph");
   if (ngisec > 0) mcx_check(mcx_graph_configure(g, "intersect", 1), "intersect mode");
   uint64_t slots = 0, tbytes = 0;
   mcx_graph_capacity(g, &slots, &tbytes);

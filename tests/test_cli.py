@@ -335,3 +335,53 @@ def test_gzip_inputs_are_read_ahead(built, orc, tmp_path):
     rc, _, err = run(31, *(args[:1] + ["-t", "1"] + args[1:] + [out1]))
     assert rc == 0, err
     assert open(out1, "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_build_on_several_devices_matches_oracle_ctx(built, orc, tmp_path):
+    """`build -D 0,0[,0,0]`: one table split over several devices behind the same command line
+    (csrc/mcx_multi.h; the test box has one GPU, so the same device is named 2 / 4 times): two
+    samples, gzip'd and plain inputs, -Q / -H, --remove-pcr pairs, a --graph load, sorted and
+    unsorted output -- byte-identical to the oracle's .ctx (ctx_build.c:384-407 is what is replaced)."""
+    g = synth.genome(30000, 5)
+    b0, o0 = synth.reads(4000, 100, seed=1, g=g, n_frac=0.05, lower_frac=0.1)
+    b1, o1 = synth.reads(3000, 120, seed=2, g=g, n_frac=0.05)
+    rng = np.random.default_rng(2)
+    q1 = rng.integers(33, 74, len(b1)).astype(np.uint8)
+    f0 = _write_inputs(tmp_path, b0, o0, "m0", "fa", width=60)
+    f1 = _write_inputs(tmp_path, b1, o1, "m1", "fq", gz=True, qual=q1)
+    for devs, (maxk, k) in [("0,0", (31, 31)), ("0,0,0,0", (31, 21)), ("0,0", (63, 41))]:
+        out = str(tmp_path / ("multi%d.ctx" % k))
+        rc, _, err = run(maxk, "build", "-D", devs, "-k", str(k), "-n", "4M", "--sort", "-t", "3",
+                         "--sample", "alice", "--seq", f0, "--sample", "bob", "-Q", "10", "-O", "33", "-H", "7", "--seq", f1, out)
+        assert rc == 0, err
+        assert "device 0" in err
+        og = orc.Graph(k, 2, 1 << 22)
+        og.set_sample(0, "alice"); og.set_sample(1, "bob")
+        st = og.add_reads(0, b0, o0); og.update_stats(0, st)
+        st = og.add_reads(1, b1, o1, quals=q1, fq_cutoff=43, hp_cutoff=7); og.update_stats(1, st)
+        want = og.ctx_bytes(True)
+        assert open(out, "rb").read() == want, devs
+        # the graph just written, loaded back with --graph into a 1-colour build next to new reads
+        out2 = str(tmp_path / ("multi%d_b.ctx" % k))
+        rc, _, err = run(maxk, "build", "-q", "-D", devs, "-k", str(k), "-n", "4M", "--sort", "--graph", "0:" + out + ":0",
+                         "--sample", "carol", "--seq", f0, out2)
+        assert rc == 0, err
+        rc, _, err = run(maxk, "build", "-q", "-k", str(k), "-n", "4M", "--sort", "--graph", "0:" + out + ":0",
+                         "--sample", "carol", "--seq", f0, out2 + ".one")
+        assert rc == 0, err
+        assert open(out2, "rb").read() == open(out2 + ".one", "rb").read()
+    # --remove-pcr pairs on two devices == on one
+    p1 = _write_inputs(tmp_path, b0, o0, "p1", "fq")
+    b2, o2 = synth.reads(4000, 100, seed=9, g=g)
+    p2 = _write_inputs(tmp_path, b2, o2, "p2", "fq")
+    outs = []
+    for devs in ("0", "0,0"):
+        out = str(tmp_path / ("pcr_%d.ctx" % len(devs)))
+        rc, _, err = run(31, "build", "-q", "-D", devs, "-k", "27", "-n", "4M", "--sort", "-s", "x", "--remove-pcr", "--seq2", p1 + ":" + p2, out)
+        assert rc == 0, err
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
+    # an odd number of devices is refused; --intersect needs one device
+    rc, _, err = run(31, "build", "-D", "0,0,0", "-k", "31", "-s", "a", "--seq", f0, str(tmp_path / "x.ctx"))
+    assert rc == 1 and "power of two" in err

@@ -1,0 +1,131 @@
+"""One table over several GPUs behind the C ABI (mcx_graph_create_multi, csrc/mcx_multi.h): the
+facade handle against the oracle, bit-exact.  The test box has one GPU: the same device is named
+two or four times, which exercises everything but the xGMI hop itself (the peer copy becomes a
+device-local copy).  Reference call site replaced: the batch loop of ctx_build.c:384-407."""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _multi(mcx, k, ncols, devices, cap=1 << 20):
+    g = mcx.Graph(k, ncols, cap, devices=devices)
+    assert g.ndevices == len(devices)
+    return g
+
+
+@pytest.mark.parametrize("k,ndev", [(31, 2), (31, 4), (63, 2), (21, 2)])
+def test_multi_add_reads_matches_oracle(mcx, orc, k, ndev):
+    bases, offs = synth.reads(6000, 120, genome_len=60000, seed=k + ndev, n_frac=0.05, lower_frac=0.1)
+    og = orc.Graph(k, 1, 1 << 20)
+    ost = og.add_reads(0, bases, offs)
+    g = _multi(mcx, k, 1, [0] * ndev)
+    g.add_reads(0, bases, offs)
+    g.sync()
+    st = g.device_stats()
+    for f in ("num_good_reads", "num_bad_reads", "total_bases_loaded", "contigs_parsed", "num_kmers_loaded", "num_kmers_novel"):
+        assert getattr(st, f) == getattr(ost, f), f
+    assert g.nkmers == og.nkmers
+    want = og.ctx_bytes(True)[og.header_size():]
+    assert g.export(True) == want
+    rs = 8 * g.W + 5
+    a = np.frombuffer(g.export(False), np.uint8).reshape(-1, rs)
+    b = np.frombuffer(want, np.uint8).reshape(-1, rs)
+    assert sorted(map(bytes, a)) == sorted(map(bytes, b))
+    cs, n = g.checksum()
+    assert n == og.nkmers and cs == mcx.records_checksum(want, k, 1)
+    g.close()
+
+
+def test_multi_small_pieces_and_colours(mcx, orc, monkeypatch):
+    """many exchange pieces per batch (double buffering, slot reuse) and two colours"""
+    monkeypatch.setenv("MCX_MULTI_PIECE", "20000")
+    k = 31
+    b0, o0 = synth.reads(4000, 100, genome_len=30000, seed=3)
+    b1, o1 = synth.reads(3000, 100, genome_len=30000, seed=3, err=0.01)
+    og = orc.Graph(k, 2, 1 << 20)
+    og.add_reads(0, b0, o0)
+    og.add_reads(1, b1, o1)
+    og.add_reads(0, b1, o1)
+    g = _multi(mcx, k, 2, [0, 0])
+    g.add_reads(0, b0, o0)
+    g.add_reads(1, b1, o1)
+    g.add_reads(0, b1, o1)
+    assert g.nkmers == og.nkmers
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    nk, sc = g.kmer_covg()
+    h = g.covg_histogram(16)
+    assert sum(h) == og.nkmers and len(nk) == 2
+    g.close()
+
+
+def test_multi_quality_and_homopolymer_cutoffs(mcx, orc):
+    k = 21
+    rng = np.random.default_rng(9)
+    bases, offs = synth.reads(3000, 90, genome_len=20000, seed=4, n_frac=0.03)
+    quals = rng.integers(33, 74, len(bases)).astype(np.uint8)
+    for fq, hp in [(33 + 12, 0), (0, 4), (33 + 8, 5)]:
+        og = orc.Graph(k, 1, 1 << 20)
+        ost = og.add_reads(0, bases, offs, quals=quals, fq_cutoff=fq, hp_cutoff=hp)
+        g = _multi(mcx, k, 1, [0, 0])
+        g.add_reads(0, bases, offs, quals=quals, fq_cutoff=fq, hp_cutoff=hp)
+        st = g.device_stats()
+        assert st.num_kmers_loaded == ost.num_kmers_loaded and st.contigs_parsed == ost.contigs_parsed
+        assert st.num_good_reads == ost.num_good_reads and st.num_bad_reads == ost.num_bad_reads
+        assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+        g.close()
+
+
+@pytest.mark.parametrize("k,paired,matedir,nbatches", [(31, False, "FF", 1), (31, True, "FR", 3), (63, True, "RF", 2), (21, False, "RR", 2)])
+def test_multi_remove_pcr(mcx, orc, k, paired, matedir, nbatches):
+    """the duplicate filter with the read-start table spread over the shards (k_pcr_claim / k_pcr_decide_claims)"""
+    n = 6000
+    bases, offs = synth.reads(n, 90, genome_len=600, seed=k + nbatches, n_frac=0.1, lower_frac=0.1, var_len=(nbatches > 1))
+    g = _multi(mcx, k, 1, [0, 0])
+    og = orc.Graph(k, 1, 1 << 20)
+    st, ot = mcx.LoadStats(), orc.Stats()
+    odup = [0, 0, 0]
+    cuts = [2 * (n // 2 * i // nbatches) for i in range(nbatches + 1)]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        o = offs[lo:hi + 1]
+        g.add_reads_pcr(0, bases, o, paired=paired, matedir=matedir, stats=st)
+        _, d = og.add_reads_pcr(0, bases, o, paired=paired, matedir=matedir, stats=ot)
+        odup = [x + y for x, y in zip(odup, d)]
+    assert (st.num_dup_se_reads, st.num_dup_pe_pairs, st.num_pe_reads) == tuple(odup)
+    assert odup[1 if paired else 0] > n // 20
+    cur = g.device_stats()
+    for f in ("num_good_reads", "num_bad_reads", "total_bases_loaded", "contigs_parsed", "num_kmers_loaded", "num_kmers_novel"):
+        assert getattr(cur, f) == getattr(ot, f), f
+    assert g.nkmers == og.nkmers
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    g.close()
+
+
+def test_multi_add_records_and_stream(mcx, orc):
+    import torch
+    k = 31
+    bases, offs = synth.reads(3000, 100, genome_len=20000, seed=21)
+    og = orc.Graph(k, 1, 1 << 20)
+    og.add_reads(0, bases, offs)
+    body = og.ctx_bytes(True)[og.header_size():]
+    g = _multi(mcx, k, 1, [0, 0])
+    st = g.add_records(body, 1, [(0, 0)])
+    assert st.nkmers_loaded == og.nkmers and st.nkmers_novel == og.nkmers
+    # ... and the same reads once more as a device-resident stream: coverage doubles
+    stream = torch.from_numpy(synth.to_stream(bases, offs)).cuda()
+    g.add_stream_dev(0, stream, stream.numel())
+    g.sync()
+    og.add_reads(0, bases, offs)
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    with pytest.raises(mcx.McxError):
+        g.configure("intersect", 1)
+    g.close()
+
+
+def test_multi_needs_power_of_two(mcx):
+    with pytest.raises(mcx.McxError):
+        mcx.Graph(31, 1, 1 << 20, devices=[0, 0, 0])
