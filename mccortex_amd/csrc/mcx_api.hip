@@ -1554,6 +1554,13 @@ static void export_clock(const char *what)
   fprintf(stderr, "[timing]   export %8.1f ms  %s\n", ms, what);
 }
 
+// Scratch of the export: per k-mer 8 (key word) + 8 (slot) + 4 x 8 (sort keys / permutation, in
+// and out) bytes, two more words for two-word keys, plus the radix sort's own temporary.  When that
+// does not fit beside the table (a table at 75 % load that takes more than a third of HBM), the
+// deferred-insert workspace is released first, and if it still does not fit the key space is
+// walked in 2^p ranges of the k-mer's top bits (k_compact's prefix filter): ranges in ascending
+// order keep a sorted export sorted, and a range that turns out fuller than its arrays (real
+// genomes are not uniform over prefixes) is split in two and redone.
 template <int W>
 static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
 {
@@ -1563,15 +1570,45 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   const uint64_t n = g->h_ctr->novel;
   if (n == 0) return MCX_OK;
   hipStream_t st = g->stream;
-  uint64_t *d_k0 = nullptr, *d_k1 = nullptr, *d_slot = nullptr, *d_idx = nullptr, *d_idx2 = nullptr, *d_ks = nullptr, *d_ks2 = nullptr;
+  const uint32_t recsz = 8u * W + 5u * (uint32_t)g->ncols_vis;
+  const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz);
+  const uint64_t per_kmer = 8 * (uint64_t)W + 8 + 32 + (W == 2 ? 8 : 0) + 8 /* radix temporary, roughly */;
+  const uint64_t fixed = 2 * chunk * recsz + (64ull << 20);
+  auto free_bytes = []() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? (uint64_t)f : 0; };
+  uint32_t pbits = 0;
+  {
+    uint64_t avail = free_bytes();
+    if (const char *e = getenv("MCX_EXPORT_SCRATCH")) avail = std::min<uint64_t>(avail, strtoull(e, nullptr, 10));  // tests
+    if (n * per_kmer + fixed > avail && g->l1_keys && !g->pending && !g->pending_l2) {
+      HIP_TRY(hipStreamSynchronize(st));
+      free_defer(g);  // the bins come back with the next batch of reads
+      avail = free_bytes();
+      if (const char *e = getenv("MCX_EXPORT_SCRATCH")) avail = std::min<uint64_t>(avail, strtoull(e, nullptr, 10));
+    }
+    const int key_bits = 2 * g->k;
+    while (pbits < 16 && (int)pbits + 2 <= key_bits && (n >> pbits) * per_kmer * 5 / 4 + fixed > avail) pbits++;
+    if ((n >> pbits) * per_kmer * 5 / 4 + fixed > avail)
+      return fail(MCX_ERR_NOMEM, "not enough free HBM to dump the graph (%llu MB free)", (unsigned long long)(avail >> 20));
+  }
+
+  hipEvent_t done[2] = {nullptr, nullptr};
+  uint8_t *d_rec2[2] = {nullptr, nullptr}, *h_rec2[2] = {nullptr, nullptr};
   unsigned long long *d_cursor = nullptr;
+  uint64_t *d_k0 = nullptr, *d_k1 = nullptr, *d_slot = nullptr, *d_idx = nullptr, *d_idx2 = nullptr, *d_ks = nullptr, *d_ks2 = nullptr;
   void *d_tmp = nullptr;
-  uint8_t *d_rec = nullptr, *h_rec = nullptr;
-  size_t tmp_bytes = 0;
-  auto cleanup = [&]() {
+  auto free_range = [&]() {
     (void)hipFree(d_k0); (void)hipFree(d_k1); (void)hipFree(d_slot); (void)hipFree(d_idx); (void)hipFree(d_idx2);
-    (void)hipFree(d_ks); (void)hipFree(d_ks2); (void)hipFree(d_cursor); (void)hipFree(d_tmp); (void)hipFree(d_rec);
-    if (h_rec) (void)hipHostFree(h_rec);
+    (void)hipFree(d_ks); (void)hipFree(d_ks2); (void)hipFree(d_tmp);
+    d_k0 = d_k1 = d_slot = d_idx = d_idx2 = d_ks = d_ks2 = nullptr; d_tmp = nullptr;
+  };
+  auto cleanup = [&]() {
+    free_range();
+    (void)hipFree(d_cursor);
+    for (int i = 0; i < 2; i++) {
+      if (done[i]) (void)hipEventDestroy(done[i]);
+      (void)hipFree(d_rec2[i]);
+      if (h_rec2[i]) (void)hipHostFree(h_rec2[i]);
+    }
   };
 #define EXP_TRY(expr)                                                                     \
   do {                                                                                    \
@@ -1582,83 +1619,89 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
     }                                                                                     \
   } while (0)
   export_clock("counters fetched");
-  EXP_TRY(hipMalloc((void **)&d_k0, n * 8));
-  if (W == 2) EXP_TRY(hipMalloc((void **)&d_k1, n * 8));
-  EXP_TRY(hipMalloc((void **)&d_slot, n * 8));
   EXP_TRY(hipMalloc((void **)&d_cursor, 8));
-  export_clock("key arrays allocated");
-  EXP_TRY(hipMemsetAsync(d_cursor, 0, 8, st));
-  hipLaunchKernelGGL((k_compact<W>), dim3(g->grid), dim3(kThreads), 0, st, g->t, d_k0, d_k1, d_slot, d_cursor, n);
-  EXP_TRY(hipGetLastError());
-  unsigned long long found = 0;
-  EXP_TRY(hipMemcpyAsync(&found, d_cursor, 8, hipMemcpyDeviceToHost, st));
-  EXP_TRY(hipStreamSynchronize(st));
-  if (found != n) { cleanup(); return fail(MCX_ERR_HIP, "table scan found %llu nodes, counter says %llu", found, (unsigned long long)n); }
-  export_clock("compacted");
-
-  // permutation of the compacted entries: by key (sorted) or by slot (table order)
-  EXP_TRY(hipMalloc((void **)&d_idx, n * 8));
-  EXP_TRY(hipMalloc((void **)&d_idx2, n * 8));
-  EXP_TRY(hipMalloc((void **)&d_ks, n * 8));
-  EXP_TRY(hipMalloc((void **)&d_ks2, n * 8));
-  const unsigned gb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, n);
-  const uint64_t *first_key = sorted ? (W == 2 ? d_k1 : d_k0) : d_slot;
-  EXP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, first_key, d_ks, d_idx, d_idx2, n, 0, 64, st));
-  EXP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-  EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, first_key, d_ks, d_idx, d_idx2, n, 0, 64, st));
-  uint64_t *perm = d_idx2;
-  if (sorted && W == 2) {  // LSD: stable second pass on the most significant word
-    hipLaunchKernelGGL(k_gather_u64, dim3(gb), dim3(256), 0, st, (const uint64_t *)d_k0, (const uint64_t *)d_idx2, d_ks2, n);
-    EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, d_idx2, d_idx, n, 0, 64, st));
-    perm = d_idx;
-  }
-
-  EXP_TRY(hipStreamSynchronize(st));
-  export_clock("sorted");
   // records are produced and copied to pinned memory in 64 MiB chunks, double buffered: while the
   // sink consumes chunk i on the host, the device emits and copies chunk i + 1
-  const uint32_t recsz = 8u * W + 5u * (uint32_t)g->ncols_vis;
-  const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz);
-  hipEvent_t done[2] = {nullptr, nullptr};
-  uint8_t *d_rec2[2] = {nullptr, nullptr}, *h_rec2[2] = {nullptr, nullptr};
-  auto cleanup2 = [&]() {
-    for (int i = 0; i < 2; i++) {
-      if (done[i]) (void)hipEventDestroy(done[i]);
-      (void)hipFree(d_rec2[i]);
-      if (h_rec2[i]) (void)hipHostFree(h_rec2[i]);
-    }
-  };
-#define EXP2_TRY(expr) do { hipError_t _e2 = (expr); if (_e2 != hipSuccess) { cleanup2(); EXP_TRY(_e2); } } while (0)
   for (int i = 0; i < 2; i++) {
-    EXP2_TRY(hipMalloc((void **)&d_rec2[i], chunk * recsz));
-    EXP2_TRY(hipHostMalloc((void **)&h_rec2[i], chunk * recsz, hipHostMallocDefault));
-    EXP2_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    EXP_TRY(hipMalloc((void **)&d_rec2[i], chunk * recsz));
+    EXP_TRY(hipHostMalloc((void **)&h_rec2[i], chunk * recsz, hipHostMallocDefault));
+    EXP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
   }
-  auto produce = [&](uint64_t first, int b) -> hipError_t {
-    const uint64_t cnt = std::min(chunk, n - first);
-    hipLaunchKernelGGL((k_emit_records<W>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g->t,
-                       (const uint64_t *)d_slot, (const uint64_t *)perm, first, cnt, (uint32_t)g->ncols_vis, d_rec2[b]);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = hipMemcpyAsync(h_rec2[b], d_rec2[b], cnt * recsz, hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return e;
-    return hipEventRecord(done[b], st);
-  };
   export_clock("buffers allocated");
-  EXP2_TRY(produce(0, 0));
-  int b = 0;
-  for (uint64_t first = 0; first < n; first += chunk, b ^= 1) {
-    const uint64_t cnt = std::min(chunk, n - first);
-    if (first + chunk < n) EXP2_TRY(produce(first + chunk, b ^ 1));
-    EXP2_TRY(hipEventSynchronize(done[b]));
-    if (sink(ctx, h_rec2[b], cnt * recsz) != 0) { cleanup2(); cleanup(); return fail(MCX_ERR_SINK, "export sink failed"); }
+
+  struct Range { uint32_t prefix, bits; };
+  std::vector<Range> todo;  // a stack: the lowest prefix on top
+  for (uint32_t p = 1u << pbits; p-- > 0;) todo.push_back({p, pbits});
+  uint64_t emitted = 0;
+  while (!todo.empty()) {
+    const Range r = todo.back();
+    todo.pop_back();
+    const uint64_t cap = r.bits == 0 ? n : std::min<uint64_t>(n, (n >> r.bits) * 5 / 4 + 65536);
+    EXP_TRY(hipMalloc((void **)&d_k0, cap * 8));
+    if (W == 2) EXP_TRY(hipMalloc((void **)&d_k1, cap * 8));
+    EXP_TRY(hipMalloc((void **)&d_slot, cap * 8));
+    EXP_TRY(hipMemsetAsync(d_cursor, 0, 8, st));
+    hipLaunchKernelGGL((k_compact<W>), dim3(g->grid), dim3(kThreads), 0, st, g->t, d_k0, d_k1, d_slot, d_cursor, cap, g->k, r.prefix, r.bits);
+    EXP_TRY(hipGetLastError());
+    unsigned long long found = 0;
+    EXP_TRY(hipMemcpyAsync(&found, d_cursor, 8, hipMemcpyDeviceToHost, st));
+    EXP_TRY(hipStreamSynchronize(st));
+    if (r.bits == 0 && found != n) { cleanup(); return fail(MCX_ERR_HIP, "table scan found %llu nodes, counter says %llu", found, (unsigned long long)n); }
+    if (found > cap) {  // fuller than expected: two halves, the lower one first
+      free_range();
+      if ((int)r.bits + 1 > 2 * g->k || r.bits >= 30) { cleanup(); return fail(MCX_ERR_NOMEM, "not enough free HBM to dump the graph"); }
+      todo.push_back({r.prefix * 2 + 1, r.bits + 1});
+      todo.push_back({r.prefix * 2, r.bits + 1});
+      continue;
+    }
+    const uint64_t m = found;
+    if (m == 0) { free_range(); continue; }
+    export_clock("compacted");
+    // permutation of the compacted entries: by key (sorted) or by slot (table order)
+    size_t tmp_bytes = 0;
+    EXP_TRY(hipMalloc((void **)&d_idx, m * 8));
+    EXP_TRY(hipMalloc((void **)&d_idx2, m * 8));
+    EXP_TRY(hipMalloc((void **)&d_ks, m * 8));
+    if (sorted && W == 2) EXP_TRY(hipMalloc((void **)&d_ks2, m * 8));
+    const unsigned gb = (unsigned)((m + 255) / 256);
+    hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, m);
+    const uint64_t *first_key = sorted ? (W == 2 ? d_k1 : d_k0) : d_slot;
+    EXP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, first_key, d_ks, d_idx, d_idx2, m, 0, 64, st));
+    EXP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, first_key, d_ks, d_idx, d_idx2, m, 0, 64, st));
+    uint64_t *perm = d_idx2;
+    if (sorted && W == 2) {  // LSD: stable second pass on the most significant word
+      hipLaunchKernelGGL(k_gather_u64, dim3(gb), dim3(256), 0, st, (const uint64_t *)d_k0, (const uint64_t *)d_idx2, d_ks2, m);
+      EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, d_idx2, d_idx, m, 0, 64, st));
+      perm = d_idx;
+    }
+    EXP_TRY(hipStreamSynchronize(st));
+    export_clock("sorted");
+    auto produce = [&](uint64_t first, int b) -> hipError_t {
+      const uint64_t cnt = std::min(chunk, m - first);
+      hipLaunchKernelGGL((k_emit_records<W>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g->t,
+                         (const uint64_t *)d_slot, (const uint64_t *)perm, first, cnt, (uint32_t)g->ncols_vis, d_rec2[b]);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      e = hipMemcpyAsync(h_rec2[b], d_rec2[b], cnt * recsz, hipMemcpyDeviceToHost, st);
+      if (e != hipSuccess) return e;
+      return hipEventRecord(done[b], st);
+    };
+    EXP_TRY(produce(0, 0));
+    int b = 0;
+    for (uint64_t first = 0; first < m; first += chunk, b ^= 1) {
+      const uint64_t cnt = std::min(chunk, m - first);
+      if (first + chunk < m) EXP_TRY(produce(first + chunk, b ^ 1));
+      EXP_TRY(hipEventSynchronize(done[b]));
+      if (sink(ctx, h_rec2[b], cnt * recsz) != 0) { cleanup(); return fail(MCX_ERR_SINK, "export sink failed"); }
+    }
+    emitted += m;
+    free_range();
   }
   export_clock("records delivered");
-  cleanup2();
-#undef EXP2_TRY
 #undef EXP_TRY
   cleanup();
+  if (emitted != n) return fail(MCX_ERR_HIP, "export delivered %llu of %llu nodes", (unsigned long long)emitted, (unsigned long long)n);
   return MCX_OK;
 }
 

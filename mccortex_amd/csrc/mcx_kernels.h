@@ -1124,8 +1124,11 @@ __global__ __launch_bounds__(256) void k_intersect_finish(TableView t, uint32_t 
 // waves hit the same address: ~12 ns each, so one atomic per 64 slots made the 2^29-slot scan take
 // 100 ms; per 1024 slots it is 6 ms).
 template <int W>
+// (prefix, pbits): only keys whose top `pbits` bits (of the 2k-bit k-mer) equal `prefix` -- the export
+// walks the key space in ranges when its scratch arrays would not fit beside the table.
 __global__ __launch_bounds__(kThreads) void k_compact(TableView t, uint64_t *key0, uint64_t *key1, uint64_t *slot_out,
-                                                      unsigned long long *cursor, uint64_t cap_out)
+                                                      unsigned long long *cursor, uint64_t cap_out, int kmer_size,
+                                                      uint32_t prefix, uint32_t pbits)
 {
   constexpr int PER = 16;
   const uint32_t lane = threadIdx.x & 63u;
@@ -1138,7 +1141,16 @@ __global__ __launch_bounds__(kThreads) void k_compact(TableView t, uint64_t *key
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       w0[i] = (s0 + i < t.nslots) ? *key_ptr(t, s0 + i) : 0;
-      occ |= (uint32_t)((w0[i] & kFlag) != 0) << i;
+      bool take = (w0[i] & kFlag) != 0;
+      if (take && pbits) {
+        const uint64_t kw = w0[i] & kKeyMask;
+        const int nb0 = 2 * kmer_size - 64 * (W - 1);  // key bits in the top word
+        uint64_t top;
+        if ((int)pbits <= nb0) top = kw >> (nb0 - (int)pbits);
+        else top = (kw << ((int)pbits - nb0)) | (key_ptr(t, s0 + i)[W - 1] >> (64 - ((int)pbits - nb0)));
+        take = top == prefix;
+      }
+      occ |= (uint32_t)take << i;
     }
     const uint32_t cnt = __popc(occ);
     uint32_t incl = cnt;  // inclusive prefix sum over the wave

@@ -411,3 +411,33 @@ def test_really_full_table_is_still_reported(mcx):
         g.sync()
     assert ei.value.code == mcx.MCX_ERR_FULL and "Hash table is full" in str(ei.value)
     g.close()
+
+
+@pytest.mark.parametrize("k", [31, 63, 15])
+def test_export_in_key_ranges_when_scratch_is_short(mcx, orc, k, monkeypatch):
+    """The sorted dump needs ~56 B of scratch per k-mer; when HBM is short it walks the key space in
+    ranges of the top bits and splits a range that is fuller than expected (an AT-rich genome puts
+    most k-mers under a few prefixes).  MCX_EXPORT_SCRATCH caps what the export may take."""
+    rng = np.random.default_rng(k)
+    n = 400_000
+    g0 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, n, p=[0.45, 0.05, 0.05, 0.45])]  # AT-rich
+    bases, offs = synth.reads(6000, 150, seed=k, g=g0, n_frac=0.02)
+    og = orc.Graph(k, 1, 1 << 21)
+    og.add_reads(0, bases, offs)
+    want = og.ctx_bytes(True)[og.header_size():]
+    g = mcx.Graph(k, 1, 1 << 21)
+    g.add_reads(0, bases, offs)
+    full = g.export(True)
+    assert full == want
+    rs = 8 * g.W + 5
+    nk = len(want) // rs
+    # room for about 1/8 of the k-mers at a time (+ the fixed part: 2 x 64 MiB record buffers and 64 MiB slack)
+    monkeypatch.setenv("MCX_EXPORT_SCRATCH", str(3 * (64 << 20) + nk * 72 // 8))
+    assert g.export(True) == want
+    a = np.frombuffer(g.export(False), np.uint8).reshape(-1, rs)
+    b = np.frombuffer(want, np.uint8).reshape(-1, rs)
+    assert sorted(map(bytes, a)) == sorted(map(bytes, b))
+    monkeypatch.setenv("MCX_EXPORT_SCRATCH", str(1 << 20))
+    with pytest.raises(mcx.McxError):
+        g.export(True)
+    g.close()
