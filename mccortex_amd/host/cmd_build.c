@@ -31,7 +31,7 @@ static const char build_usage[] =
 "  -h, --help               This help message\n"
 "  -q, --quiet              Silence status output normally printed to STDERR\n"
 "  -f, --force              Overwrite output files\n"
-"  -m, --memory <mem>       Memory to use\n"
+"  -m, --memory <mem>       Memory to use (sizes the table when -n is absent; only an explicit -m is enforced)\n"
 "  -n, --nkmers <kmers>     Number of hash table entries (e.g. 1G ~ 1 billion)\n"
 "  -t, --threads <T>        Number of threads to use [default: " MCX_STR(DEFAULT_NTHREADS) "]\n"
 "  -k, --kmer <kmer>        Kmer size must be odd (" MCX_STR(MAX_KMER_SIZE) " >= k >= " MCX_STR(MIN_KMER_SIZE) ")\n"
@@ -77,6 +77,7 @@ typedef struct {
   char *path, *path2;   /* path2: second mate file of a --seq2 task kept paired (--remove-pcr) */
   int colour;
   uint8_t fq_cutoff, fq_offset, hp_cutoff;
+  int fq_detected, fq_detected2; /* offset of path / path2 from the head of the file (fq_offset_probe); 0 = not yet known */
   bool remove_pcr, interleaved; /* interleaved: --seqi with --remove-pcr, reads 2i / 2i+1 are mates */
   int matedir;          /* 0 FF, 1 FR, 2 RF, 3 RR (cortex_types.h:18-21) */
   mcx_load_stats stats;
@@ -206,8 +207,10 @@ static void submit_batch(void *arg, read_batch *b, int fq_offset_guess)
   if (parse_only < 0) parse_only = getenv("MCX_PARSE_ONLY") != NULL;
   if (parse_only) return;
   if (sc->use_q && !sc->fq_abs) { /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 */
-    int off = sc->bt->fq_offset ? sc->bt->fq_offset : fq_offset_guess;
-    if (!off) off = 33;
+    /* decided once per file from its head (task_detect_fq_offset); stdin: from its first batch */
+    if (!sc->bt->fq_offset && sc->bt->fq_detected <= 0) sc->bt->fq_detected = fq_offset_guess;
+    int off = sc->bt->fq_offset ? sc->bt->fq_offset : sc->bt->fq_detected;
+    if (off <= 0) off = 33;
     sc->fq_abs = (uint8_t)(sc->bt->fq_cutoff + off);
   }
   struct timespec t0, t1;
@@ -292,12 +295,22 @@ static read_batch *reader_pop(reader_job *j, int *fq_guess)
 
 /* --remove-pcr task: reads go to the GPU in input order, mates side by side
  * (build_graph_from_reads_mt with prefs.remove_pcr_dups, build_graph.c:192-231) */
-static uint8_t fq_abs_of(const build_task *bt, seq_in *in)
-{ /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 */
+static uint8_t fq_abs_of(build_task *bt, seq_in *in, int which)
+{ /* build_graph.c:203-206: cutoff + offset; offset auto-detected when 0 (once per file) */
   if (!bt->fq_cutoff || seq_in_format(in) != SEQ_FMT_FASTQ) return 0;
-  int off = bt->fq_offset ? bt->fq_offset : seq_in_guess_fq_offset(in);
-  if (!off) off = 33;
+  int *det = which ? &bt->fq_detected2 : &bt->fq_detected;
+  if (!bt->fq_offset && *det <= 0) *det = seq_in_guess_fq_offset(in); /* stdin: latched at the first batch */
+  int off = bt->fq_offset ? bt->fq_offset : *det;
+  if (off <= 0) off = 33;
   return (uint8_t)(bt->fq_cutoff + off);
+}
+
+/* FASTQ offset of a task's file(s), once, before any of it is loaded (seq_reader.c:304,376-381) */
+static void task_detect_fq_offset(build_task *bt)
+{
+  if (!bt->fq_cutoff || bt->fq_offset) return;
+  bt->fq_detected = fq_offset_probe(bt->path);
+  if (bt->path2) bt->fq_detected2 = fq_offset_probe(bt->path2);
 }
 
 static void load_task_pcr(mcx_graph *g, build_task *bt)
@@ -344,7 +357,7 @@ static void load_task_pcr(mcx_graph *g, build_task *bt)
       send = &both;
       if (!send->nreads) continue;
     }
-    const uint8_t fq1 = use_q ? fq_abs_of(bt, in1) : 0, fq2 = use_q ? (in2 ? fq_abs_of(bt, in2) : fq1) : 0;
+    const uint8_t fq1 = use_q ? fq_abs_of(bt, in1, 0) : 0, fq2 = use_q ? (in2 ? fq_abs_of(bt, in2, 1) : fq1) : 0;
     mcx_check(mcx_graph_add_reads_pcr(g, bt->colour, send->bases, use_q ? send->quals : NULL, send->offsets, send->nreads,
                                       fq1, fq2, bt->hp_cutoff, paired ? 1 : 0, bt->matedir, &bt->stats), "add reads");
     if (send == &b1) read_batch_clear(&b1);
@@ -606,19 +619,15 @@ int ctx_build(int argc, char **argv)
   size_t graph_mem = 0;
   char s1[64], s2[64];
   status("[memory] %zu bits per kmer", bits_per_kmer);
-  if (nkmers_set) graph_mem = hash_table_mem(num_kmers, bits_per_kmer, &kmers_in_hash);
-  else graph_mem = hash_table_mem_limit(mem_to_use, bits_per_kmer, &kmers_in_hash);
-  if (max_kmers != SIZE_MAX && max_kmers > 0 && !nkmers_set) {
-    uint64_t k2; size_t m2 = hash_table_mem((uint64_t)((double)max_kmers / IDEAL_OCCUPANCY), bits_per_kmer, &k2);
-    if (m2 < graph_mem) { graph_mem = m2; kmers_in_hash = k2; }
+  {
+    table_plan plan;
+    char ebuf[256];
+    const char *err = table_plan_for_build(mem_to_use, mem_set, num_kmers, nkmers_set, bits_per_kmer,
+                                           max_kmers == SIZE_MAX ? -1 : (int64_t)max_kmers, &plan, ebuf, sizeof(ebuf));
+    if (err) die("%s", err);
+    graph_mem = plan.bytes;
+    kmers_in_hash = plan.capacity;
   }
-  if (kmers_in_hash < 1024) graph_mem = hash_table_mem(1024, bits_per_kmer, &kmers_in_hash);
-  if (mem_set && nkmers_set && num_kmers > kmers_in_hash)
-    die("-n <kmers> requires more memory than given with -m <mem> [%s > %s]",
-        bytes_to_str(graph_mem, 1, s1), bytes_to_str(mem_to_use, 1, s2));
-  if (mem_set && graph_mem > mem_to_use)
-    die("Not enough memory for requested graph: require at least %s [>%s]",
-        bytes_to_str(graph_mem, 1, s1), bytes_to_str(mem_to_use, 1, s2));
   status("[memory] graph: %s", bytes_to_str(graph_mem, 1, s1));
 
   stage_time("arguments parsed");
@@ -689,6 +698,7 @@ int ctx_build(int argc, char **argv)
   mcx_check(mcx_graph_device_stats(g, &prev), "device stats"); /* k-mers created by --graph are not a file's */
   for (size_t t = 0; t < ntasks; t++) {
     build_task *bt = &tasks[t];
+    task_detect_fq_offset(bt);
     /* -t threads parse an uncompressed regular file in parallel; gzip, stdin and files the fast
      * path declines go through the sequential parser */
     submit_ctx sc = {g, bt, bt->fq_cutoff > 0 && bt->fmt == SEQ_FMT_FASTQ, 0};

@@ -38,10 +38,13 @@ char *bytes_to_str(unsigned long n, int decimals, char *out);
 /* binary_kmer_to_str (binary_kmer.c:190-210) for the key of a .ctx record: word 0 (most significant) first */
 void kmer_words_to_str(const unsigned char *rec, unsigned kmer_size, char *out);
 
-/* ---- table sizing (src/basic/hash_mem.c:5-51, src/graph/cmd_mem.c:38-130) ---- */
-uint64_t hash_table_cap(uint64_t nkmers, uint64_t *nbuckets, uint8_t *bucket_size);
-size_t hash_table_mem(uint64_t nkmers, size_t entrybits, uint64_t *nkmers_out);
-size_t hash_table_mem_limit(size_t memlimit, size_t entrybits, uint64_t *nkmers_out);
+/* ---- table sizing: entry counts and memory figures of -n / -m as the reference computes them
+ * (src/basic/hash_mem.c:5-51, src/graph/cmd_mem.c:38-130) ---- */
+typedef struct { uint64_t nbuckets, bucket_size, capacity; size_t bytes; } table_plan;
+table_plan table_plan_for_kmers(uint64_t nkmers, size_t entry_bits);
+table_plan table_plan_for_memory(size_t mem, size_t entry_bits);
+const char *table_plan_for_build(size_t mem_to_use, bool mem_set, size_t num_kmers, bool nkmers_set, size_t entry_bits,
+                                 int64_t max_kmers, table_plan *out, char *errbuf, size_t errlen);
 
 /* ---- sequence input (replaces seq_file + src/basic/async_read_io.c for FASTA/FASTQ/plain, .gz) ---- */
 typedef enum { SEQ_FMT_UNKNOWN = 0, SEQ_FMT_FASTA, SEQ_FMT_FASTQ, SEQ_FMT_PLAIN, SEQ_FMT_SAM } seq_fmt;
@@ -65,6 +68,9 @@ size_t seq_in_fill(seq_in *s, read_batch *b, size_t max_bases);
 void read_batch_append(read_batch *dst, const read_batch *src, size_t i); /* read i of src */
 /* FASTQ offset guess from the qualities seen so far (33 or 64); 0 if no qualities */
 int seq_in_guess_fq_offset(const seq_in *s);
+int fq_offset_from_range(int qmin, int qmax);
+/* the offset of a file from its first 1000 records; 0 = no qualities, -1 = stdin (cannot look ahead) */
+int fq_offset_probe(const char *path);
 
 /* Multi-threaded parse of an uncompressed regular file (par_ingest.c): `submit` is called on the
  * calling thread for every batch.  Returns 0 = done, 1 = not suitable (nothing submitted: use the

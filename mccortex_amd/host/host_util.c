@@ -151,38 +151,72 @@ char *bytes_to_str(unsigned long num, int decimals, char *out)
   return out;
 }
 
-/* hash_mem.h:4-13, hash_mem.c:5-51 */
-#define MAX_BUCKET_SIZE 48
-static size_t ht_mem(size_t bktsize, size_t nbkts, size_t nbits) { return (bktsize * nbkts * nbits) / 8 + nbkts * 2; }
+/* ---- table sizing ------------------------------------------------------------------------------
+ * `-n <kmers>` and `-m <mem>` must size the table as the reference does, or a command line that
+ * fits there does not fit here: the reference's table is 2^b buckets of s <= 48 entries plus two
+ * bytes per bucket (src/basic/hash_mem.c:5-51).  The HBM table has no buckets of that kind; only the
+ * resulting entry count (and the memory figure the status lines print) is taken from this plan. */
+#define PLAN_MAX_BUCKET 48
+static size_t plan_bytes(const table_plan *p, size_t entry_bits) { return (size_t)(p->bucket_size * p->nbuckets * entry_bits) / 8 + (size_t)p->nbuckets * 2; }
 
-uint64_t hash_table_cap(uint64_t nkmers, uint64_t *nbuckets, uint8_t *bucket_size)
-{
-  uint64_t bits = 10;
-  while (nkmers / (1UL << bits) > MAX_BUCKET_SIZE) bits++;
-  uint64_t nb = 1UL << bits, bs = (nkmers + nb - 1) / nb;
-  if (bs < 1) bs = 1;
-  if (nbuckets) *nbuckets = nb;
-  if (bucket_size) *bucket_size = (uint8_t)bs;
-  return nb * bs;
+table_plan table_plan_for_kmers(uint64_t nkmers, size_t entry_bits)
+{ /* smallest power-of-two bucket count (>= 1024) whose buckets need at most 48 entries each */
+  table_plan p;
+  unsigned b = 10;
+  while (nkmers / (1UL << b) > PLAN_MAX_BUCKET) b++;
+  p.nbuckets = 1UL << b;
+  p.bucket_size = (nkmers + p.nbuckets - 1) / p.nbuckets;
+  if (p.bucket_size < 1) p.bucket_size = 1;
+  p.capacity = p.nbuckets * p.bucket_size;
+  p.bytes = plan_bytes(&p, entry_bits);
+  return p;
 }
 
-size_t hash_table_mem(uint64_t nkmers, size_t entrybits, uint64_t *nkmers_out)
-{
-  uint64_t nb; uint8_t bs;
-  uint64_t cap = hash_table_cap(nkmers, &nb, &bs);
-  if (nkmers_out) *nkmers_out = cap;
-  return ht_mem(bs, nb, entrybits);
+table_plan table_plan_for_memory(size_t mem, size_t entry_bits)
+{ /* the most entries that fit `mem`: first bucket count whose full-size table reaches it, filled as far as it goes */
+  table_plan p;
+  unsigned b = 10;
+  p.nbuckets = 1UL << b; p.bucket_size = PLAN_MAX_BUCKET;
+  while (plan_bytes(&p, entry_bits) < mem) p.nbuckets = 1UL << ++b;
+  p.bucket_size = (mem - p.nbuckets * 2) / ((p.nbuckets * entry_bits) / 8);
+  if (p.bucket_size == 0) { p.nbuckets = 1UL << --b; p.bucket_size = 1; }
+  if (p.bucket_size > PLAN_MAX_BUCKET) p.bucket_size = PLAN_MAX_BUCKET;
+  p.capacity = p.nbuckets * p.bucket_size;
+  p.bytes = plan_bytes(&p, entry_bits);
+  return p;
 }
 
-size_t hash_table_mem_limit(size_t memlimit, size_t entrybits, uint64_t *nkmers_out)
+/* cmd_get_kmers_in_hash as `build` calls it (src/graph/cmd_mem.c:38-130 with min_num_kmer_req = 0,
+ * use_mem_limit = true; src/commands/ctx_build.c:317-322): -n wins over -m; with neither, the 512 MB
+ * default of -m is filled; an estimate of the k-mers the inputs can hold (max_kmers > 0, at the
+ * ideal occupancy 0.75) caps the table unless -n was given; never fewer than 1024 entries.
+ * Returns NULL or the reference's error message (the caller dies with it). */
+const char *table_plan_for_build(size_t mem_to_use, bool mem_set, size_t num_kmers, bool nkmers_set, size_t entry_bits,
+                                 int64_t max_kmers, table_plan *out, char *errbuf, size_t errlen)
 {
-  size_t bits = 10, nb = 1UL << bits, bs;
-  while (ht_mem(MAX_BUCKET_SIZE, nb, entrybits) < memlimit) { bits++; nb = 1UL << bits; }
-  bs = (memlimit - nb * 2) / ((nb * entrybits) / 8);
-  if (bs == 0) { bits--; nb = 1UL << bits; bs = 1; }
-  if (bs > MAX_BUCKET_SIZE) bs = MAX_BUCKET_SIZE;
-  if (nkmers_out) *nkmers_out = nb * bs;
-  return ht_mem(bs, nb, entrybits);
+  table_plan p = nkmers_set ? table_plan_for_kmers(num_kmers, entry_bits) : table_plan_for_memory(mem_to_use, entry_bits);
+  if (max_kmers > 0 && !nkmers_set) {
+    /* (single precision, as `max_num_kmers_req/IDEAL_OCCUPANCY` with IDEAL_OCCUPANCY 0.75f is: cmd_mem.c:66, hash_mem.h:5) */
+    const table_plan q = table_plan_for_kmers((uint64_t)((float)max_kmers / 0.75f), entry_bits);
+    if (q.bytes < p.bytes) p = q;
+  }
+  if (p.capacity < 1024) p = table_plan_for_kmers(1024, entry_bits);
+  *out = p;
+  char s1[64], s2[64];
+  if (mem_set && nkmers_set && num_kmers > p.capacity) {
+    snprintf(errbuf, errlen, "-n <kmers> requires more memory than given with -m <mem> [%s > %s]",
+             bytes_to_str(p.bytes, 1, s1), bytes_to_str(mem_to_use, 1, s2));
+    return errbuf;
+  }
+  /* The reference checks graph_mem against -m even when -m was not given (its 512 MB default), so
+   * `-n 1G` alone dies there.  Here the table lives in HBM and -m bounds nothing on the host: the
+   * check is made only for an explicit -m (documented in the usage text); HBM is checked apart. */
+  if (mem_set && p.bytes > mem_to_use) {
+    snprintf(errbuf, errlen, "Not enough memory for requested graph: require at least %s [>%s]",
+             bytes_to_str(p.bytes, 1, s1), bytes_to_str(mem_to_use, 1, s2));
+    return errbuf;
+  }
+  return NULL;
 }
 
 void kmer_words_to_str(const unsigned char *rec, unsigned kmer_size, char *out)

@@ -101,10 +101,44 @@ void seq_in_close(seq_in *s)
 seq_fmt seq_in_format(seq_in *s) { return s->fmt; }
 const char *seq_in_path(const seq_in *s) { return s->path; }
 
-int seq_in_guess_fq_offset(const seq_in *s)
-{ /* Sanger/Illumina-1.8 (33) unless every quality seen is >= 59 (Solexa/Illumina 1.3-1.5 use 64) */
-  if (s->qmax == 0) return 0;
-  return s->qmin >= 59 ? 64 : 33;
+/* FASTQ offset from the range of quality characters seen.  The reference asks seq_file
+ * (seq_guess_fastq_format, third-party library github.com/noporpoise/seq_file, an empty submodule
+ * in this checkout: no pinned version) through guess_fastq_format (src/basic/seq_reader.c:252-288,
+ * which prints the table's FASTQ_OFFSET / FASTQ_MIN / FASTQ_MAX).  seq_file's published rule: the
+ * Sanger range is tested FIRST -- min >= 33 and max <= 73 is "Sanger (Phred+33)" even when every
+ * quality is high (simulated reads, binned qualities: all 'I') --, a wider range from 33 is Sanger /
+ * Illumina 1.8+, then the Phred+64 families by their minimum (67: Illumina 1.5+, 64: Illumina 1.3+,
+ * 59: Solexa) with max <= 104 (one above the nominal top is tolerated); anything else is read as
+ * offset 33. */
+int fq_offset_from_range(int qmin, int qmax)
+{
+  if (qmax == 0 || qmin > qmax) return 0;          /* no qualities seen */
+  if (qmin >= 33 && qmax <= 73) return 33;          /* Sanger */
+  if (qmin >= 33 && qmin < 59) return 33;           /* Sanger / Illumina 1.8+, range up to 126 */
+  if (qmin >= 59 && qmax <= 105) return 64;         /* Solexa (59), Illumina 1.3+ (64), Illumina 1.5+ (66/67) */
+  return 33;                                        /* unknown: offset 33, max 126 */
+}
+
+int seq_in_guess_fq_offset(const seq_in *s) { return fq_offset_from_range(s->qmin, s->qmax); }
+
+/* The offset of a file, decided ONCE from the head of the file (the first 1000 records with
+ * qualities) before anything of it is loaded, so that it depends neither on -t nor on which batch
+ * is parsed first.  0 = not a FASTQ file / no qualities; -1 = cannot look ahead (stdin). */
+int fq_offset_probe(const char *path)
+{
+  if (strcmp(path, "-") == 0) return -1;
+  seq_in *s = seq_in_open(path);
+  if (!s) return 0;
+  int off = 0;
+  if (s->fmt == SEQ_FMT_FASTQ) {
+    read_batch b;
+    read_batch_init(&b, false);
+    while (b.nreads < 1000 && seq_in_fill(s, &b, b.nbases + 1) > 0) {}
+    off = fq_offset_from_range(s->qmin, s->qmax);
+    read_batch_free(&b);
+  }
+  seq_in_close(s);
+  return off;
 }
 
 void read_batch_init(read_batch *b, bool want_quals)

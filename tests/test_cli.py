@@ -385,3 +385,23 @@ def test_build_on_several_devices_matches_oracle_ctx(built, orc, tmp_path):
     # an odd number of devices is refused; --intersect needs one device
     rc, _, err = run(31, "build", "-D", "0,0,0", "-k", "31", "-s", "a", "--seq", f0, str(tmp_path / "x.ctx"))
     assert rc == 1 and "power of two" in err
+
+
+@pytest.mark.gpu
+def test_quality_offset_is_decided_once_per_file(built, orc, tmp_path):
+    """Uniformly high Phred+33 qualities ('I' everywhere with a few low ones late in the file) are
+    Sanger: -Q 10 must cut at 43, whatever -t is and whichever byte range is parsed first."""
+    bases, offs = synth.reads(30000, 100, genome_len=50000, seed=31)
+    quals = np.full(len(bases), ord("I"), dtype=np.uint8)
+    quals[len(quals) // 2::97] = ord("#")  # low qualities only in the second half of the file
+    fq = _write_inputs(tmp_path, bases, offs, "hi", "fq", qual=quals)
+    og = orc.Graph(21, 1, 1 << 22)
+    og.set_sample(0, "s")
+    st = og.add_reads(0, bases, offs, quals=quals, fq_cutoff=43)
+    og.update_stats(0, st)
+    want = og.ctx_bytes(True)
+    for t in ("1", "2", "7"):
+        out = str(tmp_path / ("hi%s.ctx" % t))
+        rc, _, err = run(31, "build", "-q", "-t", t, "-k", "21", "-n", "4M", "-S", "-s", "s", "-Q", "10", "--seq", fq, out)
+        assert rc == 0, err
+        assert open(out, "rb").read() == want, t
