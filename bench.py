@@ -4,7 +4,12 @@
 Workload (BASELINE.json configs[1], "C2"): k=31, 1 colour, synthetic 150 bp reads drawn from a
 200 Mbp random genome (50% reverse strand, 0.1% substitutions, 1% of reads with an N), table of
 2^30 slots.  One step = one batch of 5,000,000 reads (600M k-mer occurrences) that is already
-resident in HBM as a '\\n'-separated byte stream; the default 10 steps are the 50M x 150bp set.
+resident in HBM as a '\\n'-separated ASCII byte stream (`value`: parse and H2D are outside the number);
+the default 10 steps are the 50M x 150bp set.  The same run also reports, as separate objects of the
+JSON line: `host_fed` (the same reads handed over in host memory: staging + PCIe inside the clock),
+`e2e` (`mccortex31 build --sort` on a FASTQ file of the same shape: process start, parse, build, sort,
+.ctx write), `default_defer` (the library's own flush size instead of the bench's), `other_configs`
+(C4: k=63; C5-like: 4 colours) and `cpu_baseline` (the oracle on the host cores).
 
 N>1 (one process per GPU, torchrun): weak scaling -- every rank takes its own 5M-read batch per step
 (genome scaled to N x 200 Mbp so every shard sees the same load), cuts the reads into per-owner
@@ -86,53 +91,234 @@ def make_batch_iid(nreads, seed, device):
     return out.reshape(-1)
 
 
+def csrc_digest():
+    """sha1 over the kernel sources: a PMC traffic figure is only valid for the code it was taken on"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mccortex_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        h.update(n.encode())
+        h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, occurrences_per_launch):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json,
     written by tools/prof.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's launch size."""
+    command, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's launch size.  Refused
+    (None) when the summary was taken on other kernel sources than the ones that just ran."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
         return None, None
     try:
-        t = json.load(open(files[-1]))["kernels"][kernel]
+        meta = json.load(open(files[-1]))
+        rel = os.path.relpath(files[-1], ROOT)
+        if meta.get("csrc_digest") != csrc_digest():
+            return None, "%s is stale (kernel sources changed since it was taken)" % rel
+        t = meta["kernels"][kernel]
         per_occ = (t["read_bytes"] + t["written_bytes"]) / t["occurrences"]
-        return per_occ * occurrences_per_launch, os.path.relpath(files[-1], ROOT)
+        return per_occ * occurrences_per_launch, rel
     except (KeyError, ValueError, ZeroDivisionError):
         return None, None
 
 
-def cpu_baseline(stream_dev, rank):
-    """Time the CPU oracle (port of the reference algorithm, pthreads) on a bounded sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(stream_dev, fastq_sample=None):
+    """The CPU oracle (port of the reference algorithm: bucket-locked table, pthreads) on the host's
+    cores, bounded samples of the same reads.  Insert phase from memory at -t {1, 8, 32, nproc} on
+    500k reads per point (the arrays are prefaulted by the same number of threads first, see
+    orc_graph_tune: first-touch faults made the short samples of round 1 scale negatively), and the
+    reference-shaped end-to-end run -- ONE reader thread parsing the FASTQ file into a 2048-slot pool,
+    -t workers (src/basic/async_read_io.c:145-175,283-310) -- on a 500k-read file."""
     from oracle import orc
     ncores = os.cpu_count() or 1
-    nthreads = 1
+    nsample = 500_000
 
-    def run(nreads):
-        s = stream_dev[:nreads * (READ_LEN + 1)].reshape(nreads, READ_LEN + 1)[:, :READ_LEN].contiguous().cpu().numpy()
-        bases = s.reshape(-1)
-        offs = (np.arange(nreads + 1, dtype=np.uint64) * READ_LEN)
-        g = orc.Graph(K, 1, max(1 << 20, nreads * 320))  # occupancy ~0.4 as in C2
+    s = stream_dev[:nsample * (READ_LEN + 1)].reshape(nsample, READ_LEN + 1)[:, :READ_LEN].contiguous().cpu().numpy()
+    bases = s.reshape(-1)
+    offs = (np.arange(nsample + 1, dtype=np.uint64) * READ_LEN)
+
+    def run(nt):
+        g = orc.Graph(K, 1, max(1 << 20, nsample * 320))  # occupancy ~0.4 as in C2
+        g.tune(nt)
         t0 = time.perf_counter()
-        st = g.add_reads(0, bases, offs, nthreads=nthreads)
+        st = g.add_reads(0, bases, offs, nthreads=nt)
         dt = time.perf_counter() - t0
         return st.num_kmers_loaded, dt
 
-    # the reference's bucket-locked table scales badly (its own benchmark shows negative
-    # scaling, BASELINE.md): scan thread counts on a small sample and time the best one
-    n0 = 50_000
-    scan = {}
-    for nt in [t for t in (1, 4, 8, 16, 32, 64, 128) if t <= ncores]:
-        nthreads = nt
-        km, dt = run(n0)
-        scan[nt] = km / dt
-    nthreads = max(scan, key=scan.get)
-    n1 = int(min(BATCH_READS, max(n0, 12.0 * scan[nthreads] / 120)))
-    km, dt = run(n1)
-    return {"value": km / dt, "unit": "k-mers/s", "cores": nthreads, "kind": "port",
-            "sample": "first %d reads of step 0 (%d k-mer occurrences, %.1f s), oracle/mcx_oracle.c "
-                      "bucketed-table build, best of thread counts %s" % (n1, km, dt, sorted(scan)),
-            "host_cpus": ncores, "thread_scan_kmers_per_s": {str(k): round(v) for k, v in scan.items()}}
+    scan, kmers = {}, 0
+    for nt in sorted({t for t in (1, 8, 32, ncores) if t <= ncores}):
+        kmers, dt = run(nt)
+        scan[nt] = kmers / dt
+    best = max(scan, key=scan.get)
+    out = {"value": scan[best], "unit": "k-mers/s", "cores": best, "kind": "port",
+           "sample": "first %d reads of step 0 (%d k-mer occurrences) per thread count, oracle/mcx_oracle.c "
+                     "bucket-locked table build from memory, arrays prefaulted; value = best thread count" % (nsample, kmers),
+           "host_cpus": ncores, "cpu_model": cpu_model(),
+           "threads_kmers_per_s": {str(k): round(v) for k, v in sorted(scan.items())}}
+    if fastq_sample:
+        e2e = {}
+        for nt in sorted({t for t in (best,) if t <= ncores}):
+            g = orc.Graph(K, 1, max(1 << 20, nsample * 320))
+            g.tune(nt)
+            tot, ins, st = g.build_file(fastq_sample, nt)
+            t0 = time.perf_counter()
+            g.ctx_bytes(False)  # graph_write_all_kmers_direct in table order (the reference's default: no --sort)
+            tot += time.perf_counter() - t0
+            e2e[str(nt)] = {"kmers_per_s": round(st.num_kmers_loaded / tot), "seconds": round(tot, 3), "insert_seconds": round(ins, 3)}
+        out["e2e_reference_shaped"] = {"what": "1 reader thread per file -> 2048-slot pool -> -t workers, unsorted .ctx dump to memory; %d-read FASTQ" % nsample,
+                                       "by_workers": e2e}
+    return out
+
+
+def kernel_table(prof, kmers, W=1, bases_per_kmer=1.25):
+    """{kernel: launches / ms / achieved GB/s / frac of HBM peak} from the library's HIP-event spans;
+    algorithmic bytes per occurrence of every kernel as in DESIGN.md section 4"""
+    alg = {"k_stream": bases_per_kmer + 20.0, "k_stream_bin": bases_per_kmer + 8.0 * W, "k_tuples_bin": 16.0 * W,
+           "k_lds_insert": 8.0 * W, "k_insert_tuples": 21.0 + 8.0 * W, "k_stream_superk": bases_per_kmer + 2.3, "k_superk_bin": 2.3 + 8.0}
+    out = {}
+    for n, (c, t) in prof.items():
+        if t <= 0:
+            continue
+        ach = alg.get(n, 0.0) * kmers / (t * 1e-3) / 1e9
+        out[n] = {"launches": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4), "achieved": round(ach, 1),
+                  "frac": round(ach / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples):
+    """one device-resident build of `batches` (fresh graph) -> record"""
+    import torch
+    g = mcx.Graph(k, ncols, table_slots)
+    if defer_tuples:
+        g.configure("defer_tuples", defer_tuples)
+    g.add_stream_dev(0, batches[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
+    g.sync(); g.reset(); g.sync()
+    g.configure("profile", 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c, b in zip(colours, batches):
+        g.add_stream_dev(c, b, b.numel())
+    g.sync()
+    dt = time.perf_counter() - t0
+    st = g.device_stats()
+    prof = g.profile()
+    g.close()
+    torch.cuda.empty_cache()
+    W = (2 * k + 63) // 64
+    kt = kernel_table(prof, st.num_kmers_loaded, W, READ_LEN / (READ_LEN - k + 1.0))
+    dom = max(kt, key=lambda n: kt[n]["total_ms"])
+    return {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(batches), "steps": len(batches),
+            "kmers_inserted": int(st.num_kmers_loaded), "distinct_kmers": int(st.num_kmers_novel),
+            "dominant_kernel": dom, "dominant_frac": kt[dom]["frac"], "kernels": kt}
+
+
+def extras(mcx, batches, nsteps, table_slots):
+    """host-fed, end-to-end, default flush size and the other BASELINE configs (rank 0, N = 1)"""
+    import subprocess
+    import tempfile
+    import torch
+    out = {}
+    B = batches[0].numel() // (READ_LEN + 1)
+    steps = batches[:nsteps]
+    # (d) the library's own flush size (min(4 x slots, 2^31) occurrences) instead of the bench's
+    r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, 0)
+    r["what"] = "as `value`, but with the library's default flush size instead of %d occurrences" % DEFER_TUPLES
+    out["default_defer"] = r
+    # (e) C4: k = 63 (two-word keys); C5-like: 4 colours on one GPU
+    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, 5_000_000_000)
+    r["workload"] = "C4: k=63 (2-word BinaryKmer), 1 colour, %d reads x %d bp per step, table %d slots, 1 GPU" % (B, READ_LEN, table_slots)
+    out["other_configs"] = {"C4_k63": r}
+    cols = [min(3, 4 * i // max(1, len(steps))) for i in range(len(steps))]
+    r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000)
+    r["workload"] = "C5-like: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
+    out["other_configs"]["C5_like_4_colours_1gpu"] = r
+    # (b) the same reads handed over in HOST memory through mcx_graph_add_reads (pinned buffers):
+    # staging, PCIe and the kernels inside the clock
+    nh = len(steps)
+    hb = []
+    for b in steps[:nh]:
+        t = torch.empty((B, READ_LEN), dtype=torch.uint8).pin_memory()
+        t.copy_(b.reshape(B, READ_LEN + 1)[:, :READ_LEN])
+        hb.append(t.numpy().reshape(-1))
+    offs = np.arange(B + 1, dtype=np.uint64) * READ_LEN
+    g = mcx.Graph(K, 1, table_slots)
+    g.add_reads(0, hb[0][:READ_LEN * 1000], offs[:1001]); g.sync(); g.reset(); g.sync()
+    t0 = time.perf_counter()
+    for h in hb:
+        g.add_reads(0, h, offs)
+    g.sync()
+    dt = time.perf_counter() - t0
+    st = g.device_stats()
+    g.close()
+    torch.cuda.empty_cache()
+    out["host_fed"] = {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "steps": nh, "ms_per_step": 1e3 * dt / nh,
+                       "host_gb_per_s": sum(h.size for h in hb) / dt / 1e9,
+                       "what": "reads as concatenated ASCII bases + offsets in pinned host memory -> mcx_graph_add_reads "
+                               "(staging threads, H2D and kernels inside the clock), %d x %d reads" % (nh, B)}
+    # (c) end to end: mccortex31 build --sort on a FASTQ file of the same reads
+    exe = os.path.join(ROOT, "mccortex_amd", "bin", "mccortex31")
+    tmp = tempfile.mkdtemp(prefix="mcx_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    fq, fq_small, ctx = os.path.join(tmp, "reads.fq"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "out.ctx")
+    try:
+        ne = min(2, len(steps))
+        hdr = torch.tensor(list(b"@r\n"), dtype=torch.uint8, device=steps[0].device)
+        mid = torch.tensor(list(b"+\n"), dtype=torch.uint8, device=steps[0].device)
+        with open(fq, "wb") as f:
+            for i, b in enumerate(steps[:ne]):
+                rec = torch.empty((B, 3 + (READ_LEN + 1) + 2 + (READ_LEN + 1)), dtype=torch.uint8, device=b.device)
+                rec[:, :3] = hdr
+                rec[:, 3:3 + READ_LEN + 1] = b.reshape(B, READ_LEN + 1)
+                rec[:, 3 + READ_LEN + 1:3 + READ_LEN + 3] = mid
+                rec[:, 3 + READ_LEN + 3:-1] = ord("I")
+                rec[:, -1] = ord("\n")
+                a = rec.cpu().numpy()
+                a.tofile(f)
+                if i == 0:
+                    a[:500_000].tofile(fq_small)
+                del rec, a
+        nthreads = min(32, os.cpu_count() or 1)
+        cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-t", str(nthreads), "--sort", "--sample", "bench", "--seq", fq, ctx]
+        best = None
+        for _ in range(2):  # second run: file in the page cache, HIP kernels' code objects loaded before
+            t0, w0 = time.perf_counter(), time.time()
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MCX_TIMING="1"))
+            dt, w1 = time.perf_counter() - t0, time.time()
+            if p.returncode != 0:
+                raise RuntimeError("mccortex31 build failed: " + p.stderr.decode(errors="replace")[-400:])
+            if best is None or dt < best[0]:
+                best = (dt, p.stderr.decode(errors="replace"), w0, w1)
+        kmers = ne * B * (READ_LEN - K + 1)  # upper bound; the exact figure: reads with an N lose a few
+        for line in best[1].splitlines():
+            if "kmers" in line and "Loaded" in line:
+                pass
+        stages = [ln.strip() for ln in best[1].splitlines() if ln.startswith("[timing]")]
+        ep = {ln.split()[1]: float(ln.split()[2]) for ln in stages if "epoch_" in ln}
+        outside = {}
+        if "epoch_main_entry" in ep and "epoch_main_exit" in ep:  # what the command itself does not see
+            outside = {"spawn_to_main_s": round(ep["epoch_main_entry"] - best[2], 3), "main_s": round(ep["epoch_main_exit"] - ep["epoch_main_entry"], 3),
+                       "exit_to_reaped_s": round(best[3] - ep["epoch_main_exit"], 3)}
+        out["e2e"] = {"value": kmers / best[0], "unit": "k-mers/s (upper bound on k-mers: %d per read)" % (READ_LEN - K + 1),
+                      "seconds": best[0], "fastq_bytes": os.path.getsize(fq), "ctx_bytes": os.path.getsize(ctx),
+                      "command": "mccortex31 build -k %d -n %d -t %d --sort --seq <%d-read FASTQ> out.ctx" % (K, table_slots, nthreads, ne * B),
+                      "what": "wall clock of the whole process (start, HIP init, parse, build, device sort, .ctx write), best of 2 runs",
+                      "process": outside, "stages": [x for x in stages if "epoch_" not in x][-14:]}
+        out["_fastq_sample"] = fq_small
+        out["_tmpdir"] = tmp
+    except Exception as e:  # the extras must never cost the headline its line
+        out["e2e"] = {"error": str(e)[:300]}
+        out["_tmpdir"] = tmp
+    return out
 
 
 def main():
@@ -142,6 +328,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-reads", type=int, default=BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the device-resident figure (profiling passes)")
     ap.add_argument("--table-slots", type=int, default=TABLE_SLOTS, help="experiments only")
     ap.add_argument("--genome", type=int, default=GENOME_PER_GPU, help="experiments only")
     ap.add_argument("--err", type=float, default=0.001, help="experiments only")
@@ -279,10 +466,12 @@ def main():
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": nsteps, "warmup": nwarm,
             "ms_per_step": 1e3 * dt / nsteps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("C2-stress: k=31, 1 colour, %d iid random reads x %d bp per step per GPU, table %d slots per GPU"
-                                    % (B, READ_LEN, args.table_slots)) if args.iid else
+            "config": {"workload": ("C2-stress: k=31, 1 colour, %d iid random reads x %d bp per step per GPU, table %d slots per GPU; "
+                                    "input resident in HBM as an ASCII byte stream" % (B, READ_LEN, args.table_slots)) if args.iid else
                                    "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
-                                   "table %d slots per GPU" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots),
+                                   "table %d slots per GPU; input already resident in HBM as an ASCII byte stream (parse and H2D "
+                                   "outside `value`: see host_fed and e2e)" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots),
+                       "input": "device-resident ASCII stream",
                        "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
                        "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
@@ -304,10 +493,7 @@ def main():
                            "avg_kernel_ms": avg_ms, "launches": calls, "alg_bytes_per_launch": alg_bytes,
                            # every kernel of the path: its own algorithmic bytes per occurrence (tuples and bases
                            # only; k_lds_insert also streams the table once per flush) over its time
-                           "kernels": {n: {"launches": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4),
-                                           "achieved": round(KERNEL_ALG_BYTES.get(n, 0.0) * kmers_local / (t * 1e-3) / 1e9, 1),
-                                           "frac": round(KERNEL_ALG_BYTES.get(n, 0.0) * kmers_local / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                                       for n, (c, t) in prof.items() if t > 0},
+                           "kernels": kernel_table(prof, kmers_local),
                            "pipeline": {"gpu_ms": gpu_ms, "alg_bytes": pipe_bytes,
                                         "achieved": pipe_bytes / (gpu_ms * 1e-3) / 1e9,
                                         "frac": pipe_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -319,8 +505,19 @@ def main():
         out["roofline"]["random_access"] = {"occurrences_per_s": kmers_local / (gpu_ms * 1e-3),
                                             "measured_random_rmw_peak_per_s": 17.3e9,
                                             "ratio": kmers_local / (gpu_ms * 1e-3) / 17.3e9}
+        ex = {}
+        if not sharded and not args.no_extras and not args.iid and not args.direct:
+            graph.close()
+            torch.cuda.empty_cache()
+            ex = extras(mcx, batches, nsteps, args.table_slots)
+            for key in ("host_fed", "e2e", "default_defer", "other_configs"):
+                if key in ex:
+                    out[key] = ex[key]
         if not args.no_cpu_baseline and not sharded:
-            out["cpu_baseline"] = cpu_baseline(batches[0], rank)
+            out["cpu_baseline"] = cpu_baseline(batches[0], ex.get("_fastq_sample"))
+        if ex.get("_tmpdir"):
+            import shutil
+            shutil.rmtree(ex["_tmpdir"], ignore_errors=True)
     if world > 1 or force_shard:
         dist.barrier()
         dist.destroy_process_group()

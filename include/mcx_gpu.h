@@ -87,7 +87,8 @@ int mcx_graph_reset(mcx_graph *g);
  *                  up or the graph is read (sync / nkmers / stats / export); 0: every
  *                  occurrence is inserted straight into the HBM table with device atomics.
  *                  Both give the same graph.
- *   "defer_tuples" occurrences buffered per flush (sizes the bin workspace in HBM)
+ *   "defer_tuples" occurrences buffered per flush (sizes the bin workspace in HBM); default: 64 per
+ *                  table slot within 30 % of the HBM free after the table was allocated
  *   "flush_regions" table regions split + applied per step of a flush (0 = automatic: 16 K sub-tables
  *                  per step); bounds the sub-table bin workspace to that share of the table
  *   "intersect"    1: `build --intersect` (ctx_build.c:341-363,384-413).  The graph must have been
@@ -295,6 +296,12 @@ int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbyte
                               void *d_counts, uint64_t seg_cap);
 int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_recs, const void *d_counts, uint32_t nseg,
                              uint64_t seg_cap, uint64_t kmers_upper_bound);
+
+/* Host-side packer of the staging path of mcx_graph_add_reads, exported for its test: n (a
+ * multiple of 32) ASCII characters -> n / 16 code words (2 bits per base, A=0 C=1 G=2 T=3 as
+ * src/basic/dna.c:8-25, first base on top) and n / 16 x 16 invalid flags (first base = bit 15; set
+ * for every character that is not one of ACGTacgt). */
+void mcx_pack_bases(const uint8_t *src, uint64_t n, uint32_t *code, uint16_t *inv);
 
 /* Wait for all submitted work; reports MCX_ERR_FULL if any insert ran out of
  * slots (the reference dies with "Hash table is full"). */

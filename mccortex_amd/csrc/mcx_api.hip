@@ -62,7 +62,7 @@ static uint64_t stage_bytes()
   static uint64_t v = 0;
   if (!v) {
     const char *e = getenv("MCX_STAGE_BYTES");
-    v = e ? strtoull(e, nullptr, 10) : (32ull << 20);
+    v = e ? strtoull(e, nullptr, 10) : (128ull << 20);
     if (v < 1024) v = 1024;
     v = (v + 63) / 64 * 64;
   }
@@ -322,6 +322,8 @@ struct StreamLaunch {
   const uint8_t *stream;
   uint64_t nbytes, pos_lo, pos_hi;
   unsigned char *flag;
+  const uint32_t *code = nullptr;  // packed form of the stream (StreamArgs), `stream` is null then
+  const uint16_t *inv = nullptr;
 };
 
 #define DISPATCH_WC(g, F, ...)                                                        \
@@ -352,7 +354,7 @@ template <class K> static void allow_lds(K kernel, size_t bytes)
 static StreamArgs make_args(mcx_graph *g, const StreamLaunch &L)
 {
   StreamArgs a;
-  a.stream = L.stream; a.nbytes = L.nbytes; a.pos_lo = L.pos_lo; a.pos_hi = L.pos_hi;
+  a.stream = L.stream; a.code = L.code; a.inv = L.inv; a.nbytes = L.nbytes; a.pos_lo = L.pos_lo; a.pos_hi = L.pos_hi;
   a.tile0 = L.pos_lo / kTile;
   a.ntiles = (L.pos_hi + kTile - 1) / kTile;
   a.k = g->k; a.ctr = g->d_ctr; a.flag = L.flag;
@@ -366,8 +368,33 @@ template <int W, bool ONECOL> static void launch_direct_t(mcx_graph *g, const St
   if (!nt) return;
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
   SpanGuard sp(g, "k_stream");
-  hipLaunchKernelGGL((k_stream<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid)), dim3(kThreads), 0,
-                     g->stream, a, is);
+  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
+  if (a.code) hipLaunchKernelGGL((k_stream<W, ONECOL, true>), grid, dim3(kThreads), 0, g->stream, a, is);
+  else hipLaunchKernelGGL((k_stream<W, ONECOL, false>), grid, dim3(kThreads), 0, g->stream, a, is);
+}
+
+template <int W, bool ONECOL, bool FULL, int SH, bool PK>
+static void launch_bin_stream_pk(mcx_graph *g, const StreamArgs &a, uint64_t nt, int colour, BinSpec bs, BinOut out)
+{
+  InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
+  static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
+  bool &once = once_dev[g->device & 63];
+  if (!once) {
+    allow_lds(k_stream_bin<W, ONECOL, 512, FULL, SH, PK>, sizeof(BinLds<W, 512, FULL>));
+    allow_lds(k_stream_bin<W, ONECOL, 1024, FULL, SH, PK>, sizeof(BinLds<W, 1024, FULL>));
+    allow_lds(k_stream_bin<W, ONECOL, kMaxBins, FULL, SH, PK>, sizeof(BinLds<W, kMaxBins, FULL>));
+    once = true;
+  }
+  SpanGuard sp(g, "k_stream_bin");
+  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
+  // the histogram capacity sets the LDS footprint and with it the blocks per CU: 512 and 1024 bins
+  // leave room for 4 blocks (W=1), 2048 for 2
+  if (bs.nlocal <= 512)
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL, SH, PK>), grid, dim3(kThreads), sizeof(BinLds<W, 512, FULL>), g->stream, a, bs, out, is);
+  else if (bs.nlocal <= 1024)
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 1024, FULL, SH, PK>), grid, dim3(kThreads), sizeof(BinLds<W, 1024, FULL>), g->stream, a, bs, out, is);
+  else
+    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins, FULL, SH, PK>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, FULL>), g->stream, a, bs, out, is);
 }
 
 template <int W, bool ONECOL, bool FULL, int SH>
@@ -376,25 +403,8 @@ static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour,
   const StreamArgs a = make_args(g, L);
   const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
   if (!nt) return;
-  InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
-  static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
-  bool &once = once_dev[g->device & 63];
-  if (!once) {
-    allow_lds(k_stream_bin<W, ONECOL, 512, FULL, SH>, sizeof(BinLds<W, 512, FULL>));
-    allow_lds(k_stream_bin<W, ONECOL, 1024, FULL, SH>, sizeof(BinLds<W, 1024, FULL>));
-    allow_lds(k_stream_bin<W, ONECOL, kMaxBins, FULL, SH>, sizeof(BinLds<W, kMaxBins, FULL>));
-    once = true;
-  }
-  SpanGuard sp(g, "k_stream_bin");
-  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
-  // the histogram capacity sets the LDS footprint and with it the blocks per CU: 512 and 1024 bins
-  // leave room for 4 blocks (W=1), 2048 for 2
-  if (bs.nlocal <= 512)
-    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, 512, FULL>), g->stream, a, bs, out, is);
-  else if (bs.nlocal <= 1024)
-    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 1024, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, 1024, FULL>), g->stream, a, bs, out, is);
-  else
-    hipLaunchKernelGGL((k_stream_bin<W, ONECOL, kMaxBins, FULL, SH>), grid, dim3(kThreads), sizeof(BinLds<W, kMaxBins, FULL>), g->stream, a, bs, out, is);
+  if (!FULL && a.code) launch_bin_stream_pk<W, ONECOL, FULL, SH, !FULL>(g, a, nt, colour, bs, out);  // (owner bins of full tuples only exist for ASCII streams)
+  else launch_bin_stream_pk<W, ONECOL, FULL, SH, false>(g, a, nt, colour, bs, out);
 }
 
 template <int W, bool ONECOL, bool IN_FULL, bool SHARD>
@@ -519,7 +529,21 @@ static int ensure_defer(mcx_graph *g)
   uint64_t tcap = g->defer_tuples;
   if (!tcap) {
     const char *e = getenv("MCX_DEFER_TUPLES");
-    tcap = e ? strtoull(e, nullptr, 10) : std::min<uint64_t>(std::max<uint64_t>(4 * g->t.nslots, 1ull << 20), 1ull << 31);
+    if (e) {
+      tcap = strtoull(e, nullptr, 10);
+    } else {
+      // Default flush size.  Every flush streams the whole table through LDS once (2 x 16 B per
+      // slot), so the more occurrences a flush applies the better: up to 64 per slot, within 30 %
+      // of the HBM that is free once the table stands (the part has 288 GB: a 16 GiB table leaves
+      // room for 8 G occurrences per flush), never below 1 M.
+      size_t fr = 0, tot = 0;
+      (void)hipMemGetInfo(&fr, &tot);
+      // L1 segments (x 1.06) + the group's sub-table bins; a shard of a multi-GPU table splits on arrival
+      // and needs sub-table bins for the whole table (x 1.25) as well
+      const uint64_t per_tuple = 8ull * g->W * (g->t.lbo ? 240 : 118) / 100 + 1;
+      const uint64_t by_mem = (uint64_t)((double)fr * 0.30) / per_tuple;
+      tcap = std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(64 * g->t.nslots, by_mem), 1ull << 33), 1ull << 20);
+    }
   }
   // Allocate the bins; if HBM is short halve the flush size (down to 1M occurrences), and if even
   // that does not fit build with the direct path (same graph, just slower).
@@ -833,7 +857,7 @@ extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint
 static int shard_bins_launch(mcx_graph *g, const StreamLaunch &L, void *d_keys, void *d_counts, uint64_t seg_cap,
                              void *d_ov_keys, void *d_ov_edges, void *d_ov_counts, uint64_t ov_cap)
 {
-  if (((uintptr_t)L.stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  if (!L.code && ((uintptr_t)L.stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
   if (g->t.lb1 + g->t.lbo > 11) return fail(MCX_ERR_ARG, "too many (owner, region) bins");
   if (seg_cap >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "segment capacity must be below 2^32 tuples");
   HIP_TRY(hipSetDevice(g->device));
@@ -999,13 +1023,84 @@ extern "C" uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int 
 // ---------------------------------------------------------------------------
 // host-buffer entry: stage reads as a '\n'-separated stream
 // ---------------------------------------------------------------------------
-// threads that copy reads into the pinned staging buffer (MCX_STAGE_THREADS, default 4)
+// ---- 16 ASCII bases -> one code word + 16 invalid flags, on the host -----------------------------
+// The same mapping as encode_words() on the device (mcx_kernels.h): codes A=0 C=1 G=2 T=3 from bits
+// 1-2 of the character, first base on top; a position is invalid unless its character is one of
+// ACGTacgt (dna.c:8-25).  Packed on the host, a position costs 3 bits on PCIe instead of 8 and the
+// k-merising kernel starts from what it would otherwise compute in its tile prologue.
+static inline void pack16_swar(const uint8_t *src, uint32_t *code, uint16_t *inv)
+{
+  uint32_t c = 0, v = 0;
+  for (int h = 0; h < 2; h++) {
+    uint64_t x;
+    memcpy(&x, src + 8 * h, 8);
+    const uint64_t t = ((x >> 1) ^ (x >> 2)) & 0x0303030303030303ULL;
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    c = (c << 16) | ((lo * 0x40100401u) >> 24 << 8) | ((hi * 0x40100401u) >> 24);
+    const uint64_t u = x & 0xDFDFDFDFDFDFDFDFULL;
+#define MCX_NZ64(z) ((((z) & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | (z))
+    const uint64_t bad = MCX_NZ64(u ^ 0x4141414141414141ULL) & MCX_NZ64(u ^ 0x4343434343434343ULL) &
+                         MCX_NZ64(u ^ 0x4747474747474747ULL) & MCX_NZ64(u ^ 0x5454545454545454ULL) & 0x8080808080808080ULL;
+#undef MCX_NZ64
+    // bit of byte i -> bit 63 - i: multiplier = sum of 2^(63 - 9 i) (no two products meet: no carries)
+    v = (v << 8) | (uint32_t)(((bad >> 7) * 0x8040201008040201ULL) >> 56);
+  }
+  *code = c;
+  *inv = (uint16_t)v;
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,bmi2"))) static void pack_block_avx2(const uint8_t *src, size_t n, uint32_t *code, uint16_t *inv)
+{
+  const __m256i m3 = _mm256_set1_epi8(3), mdf = _mm256_set1_epi8((char)0xDF);
+  const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+  for (size_t i = 0; i + 32 <= n; i += 32) {
+    const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+    const __m256i t = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), m3);
+    const __m256i u = _mm256_and_si256(v, mdf);
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)));
+    const uint32_t bad = ~(uint32_t)_mm256_movemask_epi8(ok);  // bit j = byte j is not a base
+    uint64_t l[4];
+    _mm256_storeu_si256((__m256i *)l, t);
+    // byte-swap a lane, then gather its 2-bit fields: the first base ends up on top
+    const uint32_t c0 = (uint32_t)_pext_u64(__builtin_bswap64(l[0]), 0x0303030303030303ULL);
+    const uint32_t c1 = (uint32_t)_pext_u64(__builtin_bswap64(l[1]), 0x0303030303030303ULL);
+    const uint32_t c2 = (uint32_t)_pext_u64(__builtin_bswap64(l[2]), 0x0303030303030303ULL);
+    const uint32_t c3 = (uint32_t)_pext_u64(__builtin_bswap64(l[3]), 0x0303030303030303ULL);
+    code[i / 16] = (c0 << 16) | c1;
+    code[i / 16 + 1] = (c2 << 16) | c3;
+    const uint32_t r = __builtin_bitreverse32(bad);  // byte 0 -> bit 31
+    inv[i / 16] = (uint16_t)(r >> 16);
+    inv[i / 16 + 1] = (uint16_t)r;
+  }
+}
+#endif
+
+// n is a multiple of 32
+static void pack_block(const uint8_t *src, size_t n, uint32_t *code, uint16_t *inv)
+{
+#if defined(__x86_64__)
+  static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("MCX_NO_AVX2");
+  if (fast) { pack_block_avx2(src, n, code, inv); return; }
+#endif
+  for (size_t i = 0; i < n; i += 16) pack16_swar(src + i, code + i / 16, inv + i / 16);
+}
+
+extern "C" void mcx_pack_bases(const uint8_t *src, uint64_t n, uint32_t *code, uint16_t *inv)
+{ /* test hook: n multiple of 32 */
+  pack_block(src, (size_t)n, code, inv);
+}
+
+// threads that pack / copy reads into the pinned staging buffer (MCX_STAGE_THREADS, default: half the cores, at most 16)
 static int stage_threads()
 {
   static const int n = [] {
     const char *e = getenv("MCX_STAGE_THREADS");
-    const int v = e ? atoi(e) : 4;
-    return v < 1 ? 1 : v > 32 ? 32 : v;
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int v = e ? atoi(e) : std::max(1, std::min(16, hw / 2));
+    return v < 1 ? 1 : v > 64 ? 64 : v;
   }();
   return n;
 }
@@ -1030,6 +1125,135 @@ static int add_reads_qh(mcx_graph *g, int colour, const uint8_t *bases, const ui
                         const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp);
 static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
                                 const uint64_t *off, uint64_t nreads, uint8_t fq, uint8_t hp);
+
+// Host reads -> packed stream chunks in pinned memory -> HBM -> the front end.  A chunk is the same
+// virtual stream the ASCII path stages (128 positions of carry from the previous chunk, then whole
+// reads each followed by one separator, or a piece of a read longer than a chunk), padded with
+// separators to a multiple of 64 positions, but it travels as 3 bits per position (pack_block).
+// The staging threads each assemble and pack blocks of 64-aligned positions; nothing else touches
+// the bases on the host.
+static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, const uint64_t *off, uint64_t nreads,
+                            unsigned char *d_flags)
+{
+  const uint64_t off_region = kCarry + kStageBytes + 256;  // byte offset of the staged offsets (8-aligned), as in the ASCII layout
+  const uint64_t max_offs = kStageBytes / 16;
+  const uint64_t cap_pos = kCarry + kStageBytes + 64;       // positions a chunk may hold
+  const uint64_t inv_at = ((cap_pos / 16 * 4) + 63) & ~63ull;  // byte offset of the invalid flags inside a staging buffer
+  uint32_t carry_code[kCarry / 16];
+  uint16_t carry_inv[kCarry / 16];
+  for (uint64_t i = 0; i < kCarry / 16; i++) { carry_code[i] = 0; carry_inv[i] = 0xFFFF; }
+  uint64_t r = 0, r_pos = 0;  // next read, bytes of it already staged
+  while (r < nreads) {
+    const int b = g->cur;
+    g->cur ^= 1;
+    HIP_TRY(hipEventSynchronize(g->ev[b]));  // previous use of this buffer finished
+    uint8_t *hs = g->h_stage[b];
+    uint32_t *hcode = reinterpret_cast<uint32_t *>(hs);
+    uint16_t *hinv = reinterpret_cast<uint16_t *>(hs + inv_at);
+    uint64_t *hoff = reinterpret_cast<uint64_t *>(hs + off_region);
+    const uint64_t r0 = r;
+    uint64_t nwhole = 0, L = 0;  // reads wholly in this chunk, positions after the carry
+    long long piece_of = -1;
+    uint64_t piece_from = 0, piece_data = 0;  // a piece: where its bases start in `bases`, how many there are
+    {  // whole reads that fit: read i lands at position kCarry + (off[r0 + i] - off[r0]) + i (each is
+       // followed by one separator), which grows with i: the count is found by bisection, not by a walk
+      if (r_pos == 0) {
+        uint64_t lo = 0, hi = std::min<uint64_t>(nreads - r0, max_offs);  // largest n with n reads taking <= kStageBytes positions
+        auto need = [&](uint64_t n) { return off[r0 + n] - off[r0] + n; };
+        if (need(hi) <= kStageBytes) lo = hi;
+        else while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (need(mid) <= kStageBytes) lo = mid; else hi = mid; }
+        nwhole = lo;
+        L = need(nwhole);
+      }
+      r += nwhole;
+      if (nwhole == 0) {  // a read longer than a chunk (or its tail): a piece of it on its own
+        const uint64_t len = off[r + 1] - off[r], remain = len - r_pos;
+        uint64_t take = std::min(remain, kStageBytes - 64);
+        if (take < remain) take &= ~63ull;  // pieces end on a 64-position boundary: no padding inside a read
+        piece_of = (long long)r;
+        piece_from = off[r] + r_pos;
+        piece_data = take;
+        L = take;
+        r_pos += take;
+        if (r_pos == len) { L += 1; r++; r_pos = 0; }  // its separator
+      }
+    }
+    auto start_of = [&](uint64_t i) { return kCarry + (off[r0 + i] - off[r0]) + i; };  // first position of whole read i
+    hoff[nwhole] = kCarry + L;
+    const uint64_t Lp = (L + 63) & ~63ull, total = kCarry + Lp;
+    memcpy(hcode, carry_code, sizeof(carry_code));
+    memcpy(hinv, carry_inv, sizeof(carry_inv));
+    // position p of the chunk (p >= kCarry): base of a read, or a separator
+    const int T = stage_threads();
+    auto work = [&](int ti) {
+      constexpr uint64_t BLK = 16384;
+      uint8_t buf[BLK];
+      const uint64_t nblk = (Lp + BLK - 1) / BLK;
+      const uint64_t b_lo = nblk * (uint64_t)ti / (uint64_t)T, b_hi = nblk * (uint64_t)(ti + 1) / (uint64_t)T;
+      // the staged offsets of this thread's share of the reads (k_read_flags_packed reads them)
+      for (uint64_t q = nwhole * (uint64_t)ti / (uint64_t)T, qe = nwhole * (uint64_t)(ti + 1) / (uint64_t)T; q < qe; q++) hoff[q] = start_of(q);
+      // first read that reaches into the thread's range of positions
+      uint64_t i = 0;
+      if (piece_of < 0 && b_lo < b_hi && nwhole) {
+        const uint64_t p0 = kCarry + b_lo * BLK;
+        uint64_t lo = 0, hi = nwhole;  // last read that starts at or before p0
+        while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (start_of(mid) <= p0) lo = mid; else hi = mid; }
+        i = lo;
+      }
+      for (uint64_t bk = b_lo; bk < b_hi; bk++) {
+        const uint64_t p0 = kCarry + bk * BLK, n = std::min(BLK, kCarry + Lp - p0);
+        if (piece_of >= 0) {
+          const uint64_t at = p0 - kCarry, data = at < piece_data ? std::min(n, piece_data - at) : 0;
+          memcpy(buf, bases + piece_from + at, data);
+          memset(buf + data, '\n', n - data);  // the read's separator (if it ends here) and the padding
+        } else {
+          uint64_t p = p0;
+          while (p < p0 + n) {
+            if (i >= nwhole) { memset(buf + (p - p0), '\n', p0 + n - p); break; }
+            const uint64_t s_ = start_of(i), len = off[r0 + i + 1] - off[r0 + i];
+            if (p < s_ + len) {
+              const uint64_t cnt = std::min(s_ + len - p, p0 + n - p);
+              memcpy(buf + (p - p0), bases + off[r0 + i] + (p - s_), cnt);
+              p += cnt;
+            } else {  // the read's separator, then the next read
+              buf[p - p0] = '\n';
+              p++;
+              i++;
+            }
+          }
+        }
+        pack_block(buf, (size_t)n, hcode + p0 / 16, hinv + p0 / 16);
+      }
+    };
+    if (T > 1 && Lp >= (1u << 20)) {
+      std::vector<std::thread> th;
+      for (int ti = 1; ti < T; ti++) th.emplace_back(work, ti);
+      work(0);
+      for (auto &x : th) x.join();
+    } else {
+      for (int ti = 0; ti < T; ti++) work(ti);  // small chunk: every share on this thread
+    }
+    memcpy(carry_code, hcode + total / 16 - kCarry / 16, sizeof(carry_code));
+    memcpy(carry_inv, hinv + total / 16 - kCarry / 16, sizeof(carry_inv));
+    uint8_t *ds = g->d_stage[b];
+    HIP_TRY(hipMemcpyAsync(ds, hcode, total / 16 * 4, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(ds + inv_at, hinv, total / 16 * 2, hipMemcpyHostToDevice, g->stream));
+    if (nwhole)
+      HIP_TRY(hipMemcpyAsync(ds + off_region, hoff, (nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
+    StreamLaunch SL{nullptr, total, kCarry - (uint64_t)g->k, total - (uint64_t)g->k, piece_of >= 0 ? d_flags + piece_of : nullptr,
+                    reinterpret_cast<const uint32_t *>(ds), reinterpret_cast<const uint16_t *>(ds + inv_at)};
+    int rc = submit_stream(g, SL, colour);
+    if (rc != MCX_OK) return rc;
+    HIP_TRY(hipSetDevice(g->device));
+    if (nwhole) {
+      hipLaunchKernelGGL(k_read_flags_packed, dim3((unsigned)((nwhole + 255) / 256)), dim3(256), 0, g->stream,
+                         reinterpret_cast<const uint16_t *>(ds + inv_at), (const uint64_t *)(ds + off_region), nwhole, g->k, d_flags + r0);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(g->ev[b], g->stream));
+  }
+  return MCX_OK;
+}
 
 extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *bases, const uint8_t *quals,
                                    const uint64_t *off, uint64_t nreads, uint8_t fq_cutoff_abs,
@@ -1060,6 +1284,16 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
   unsigned char *d_flags = nullptr;
   HIP_TRY(hipMallocAsync((void **)&d_flags, nreads, g->stream));
   HIP_TRY(hipMemsetAsync(d_flags, 0, nreads, g->stream));
+
+  static const bool packed = [] { const char *e = getenv("MCX_PACKED"); return !e || atoi(e) != 0; }();
+  if (packed) {
+    rc = add_reads_packed(g, colour, bases, off, nreads, d_flags);
+    if (rc != MCX_OK) return rc;
+    hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, g->stream, (const unsigned char *)d_flags, nreads, g->d_ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(d_flags, g->stream));
+    return MCX_OK;
+  }
 
   const uint64_t off_region = kCarry + kStageBytes + 256;  // byte offset of the staged offsets (8-aligned)
   const uint64_t max_offs = kStageBytes / 16;

@@ -260,7 +260,7 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
 //    other shards take the direct insert), SH 2 of every shard (BIN_GLOBAL, exchange blocks).
 //    The variants are compiled apart: code of the rare paths costs the common one registers.
 // ---------------------------------------------------------------------------
-template <int W, bool ONECOL, int NB, bool FULL, int SH>
+template <int W, bool ONECOL, int NB, bool FULL, int SH, bool PK>
 __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
                                                                          InsertSink<W, ONECOL> isink)
 {
@@ -278,37 +278,20 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
   const uint32_t ob0 = (blockIdx.x % bs.rep) * bs.nout;
 
   // the chunks of the NEXT tile are fetched into registers while the current one is processed
-  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+  TileSrc pre;
+  pre.a = make_uint4(0, 0, 0, 0); pre.b = make_uint4(0, 0, 0, 0);
   {
     const uint64_t t0 = a.tile0 + blockIdx.x;
-    if (t0 < a.ntiles) {
-      const int64_t r0 = (int64_t)(t0 * kTile) - 16;
-      pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
-      if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
-    }
+    if (t0 < a.ntiles) tile_fetch<PK>(a, t0, tid, pre);
   }
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
-    {
-      uint32_t code, inv;
-      encode_words(pre0, code, inv);
-      s_code[tid] = code;
-      reinterpret_cast<uint16_t *>(s_inv)[tid ^ 1] = (uint16_t)inv;
-      if (tid < kChunks - kThreads) {
-        encode_words(pre1, code, inv);
-        s_code[tid + kThreads] = code;
-        reinterpret_cast<uint16_t *>(s_inv)[(tid + kThreads) ^ 1] = (uint16_t)inv;
-      }
-    }
+    tile_stage<PK>(a, pre, tid, s_code, s_inv);
     for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     {
       const uint64_t tn = tile + gridDim.x;
-      if (tn < a.ntiles) {
-        const int64_t r0 = (int64_t)(tn * kTile) - 16;
-        pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
-        if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
-      }
+      if (tn < a.ntiles) tile_fetch<PK>(a, tn, tid, pre);
     }
     __syncthreads();
 

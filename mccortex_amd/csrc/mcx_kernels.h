@@ -506,8 +506,14 @@ constexpr int kChunks = 272;                   // 16-byte chunks staged per tile
 constexpr int kBatch = MCX_BATCH;              // probes in flight per lane (must divide 16)
 
 struct StreamArgs {
-  const uint8_t *stream;
-  uint64_t nbytes;          // bytes of context available (outside = separator)
+  const uint8_t *stream;    // ASCII stream, or nullptr when the packed form below is given
+  // Packed form of the same stream (what the host entry stages: 3 bits per position instead of 8
+  // over PCIe, and no SWAR encode in the tile prologue): per 16 positions one code word (2 bits
+  // per base, first base on top) and 16 invalid flags (first base = bit 15) -- exactly what
+  // encode_words() makes of 16 ASCII bytes.  Positions >= nbytes carry the invalid flag.
+  const uint32_t *code;
+  const uint16_t *inv;
+  uint64_t nbytes;          // positions of context available (outside = separator)
   uint64_t pos_lo, pos_hi;  // k-mer start positions owned by this launch
   uint64_t tile0, ntiles;   // tiles [tile0, ntiles) cover [pos_lo, pos_hi)
   int k;
@@ -573,6 +579,45 @@ __device__ __forceinline__ void encode_chunk(const uint8_t *stream, uint64_t nby
   encode_words(load_chunk(stream, nbytes, g), code, inv);
 }
 
+// The 272 chunks of a tile in flight: two per thread (the second one only for the first 16 threads).
+// ASCII: the 16 bytes themselves; packed: x = code word, y = invalid flags.
+// PK (compile time): the launch reads the packed form (the ASCII kernels are not to pay registers for it).
+struct TileSrc { uint4 a, b; };
+template <bool PK> __device__ __forceinline__ void tile_fetch(const StreamArgs &a, uint64_t tile, int tid, TileSrc &t)
+{
+  if (PK) {
+    const int64_t c0 = (int64_t)(tile * (kTile / 16)) - 1;  // chunk 0 of the tile's region = the halo
+    const int64_t nch = (int64_t)((a.nbytes + 15) / 16);
+    const int64_t c = c0 + tid, c2 = c + kThreads;
+    const bool in = c >= 0 && c < nch;
+    t.a.x = in ? a.code[c] : 0u;
+    t.a.y = in ? (uint32_t)a.inv[c] : 0xFFFFu;
+    if (tid < kChunks - kThreads) {
+      const bool in2 = c2 >= 0 && c2 < nch;
+      t.b.x = in2 ? a.code[c2] : 0u;
+      t.b.y = in2 ? (uint32_t)a.inv[c2] : 0xFFFFu;
+    }
+  } else {
+    const int64_t r0 = (int64_t)(tile * kTile) - 16;
+    t.a = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
+    if (tid < kChunks - kThreads) t.b = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
+  }
+}
+// ... -> the tile's code words and invalid flags in LDS
+template <bool PK> __device__ __forceinline__ void tile_stage(const StreamArgs &a, const TileSrc &t, int tid, uint32_t *s_code, uint32_t *s_inv)
+{
+  uint32_t code, inv;
+  (void)a;
+  if (PK) { code = t.a.x; inv = t.a.y; } else encode_words(t.a, code, inv);
+  s_code[tid] = code;
+  reinterpret_cast<uint16_t *>(s_inv)[tid ^ 1] = (uint16_t)inv;
+  if (tid < kChunks - kThreads) {
+    if (PK) { code = t.b.x; inv = t.b.y; } else encode_words(t.b, code, inv);
+    s_code[tid + kThreads] = code;
+    reinterpret_cast<uint16_t *>(s_inv)[(tid + kThreads) ^ 1] = (uint16_t)inv;
+  }
+}
+
 // One k-mer occurrence produced by the front end
 template <int W> struct Occ {
   Kmer<W> key;
@@ -610,7 +655,7 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t h2, uint32_t nparts)
 
 // Fused build kernel: k-merise a stream tile by tile and insert straight into the table
 // (direct path; the deferred path of mcx_defer.h shares the front end helpers).
-template <int W, bool ONECOL>
+template <int W, bool ONECOL, bool PK>
 __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink)
 {
   __shared__ uint32_t s_code[kChunks + 4];
@@ -625,12 +670,10 @@ __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a
 
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
-    const int64_t region0 = (int64_t)(tile * kTile) - 16;
-    for (int c = tid; c < kChunks; c += kThreads) {
-      uint32_t code, inv;
-      encode_chunk(a.stream, a.nbytes, region0 + 16 * (int64_t)c, code, inv);
-      s_code[c] = code;
-      reinterpret_cast<uint16_t *>(s_inv)[c ^ 1] = (uint16_t)inv;
+    {
+      TileSrc ts;
+      tile_fetch<PK>(a, tile, tid, ts);
+      tile_stage<PK>(a, ts, tid, s_code, s_inv);
     }
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     __syncthreads();
@@ -760,6 +803,21 @@ __global__ void k_read_flags(const uint8_t *stream, const uint64_t *stream_off, 
   bool ok = false;
   for (uint64_t p = b; p < e && !ok; p++) {
     run = base_valid(stream[p]) ? run + 1 : 0;
+    ok = run >= k;
+  }
+  flags[i] = ok ? 1 : 0;
+}
+
+// the same on the packed form of the stream: invalid flag of position p = bit 15 - (p & 15) of inv[p >> 4]
+__global__ void k_read_flags_packed(const uint16_t *inv, const uint64_t *stream_off, uint64_t nreads, int k, unsigned char *flags)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  const uint64_t b = stream_off[i], e = stream_off[i + 1] - 1;
+  int run = 0;
+  bool ok = false;
+  for (uint64_t p = b; p < e && !ok; p++) {
+    run = ((inv[p >> 4] >> (15 - (p & 15))) & 1) ? 0 : run + 1;
     ok = run >= k;
   }
   flags[i] = ok ? 1 : 0;

@@ -30,6 +30,8 @@ int main(int argc, char **argv)
 {
   struct timeval t0, t1;
   gettimeofday(&t0, NULL);
+  const int timing = getenv("MCX_TIMING") != NULL; /* wall-clock stamps of main()'s entry and exit, for end-to-end breakdowns */
+  if (timing) fprintf(stderr, "[timing] epoch_main_entry %ld.%06ld\n", (long)t0.tv_sec, (long)t0.tv_usec);
   msg_out = stderr;
   host_set_cmdline(argc, argv);
   if (argc == 1) { fputs(usage, stderr); return EXIT_FAILURE; }
@@ -55,6 +57,7 @@ int main(int argc, char **argv)
   int rc = func(argc - 1, argv + 1);
   gettimeofday(&t1, NULL);
   double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_usec - t0.tv_usec);
+  if (timing) fprintf(stderr, "[timing] epoch_main_exit %ld.%06ld\n", (long)t1.tv_sec, (long)t1.tv_usec);
   if (rc == 0) status("[time] %.2f seconds", secs);
   status(rc == 0 ? "  Done." : "  Fail.");
   return rc;

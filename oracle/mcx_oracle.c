@@ -9,8 +9,10 @@
  * compiled from where it lies (oracle/_ref), and the KATs recorded in
  * SURVEY.md 8(c) -- see oracle/README.md.
  */
+#define _GNU_SOURCE
 #include "mcx_oracle.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
@@ -255,6 +257,7 @@ struct orc_graph {
   uint64_t *total_sequence;
   char (*sample)[256];
   volatile int full;
+  int tuned;            /* orc_graph_tune: prefaulted arrays, per-worker node tallies (timed baseline only) */
   int force_generic; /* tests: run the multi-word code even when W == 1 */
   /* build --intersect (ctx_build.c:341-363,384-413) */
   uint8_t *isec_edges;  /* [capacity]: union of the intersection graphs' edges, NULL when not intersecting */
@@ -303,6 +306,16 @@ void orc_graph_force_generic(orc_graph *g, int on) { g->force_generic = on; }
 uint64_t orc_graph_nkmers(const orc_graph *g) { return g->num_kmers; }
 uint64_t orc_graph_capacity(const orc_graph *g) { return g->capacity; }
 
+/* num_kmers: the reference adds to ONE shared counter from every worker (hash_table.c:113, an
+ * atomic add per new node).  The timed baseline (orc_graph_tune) tallies per worker and merges at
+ * the end of the batch instead, so that the port is not slowed by a cache line all threads write. */
+static __thread uint64_t *tl_new_nodes = NULL;
+static inline void count_new_node(orc_graph *g)
+{
+  if(tl_new_nodes) (*tl_new_nodes)++;
+  else __sync_add_and_fetch(&g->num_kmers, 1);
+}
+
 static inline void bkt_lock(volatile uint8_t *l)
 { /* bitlock_yield_acquire: hash_table.c:260 */
   while(__sync_lock_test_and_set(l, 1)) sched_yield();
@@ -336,7 +349,7 @@ static uint64_t find_or_insert(orc_graph *g, const orc_bkmer *key, int *found)
       slot[0] = key->b[0] | ORC_FLAG;
       for(w = 1; w < W; w++) slot[w] = key->b[w];
       g->bsize[h] = (uint8_t)(n + 1);
-      __sync_add_and_fetch(&g->num_kmers, 1);
+      count_new_node(g);
       *found = 0;
       bkt_unlock(&g->locks[h]);
       return h * g->bucket_size + n;
@@ -435,7 +448,7 @@ static inline uint64_t find_or_insert_w1(orc_graph *g, uint64_t key, int *found)
     if(n < g->bucket_size) {
       slot[n] = want;
       g->bsize[h] = (uint8_t)(n + 1);
-      __sync_add_and_fetch(&g->num_kmers, 1);
+      count_new_node(g);
       *found = 0;
       bkt_unlock(&g->locks[h]);
       return h * g->bucket_size + n;
@@ -534,17 +547,20 @@ static void load_read(orc_graph *g, int colour, const char *seq, size_t len, con
 typedef struct {
   orc_graph *g; int colour; const char *bases, *quals; const uint64_t *off;
   uint64_t lo, hi; uint8_t fq, hp; orc_stats st;
+  uint64_t new_nodes; /* tuned mode: this worker's share of num_kmers */
 } orc_job;
 
 static void *job_run(void *p)
 {
   orc_job *j = p;
   uint64_t r;
+  if(j->g->tuned) tl_new_nodes = &j->new_nodes;
   for(r = j->lo; r < j->hi && !j->g->full; r++) {
     size_t len = (size_t)(j->off[r + 1] - j->off[r]);
     load_read(j->g, j->colour, j->bases + j->off[r], len, j->quals ? j->quals + j->off[r] : NULL,
               j->fq, j->hp, &j->st);
   }
+  tl_new_nodes = NULL;
   return NULL;
 }
 
@@ -579,8 +595,148 @@ int orc_graph_add_reads(orc_graph *g, int colour, const char *bases, const char 
     for(t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
   }
   if(stats_accum) for(t = 0; t < nthreads; t++) stats_merge(stats_accum, &jobs[t].st);
+  for(t = 0; t < nthreads; t++) g->num_kmers += jobs[t].new_nodes;
   free(jobs); free(th);
   return g->full ? -1 : 0;
+}
+
+/* ---- the timed CPU baseline (bench.py's cpu_baseline leg) ---------------------------------------
+ * orc_graph_tune: what a careful user of the reference would do before timing it, without touching
+ * the algorithm: the table and node arrays are touched once up front, by `nthreads` threads in
+ * interleaved slices (so that the first-touch page faults -- which serialise on the process's
+ * mmap lock and made 4 threads slower than 1 on the 256-CPU host -- and the NUMA placement are out
+ * of the timed region), transparent huge pages are requested for them, and new nodes are counted
+ * per worker (see count_new_node). */
+#include <sys/mman.h>
+typedef struct { uint8_t *p; size_t n; int t, nt; } touch_job;
+static void *touch_run(void *a)
+{
+  touch_job *j = a;
+  const size_t slice = 2u << 20;
+  size_t o;
+  for(o = (size_t)j->t * slice; o < j->n; o += (size_t)j->nt * slice)
+    memset(j->p + o, 0, j->n - o < slice ? j->n - o : slice);
+  return NULL;
+}
+static void touch_array(void *p, size_t n, int nthreads)
+{
+  if(!p || !n) return;
+#ifdef MADV_HUGEPAGE
+  { uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095; if(a < (uintptr_t)p + n) madvise((void *)a, (uintptr_t)p + n - a, MADV_HUGEPAGE); }
+#endif
+  pthread_t th[256];
+  touch_job jb[256];
+  int t;
+  if(nthreads > 256) nthreads = 256;
+  for(t = 0; t < nthreads; t++) { jb[t] = (touch_job){p, n, t, nthreads}; pthread_create(&th[t], NULL, touch_run, &jb[t]); }
+  for(t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}
+void orc_graph_tune(orc_graph *g, int nthreads)
+{ /* only on an empty graph: the arrays are zeroed again */
+  if(g->num_kmers) return;
+  if(nthreads < 1) nthreads = 1;
+  g->tuned = 1;
+  touch_array(g->table, g->capacity * (size_t)g->W * 8, nthreads);
+  touch_array(g->bsize, g->nbuckets, nthreads);
+  touch_array((void *)g->locks, g->nbuckets, nthreads);
+  touch_array(g->covgs, g->capacity * (size_t)g->ncols * 4, nthreads);
+  touch_array(g->edges, g->capacity * (size_t)g->ncols, nthreads);
+}
+
+/* Reference-shaped end-to-end build of ONE 4-line FASTQ / one-line FASTA file into colour 0: one
+ * reader thread parses the file into a pool of read slots (asyncio_run_pool + async_io_reader,
+ * src/basic/async_read_io.c:145-175,283-310: one reader per file, a 2048-slot message pool) and
+ * `nthreads` workers take reads from it and load them (add_reads_to_graph, build_graph.c:233-254).
+ * Returns the seconds spent (*insert_s: until the workers are done); the sorted .ctx is left in the
+ * graph for orc_graph_write_ctx.  Test infrastructure: the baseline of bench.py's e2e figure. */
+#include <time.h>
+#define POOL_SLOTS 2048
+typedef struct { char *seq; size_t len, cap; } pool_read;
+typedef struct {
+  orc_graph *g;
+  pool_read slot[POOL_SLOTS];
+  size_t head, tail;  /* ring: [tail, head) filled */
+  int done;
+  pthread_mutex_t mu;
+  pthread_cond_t not_empty, not_full;
+  orc_stats st;
+} read_pool;
+typedef struct { read_pool *pool; orc_stats st; uint64_t new_nodes; } pool_worker;
+
+static void *pool_worker_run(void *a)
+{
+  pool_worker *w = a;
+  read_pool *P = w->pool;
+  pool_read mine = {NULL, 0, 0};
+  if(P->g->tuned) tl_new_nodes = &w->new_nodes;
+  for(;;) {
+    pthread_mutex_lock(&P->mu);
+    while(P->head == P->tail && !P->done) pthread_cond_wait(&P->not_empty, &P->mu);
+    if(P->head == P->tail) { pthread_mutex_unlock(&P->mu); break; }
+    pool_read *r = &P->slot[P->tail % POOL_SLOTS];
+    pool_read tmp = *r; *r = mine; mine = tmp;  /* swap buffers: the slot is free again at once */
+    P->tail++;
+    pthread_cond_signal(&P->not_full);
+    pthread_mutex_unlock(&P->mu);
+    load_read(P->g, 0, mine.seq, mine.len, NULL, 0, 0, &w->st);
+  }
+  free(mine.seq);
+  tl_new_nodes = NULL;
+  return NULL;
+}
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+
+double orc_build_file(orc_graph *g, const char *path, int nthreads, double *insert_s, orc_stats *stats_accum)
+{
+  FILE *f = fopen(path, "r");
+  if(!f) return -1.0;
+  if(nthreads < 1) nthreads = 1;
+  read_pool *P = calloc(1, sizeof(*P));
+  P->g = g;
+  pthread_mutex_init(&P->mu, NULL);
+  pthread_cond_init(&P->not_empty, NULL);
+  pthread_cond_init(&P->not_full, NULL);
+  pthread_t *th = calloc((size_t)nthreads, sizeof(*th));
+  pool_worker *w = calloc((size_t)nthreads, sizeof(*w));
+  const double t0 = now_s();
+  int t;
+  for(t = 0; t < nthreads; t++) { w[t].pool = P; pthread_create(&th[t], NULL, pool_worker_run, &w[t]); }
+  /* the reader (this thread): header line, sequence line [, '+' line, quality line] */
+  char *line = NULL;
+  size_t cap = 0;
+  ssize_t n;
+  int fastq = -1;
+  while((n = getline(&line, &cap, f)) > 0) {
+    if(fastq < 0) fastq = line[0] == '@';
+    if((n = getline(&line, &cap, f)) <= 0) break;
+    while(n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) n--;
+    pthread_mutex_lock(&P->mu);
+    while(P->head - P->tail == POOL_SLOTS) pthread_cond_wait(&P->not_full, &P->mu);
+    pool_read *r = &P->slot[P->head % POOL_SLOTS];
+    if(r->cap < (size_t)n + 1) { r->cap = (size_t)n + 64; r->seq = realloc(r->seq, r->cap); }
+    memcpy(r->seq, line, (size_t)n);
+    r->len = (size_t)n;
+    P->head++;
+    pthread_cond_signal(&P->not_empty);
+    pthread_mutex_unlock(&P->mu);
+    if(fastq) { if(getline(&line, &cap, f) <= 0 || getline(&line, &cap, f) <= 0) break; }
+  }
+  free(line);
+  fclose(f);
+  pthread_mutex_lock(&P->mu);
+  P->done = 1;
+  pthread_cond_broadcast(&P->not_empty);
+  pthread_mutex_unlock(&P->mu);
+  for(t = 0; t < nthreads; t++) {
+    pthread_join(th[t], NULL);
+    if(stats_accum) stats_merge(stats_accum, &w[t].st);
+    g->num_kmers += w[t].new_nodes;
+  }
+  if(insert_s) *insert_s = now_s() - t0;
+  for(t = 0; t < POOL_SLOTS; t++) free(P->slot[t].seq);
+  free(th); free(w); free(P);
+  return now_s() - t0;
 }
 
 /* ---- build --remove-pcr -------------------------------------------------- */

@@ -88,6 +88,9 @@ int orc_graph_add_record(orc_graph *g, const uint64_t *key_words, const uint32_t
 void orc_graph_set_must_exist(orc_graph *g, int on);
 int  orc_graph_add_isec_record(orc_graph *g, const uint64_t *key_words, uint32_t covg_sum, uint8_t edges_or);
 void orc_graph_isec_finish(orc_graph *g);
+/* timed-baseline helpers (bench.py's cpu_baseline leg): see mcx_oracle.c */
+void orc_graph_tune(orc_graph *g, int nthreads);
+double orc_build_file(orc_graph *g, const char *path, int nthreads, double *insert_s, orc_stats *stats_accum);
 size_t orc_graph_ctx_size(const orc_graph *g);
 size_t orc_graph_write_ctx(const orc_graph *g, int sorted, uint8_t *out);
 size_t orc_graph_header_size(const orc_graph *g);

@@ -78,6 +78,10 @@ def lib():
     L.orc_graph_add_reads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_uint8, C.c_uint8, C.c_int, C.POINTER(Stats)]
     L.orc_graph_update_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(Stats)]
+    L.orc_graph_tune.argtypes = [C.c_void_p, C.c_int]
+    L.orc_graph_tune.restype = None
+    L.orc_build_file.restype = C.c_double
+    L.orc_build_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(Stats)]
     L.orc_graph_ctx_size.restype = C.c_size_t
     L.orc_graph_ctx_size.argtypes = [C.c_void_p]
     L.orc_graph_header_size.restype = C.c_size_t
@@ -145,6 +149,18 @@ class Graph:
         if getattr(self, "h", None):
             self.L.orc_graph_free(self.h)
             self.h = None
+
+    def tune(self, nthreads):
+        """timed baseline only: prefault the arrays with `nthreads` threads, huge pages, per-worker node tallies"""
+        self.L.orc_graph_tune(self.h, nthreads)
+
+    def build_file(self, path, nthreads):
+        """reference-shaped build of one FASTQ / FASTA file (1 reader thread + nthreads workers) -> (total s, insert s, stats)"""
+        st, ins = Stats(), C.c_double(0)
+        tot = self.L.orc_build_file(self.h, path.encode(), nthreads, C.byref(ins), C.byref(st))
+        if tot < 0:
+            raise RuntimeError("cannot open %s" % path)
+        return tot, ins.value, st
 
     def force_generic(self, on=True):
         self.L.orc_graph_force_generic(self.h, 1 if on else 0)

@@ -82,7 +82,10 @@ for passname, counter, scale in (("pmc_fetch", "FETCH_SIZE", 2 * 1024.0), ("pmc_
         t = traffic.setdefault(name, {"launches": n, "occurrences": rec["config"]["kmers_inserted"]})
         t["read_bytes" if counter == "FETCH_SIZE" else "written_bytes"] = sum(vals[-n:])  # the timed region's launches
 if traffic:
+    sys.path.insert(0, os.getcwd())
+    import bench
     meta = {"command": "python bench.py " + " ".join(sys.argv[2:]),
+            "csrc_digest": bench.csrc_digest(),  # bench.py refuses the figure once the kernel sources change
             "note": "launches of the timed region only; read = 2 * FETCH_SIZE * 1024, written = WRITE_SIZE * 1024 (separate --pmc passes)",
             "kernels": traffic}
     json.dump(meta, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)

@@ -10,7 +10,7 @@ for so in "" build/variants/lib_*.so; do
     keep=0; for o in $ONLY; do [ "$so" = "build/variants/lib_$o.so" ] && keep=1; done
     [ $keep = 1 ] || continue
   fi
-  MCX_LIB=${so:+$PWD/$so} timeout 600 python bench.py --steps ${STEPS:-10} --warmup 1 --no-cpu-baseline "$@" 2>gpurun_out/sweep_last.err | tail -1 | \
+  MCX_LIB=${so:+$PWD/$so} timeout 600 python bench.py --steps ${STEPS:-10} --warmup 1 --no-cpu-baseline --no-extras "$@" 2>gpurun_out/sweep_last.err | tail -1 | \
     python -c "
 import sys,json
 try:
