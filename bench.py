@@ -181,6 +181,21 @@ def cpu_baseline(stream_dev, fastq_sample=None):
     return out
 
 
+def pack_batches(mcx, batches):
+    """device-resident ASCII streams -> their packed form (code words, invalid flags), outside any clock"""
+    import torch
+    out = []
+    for b in batches:
+        n = b.numel()
+        nch = (n + 15) // 16
+        code = torch.empty(nch, dtype=torch.int32, device=b.device)
+        inv = torch.empty(nch, dtype=torch.int16, device=b.device)
+        mcx.pack_stream_dev(b, n, code, inv)
+        out.append((code, inv, n))
+    torch.cuda.synchronize()
+    return out
+
+
 def kernel_table(prof, kmers, W=1, bases_per_kmer=1.25):
     """{kernel: launches / ms / achieved GB/s / frac of HBM peak} from the library's HIP-event spans;
     algorithmic bytes per occurrence of every kernel as in DESIGN.md section 4"""
@@ -196,8 +211,8 @@ def kernel_table(prof, kmers, W=1, bases_per_kmer=1.25):
     return out
 
 
-def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples):
-    """one device-resident build of `batches` (fresh graph) -> record"""
+def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packed=None):
+    """one device-resident build of `batches` (fresh graph; `packed`: their packed form) -> record"""
     import torch
     g = mcx.Graph(k, ncols, table_slots)
     if defer_tuples:
@@ -207,8 +222,12 @@ def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples):
     g.configure("profile", 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for c, b in zip(colours, batches):
-        g.add_stream_dev(c, b, b.numel())
+    if packed is not None:
+        for c, (code, inv, n) in zip(colours, packed):
+            g.add_packed_dev(c, code, inv, n)
+    else:
+        for c, b in zip(colours, batches):
+            g.add_stream_dev(c, b, b.numel())
     g.sync()
     dt = time.perf_counter() - t0
     st = g.device_stats()
@@ -216,14 +235,14 @@ def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples):
     g.close()
     torch.cuda.empty_cache()
     W = (2 * k + 63) // 64
-    kt = kernel_table(prof, st.num_kmers_loaded, W, READ_LEN / (READ_LEN - k + 1.0))
+    kt = kernel_table(prof, st.num_kmers_loaded, W, (0.375 if packed is not None else 1.0) * (READ_LEN + 1) / (READ_LEN - k + 1.0))
     dom = max(kt, key=lambda n: kt[n]["total_ms"])
     return {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(batches), "steps": len(batches),
             "kmers_inserted": int(st.num_kmers_loaded), "distinct_kmers": int(st.num_kmers_novel),
             "dominant_kernel": dom, "dominant_frac": kt[dom]["frac"], "kernels": kt}
 
 
-def extras(mcx, batches, nsteps, table_slots):
+def extras(mcx, batches, packed, nsteps, table_slots):
     """host-fed, end-to-end, default flush size and the other BASELINE configs (rank 0, N = 1)"""
     import subprocess
     import tempfile
@@ -231,16 +250,21 @@ def extras(mcx, batches, nsteps, table_slots):
     out = {}
     B = batches[0].numel() // (READ_LEN + 1)
     steps = batches[:nsteps]
-    # (d) the library's own flush size (min(4 x slots, 2^31) occurrences) instead of the bench's
-    r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, 0)
+    pk = packed[:nsteps] if packed is not None else None
+    # (d) the library's own flush size (64 occurrences per slot within 30 % of the free HBM) instead of the bench's
+    r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, 0, pk)
     r["what"] = "as `value`, but with the library's default flush size instead of %d occurrences" % DEFER_TUPLES
     out["default_defer"] = r
+    if pk is not None:  # the same build from the ASCII form of the stream (what `value` was in round 1)
+        r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, DEFER_TUPLES, None)
+        r["what"] = "as `value`, but the resident stream is ASCII (1 byte per position; the kernel encodes it in its tile prologue)"
+        out["ascii_resident"] = r
     # (e) C4: k = 63 (two-word keys); C5-like: 4 colours on one GPU
-    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, 5_000_000_000)
+    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, 5_000_000_000, pk)
     r["workload"] = "C4: k=63 (2-word BinaryKmer), 1 colour, %d reads x %d bp per step, table %d slots, 1 GPU" % (B, READ_LEN, table_slots)
     out["other_configs"] = {"C4_k63": r}
     cols = [min(3, 4 * i // max(1, len(steps))) for i in range(len(steps))]
-    r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000)
+    r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000, pk)
     r["workload"] = "C5-like: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
     out["other_configs"]["C5_like_4_colours_1gpu"] = r
     # (b) the same reads handed over in HOST memory through mcx_graph_add_reads (pinned buffers):
@@ -329,6 +353,8 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the device-resident figure (profiling passes)")
+    ap.add_argument("--input", choices=("packed", "ascii"), default="packed",
+                    help="form of the resident stream: 2-bit codes + invalid flags (what the host entry stages), or ASCII")
     ap.add_argument("--table-slots", type=int, default=TABLE_SLOTS, help="experiments only")
     ap.add_argument("--genome", type=int, default=GENOME_PER_GPU, help="experiments only")
     ap.add_argument("--err", type=float, default=0.001, help="experiments only")
@@ -397,6 +423,8 @@ def main():
         graph.add_stream_dev(0, batches[0][:1024 * 151], 1024 * 151)
         graph.sync()
         graph.reset()
+    use_packed = args.input == "packed" and not sharded
+    packed = pack_batches(mcx, batches) if use_packed else None
     ext = torch.cuda.ExternalStream(graph.stream, device=device)
     W = graph.W
 
@@ -411,7 +439,10 @@ def main():
             return
         if not sharded:
             for i in idx:
-                graph.add_stream_dev(0, batches[i], batches[i].numel())
+                if use_packed:
+                    graph.add_packed_dev(0, *packed[i])
+                else:
+                    graph.add_stream_dev(0, batches[i], batches[i].numel())
             return
         try:
             inserter.insert(0, [(batches[i], batches[i].numel()) for i in idx])
@@ -469,9 +500,11 @@ def main():
             "config": {"workload": ("C2-stress: k=31, 1 colour, %d iid random reads x %d bp per step per GPU, table %d slots per GPU; "
                                     "input resident in HBM as an ASCII byte stream" % (B, READ_LEN, args.table_slots)) if args.iid else
                                    "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
-                                   "table %d slots per GPU; input already resident in HBM as an ASCII byte stream (parse and H2D "
-                                   "outside `value`: see host_fed and e2e)" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots),
-                       "input": "device-resident ASCII stream",
+                                   "table %d slots per GPU; input already resident in HBM as %s (parse and H2D "
+                                   "outside `value`: see host_fed and e2e)" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots,
+                                                                                "the packed stream mcx_graph_add_reads stages (2-bit codes + invalid flags, 3 bits per position)"
+                                                                                if use_packed else "an ASCII byte stream"),
+                       "input": "device-resident packed stream (3 bits per position)" if use_packed else "device-resident ASCII stream",
                        "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
                        "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
@@ -484,7 +517,9 @@ def main():
         avg_ms = tot_ms / calls
         # algorithmic bytes of ONE launch of the dominant kernel: its per-occurrence figure
         #  x the occurrences one launch processes
-        alg_bytes = KERNEL_ALG_BYTES[dom] * kmers_local / calls
+        in_b = (0.375 if use_packed else 1.0) * (READ_LEN + 1) / (READ_LEN - K + 1.0)  # stream bytes per occurrence
+        kalg = dict(KERNEL_ALG_BYTES, k_stream_bin=in_b + 8.0)
+        alg_bytes = kalg[dom] * kmers_local / calls
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         pipe_bytes = ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel
         traffic, traffic_src = pmc_traffic(dom, kmers_local / calls)
@@ -493,7 +528,7 @@ def main():
                            "avg_kernel_ms": avg_ms, "launches": calls, "alg_bytes_per_launch": alg_bytes,
                            # every kernel of the path: its own algorithmic bytes per occurrence (tuples and bases
                            # only; k_lds_insert also streams the table once per flush) over its time
-                           "kernels": kernel_table(prof, kmers_local),
+                           "kernels": kernel_table(prof, kmers_local, 1, in_b),
                            "pipeline": {"gpu_ms": gpu_ms, "alg_bytes": pipe_bytes,
                                         "achieved": pipe_bytes / (gpu_ms * 1e-3) / 1e9,
                                         "frac": pipe_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -509,8 +544,8 @@ def main():
         if not sharded and not args.no_extras and not args.iid and not args.direct:
             graph.close()
             torch.cuda.empty_cache()
-            ex = extras(mcx, batches, nsteps, args.table_slots)
-            for key in ("host_fed", "e2e", "default_defer", "other_configs"):
+            ex = extras(mcx, batches, packed, nsteps, args.table_slots)
+            for key in ("host_fed", "e2e", "default_defer", "ascii_resident", "other_configs"):
                 if key in ex:
                     out[key] = ex[key]
         if not args.no_cpu_baseline and not sharded:

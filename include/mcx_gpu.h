@@ -176,6 +176,15 @@ int mcx_graph_pcr_reset(mcx_graph *g);
 int mcx_graph_add_stream_dev(mcx_graph *g, int colour,
                              const void *d_stream, uint64_t nbytes);
 
+/* The same stream in packed form: per 16 positions one code word (2 bits per base, A=0 C=1 G=2 T=3,
+ * first base on top) and 16 invalid flags (first base = bit 15; set for every position that does
+ * not hold one of ACGTacgt, and for positions >= npos of the last word) -- 3 bits per position
+ * instead of 8.  This is what mcx_graph_add_reads stages over PCIe (mcx_pack_bases on the host);
+ * mcx_pack_stream_dev converts an ASCII stream that is already in HBM (d_code: (npos + 15) / 16
+ * u32, d_inv: as many u16; asynchronous on `hip_stream`, a hipStream_t or NULL). */
+int mcx_pack_stream_dev(const void *d_stream, uint64_t nbytes, void *d_code, void *d_inv, void *hip_stream);
+int mcx_graph_add_packed_dev(mcx_graph *g, int colour, const void *d_code, const void *d_inv, uint64_t npos);
+
 /* Sharded build.  Step 1 on every rank: k-merise a device
  * stream and bin the per-occurrence tuples (canonical key words, edge byte) by
  * owner = (second result word of lookup3(key) * nparts) >> 32 (= mcx_key_owner()).  d_keys holds nparts bins of

@@ -749,6 +749,38 @@ extern "C" int mcx_graph_add_stream_dev(mcx_graph *g, int colour, const void *d_
   return submit_stream(g, L, colour);
 }
 
+// Packed form of a device-resident stream: the conversion (what a GPU-side parser would emit
+// directly) and the entry that consumes it.
+extern "C" int mcx_pack_stream_dev(const void *d_stream, uint64_t nbytes, void *d_code, void *d_inv, void *hip_stream)
+{
+  if (!d_stream || !d_code || !d_inv) return fail(MCX_ERR_ARG, "null argument");
+  if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  if (!nbytes) return MCX_OK;
+  const uint64_t nch = (nbytes + 15) / 16;
+  hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     (const uint8_t *)d_stream, nbytes, (uint32_t *)d_code, (uint16_t *)d_inv);
+  HIP_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+extern "C" int mcx_graph_add_packed_dev(mcx_graph *g, int colour, const void *d_code, const void *d_inv, uint64_t npos)
+{
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (g->as_group) {
+    mcx_graph *part = nullptr;
+    int rc = grp_part_of_pointer(g->as_group, d_code, &part);
+    if (rc != MCX_OK) return rc;
+    return mcx_graph_add_packed_dev(part, colour, d_code, d_inv, npos);
+  }
+  if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
+  if (!d_code || !d_inv) return fail(MCX_ERR_ARG, "null argument");
+  if (!npos) return MCX_OK;
+  if (g->must_exist) return fail(MCX_ERR_ARG, "device streams cannot be loaded in must-exist mode");
+  HIP_TRY(hipSetDevice(g->device));
+  StreamLaunch L{nullptr, npos, 0, npos, nullptr, (const uint32_t *)d_code, (const uint16_t *)d_inv};
+  return submit_stream(g, L, colour);
+}
+
 extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, int nparts,
                                               uint64_t bin_capacity, void *d_keys, void *d_edges, void *d_counts)
 {

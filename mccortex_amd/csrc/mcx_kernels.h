@@ -618,6 +618,17 @@ template <bool PK> __device__ __forceinline__ void tile_stage(const StreamArgs &
   }
 }
 
+// ASCII stream -> packed form on the device (one thread per 16 positions; positions >= nbytes invalid)
+__global__ void k_pack_stream(const uint8_t *stream, uint64_t nbytes, uint32_t *code_out, uint16_t *inv_out)
+{
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c * 16 >= nbytes) return;
+  uint32_t code, inv;
+  encode_words(load_chunk(stream, nbytes, (int64_t)(c * 16)), code, inv);
+  code_out[c] = code;
+  inv_out[c] = (uint16_t)inv;
+}
+
 // One k-mer occurrence produced by the front end
 template <int W> struct Occ {
   Kmer<W> key;

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_reads_pcr", "mcx_graph_pcr_reset", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
-    "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash", "mcx_pack_bases",
+    "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash", "mcx_pack_bases", "mcx_pack_stream_dev", "mcx_graph_add_packed_dev",
 ]
 
 
@@ -113,6 +113,8 @@ def lib():
                                           C.c_int, C.c_int, C.POINTER(LoadStats)]
     L.mcx_graph_pcr_reset.argtypes = [vp]
     L.mcx_graph_add_stream_dev.argtypes = [vp, C.c_int, vp, C.c_uint64]
+    L.mcx_pack_stream_dev.argtypes = [vp, C.c_uint64, vp, vp, vp]
+    L.mcx_graph_add_packed_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
     L.mcx_graph_partition_stream_dev.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp, vp, vp]
     L.mcx_graph_insert_tuples_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
     L.mcx_key_owner.restype = C.c_uint32
@@ -310,6 +312,10 @@ class Graph:
         _check(self.L.mcx_graph_covg_histogram(self.h, h.ctypes.data_as(C.POINTER(C.c_uint64)), nbins))
         return h
 
+    def add_packed_dev(self, colour, d_code, d_inv, npos):
+        """a device-resident stream in packed form (pack_stream_dev): 3 bits per position"""
+        _check(self.L.mcx_graph_add_packed_dev(self.h, colour, _ptr(d_code), _ptr(d_inv), int(npos)))
+
     def add_stream_dev(self, colour, d_stream, nbytes):
         _check(self.L.mcx_graph_add_stream_dev(self.h, colour, _ptr(d_stream), nbytes))
 
@@ -407,6 +413,11 @@ def superk_supported(kmer_size):
 def superk_owner(words, kmer_size, nparts):
     a = (C.c_uint64 * 2)(*(list(words) + [0])[:2])
     return int(lib().mcx_superk_owner(a, kmer_size, nparts))
+
+
+def pack_stream_dev(d_stream, nbytes, d_code, d_inv, hip_stream=None):
+    """ASCII stream in HBM -> packed form (d_code: int32 [(nbytes + 15) // 16], d_inv: int16 likewise)"""
+    _check(lib().mcx_pack_stream_dev(_ptr(d_stream), int(nbytes), _ptr(d_code), _ptr(d_inv), C.c_void_p(hip_stream) if hip_stream else None))
 
 
 def records_checksum(recs, kmer_size, ncols):

@@ -441,3 +441,28 @@ def test_export_in_key_ranges_when_scratch_is_short(mcx, orc, k, monkeypatch):
     with pytest.raises(mcx.McxError):
         g.export(True)
     g.close()
+
+
+@pytest.mark.parametrize("k,defer", [(31, 1), (63, 1), (21, 0)])
+def test_packed_device_stream(mcx, orc, k, defer):
+    """mcx_pack_stream_dev + mcx_graph_add_packed_dev: the 3-bit-per-position form of a device stream
+    (what the host entry stages) gives the graph of the ASCII stream; odd lengths, N, lower case."""
+    import torch
+    bases, offs = synth.reads(5000, 133, genome_len=40000, seed=k, n_frac=0.05, lower_frac=0.2, var_len=True)
+    stream = torch.from_numpy(synth.to_stream(bases, offs)).cuda()
+    n = stream.numel()
+    nch = (n + 15) // 16
+    code = torch.empty(nch, dtype=torch.int32, device="cuda")
+    inv = torch.empty(nch, dtype=torch.int16, device="cuda")
+    mcx.pack_stream_dev(stream, n, code, inv)
+    torch.cuda.synchronize()
+    og = orc.Graph(k, 1, 1 << 20)
+    og.add_reads(0, bases, offs)
+    g = mcx.Graph(k, 1, 1 << 20)
+    g.configure("defer", defer)
+    g.add_packed_dev(0, code, inv, n)
+    g.sync()
+    st = g.device_stats()
+    assert g.nkmers == og.nkmers
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    g.close()
