@@ -85,6 +85,7 @@ struct mcx_graph {
   uint64_t stage_alloc = 0;
   int cur = 0;
   int grid = 0;
+  int grid_stream = 0, grid_split = 0, grid_insert = 0;  // 0 = default; blocks of the three build kernels (experiments with concurrent launches)
   // ---- deferred (partition -> LDS insert) path, mcx_defer.h ----
   bool defer = true;
   uint64_t defer_tuples = 0;    // tuples buffered per flush (0 = pick from the table size)
@@ -386,7 +387,7 @@ static void launch_bin_stream_pk(mcx_graph *g, const StreamArgs &a, uint64_t nt,
     once = true;
   }
   SpanGuard sp(g, "k_stream_bin");
-  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
+  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid)));
   // the histogram capacity sets the LDS footprint and with it the blocks per CU: 512 and 1024 bins
   // leave room for 4 blocks (W=1), 2048 for 2
   if (bs.nlocal <= 512)
@@ -422,7 +423,7 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
     once = true;
   }
   SpanGuard sp(g, "k_tuples_bin");
-  const dim3 grid((unsigned)std::min<uint64_t>(nchunks, (uint64_t)g->grid * 4));
+  const dim3 grid((unsigned)std::min<uint64_t>(nchunks, (uint64_t)(g->grid_split ? g->grid_split : g->grid * 4)));
   if (bs.nlocal <= 512)
     hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>), grid, dim3(kThreads), sizeof(BinLds<W, 512, false>), g->stream, in, bs, out, is, g->d_ctr);
   else if (bs.nlocal <= 1024)
@@ -452,7 +453,7 @@ template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int 
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
   BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
   SpanGuard sp(g, "k_lds_insert");
-  hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nsub, (uint64_t)g->grid * 4)),
+  hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nsub, (uint64_t)(g->grid_insert ? g->grid_insert : g->grid * 4))),
                      dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, sub0, nsub, g->d_ctr);
 }
 
@@ -682,6 +683,9 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     if (g->must_exist) g->defer = false;
     return MCX_OK;
   }
+  if (!strcmp(key, "grid_stream")) { g->grid_stream = (int)value; return MCX_OK; }
+  if (!strcmp(key, "grid_split")) { g->grid_split = (int)value; return MCX_OK; }
+  if (!strcmp(key, "grid_insert")) { g->grid_insert = (int)value; return MCX_OK; }
   if (!strcmp(key, "profile")) {
     HIP_TRY(hipStreamSynchronize(g->stream));
     for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
