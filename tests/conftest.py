@@ -12,6 +12,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _have_gpu():
+    """False only when the library LOADS and reports no device: a library that does not build or load
+    must fail the gpu tests loudly, not skip them"""
+    try:
+        import mccortex_amd
+        return mccortex_amd.device_count() > 0
+    except Exception:
+        return True
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests are skipped (not failed) where there is no HIP device: plain `pytest tests`
+    is green on a CPU box; `-m gpu` on the GPU box runs them all"""
+    if not any("gpu" in it.keywords for it in items) or _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (no HIP device here)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def orc():
     from oracle import orc as o
