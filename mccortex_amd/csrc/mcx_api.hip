@@ -1733,7 +1733,7 @@ extern "C" int mcx_graph_device_stats(mcx_graph *g, mcx_load_stats *out)
   out->num_good_reads = c.good_reads;
   out->num_bad_reads = c.bad_reads;
   out->contigs_parsed = c.contigs;
-  out->num_kmers_loaded = c.kmers;
+  out->num_kmers_loaded = c.kmers - c.absent;  // must-exist mode: found k-mers only (build_graph.c:175-177)
   out->num_kmers_novel = c.novel;
   // sum of contig lengths = k-mers + (k-1) per contig (build_graph.c:173-176)
   out->total_bases_loaded = c.kmers + (uint64_t)(g->k - 1) * c.contigs;

@@ -160,7 +160,7 @@ struct Counters {  // device-resident, 64-bit each
   unsigned long long full;      // != 0: an insert ran out of probes
   unsigned long long bin_over;  // != 0: a partition bin overflowed
   unsigned long long good_reads, bad_reads;
-  unsigned long long pad;
+  unsigned long long absent;    // must-exist mode: k-mer occurrences whose k-mer is not in the graph (not "loaded", build_graph.c:175-177)
 };
 
 // Add a per-thread tally to a device counter with ONE global atomic per block: all blocks hit
@@ -1126,7 +1126,7 @@ __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint
   const uint64_t len = off[r + 1] - off[r];
   const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
   const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);
-  unsigned long long n_kmers = 0, n_contigs = 0;
+  unsigned long long n_kmers = 0, n_contigs = 0, n_absent = 0;
   uint32_t dummy_novel = 0, full = 0;
   uint64_t cs, ce, search = 0;
   while ((cs = qh_contig_start(seq, len, qual, search, (uint64_t)k, qcut, hcut)) < len) {
@@ -1154,10 +1154,12 @@ __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint
       }
       prev_slot = slot; prev_o = o; prev_first = first;
       n_kmers++;
+      n_absent += slot == kNoSlot;
     }
     n_contigs++;
   }
   if (n_kmers) atomicAdd(&ctr->kmers, n_kmers);
+  if (n_absent) atomicAdd(&ctr->absent, n_absent);
   if (n_contigs) atomicAdd(&ctr->contigs, n_contigs);
   atomicAdd(n_contigs ? &ctr->good_reads : &ctr->bad_reads, 1ULL);
 }

@@ -535,8 +535,12 @@ static void load_read(orc_graph *g, int colour, const char *seq, size_t len, con
     if(g->full) return;
     size_t ckmers = clen + 1 - k;
     st->total_bases_loaded += clen;
-    st->num_kmers_loaded += ckmers;
-    st->num_kmers_novel += ckmers - nonnovel;
+    if(g->must_exist) {  /* build_graph.c:175-177: only the k-mers that were found count as loaded */
+      st->num_kmers_loaded += nonnovel;
+    } else {
+      st->num_kmers_loaded += ckmers;
+      st->num_kmers_novel += ckmers - nonnovel;
+    }
     ncontigs++;
   }
   st->contigs_parsed += ncontigs;
