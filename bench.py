@@ -267,6 +267,34 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000, pk)
     r["workload"] = "C5-like: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
     out["other_configs"]["C5_like_4_colours_1gpu"] = r
+    # (f) the multi-GPU table of the C ABI (mcx_graph_create_multi) with BOTH shards on this one GPU:
+    # sender kernel -> peer copy (device-local here) -> owner split -> LDS insert; a check of the
+    # code path and of its overheads, not a scaling figure
+    try:
+        g = mcx.Graph(K, 1, table_slots, devices=[0, 0])
+        g.configure("defer_tuples", 3_000_000_000)
+        if pk is not None:
+            g.add_packed_dev(0, pk[0][0][:4096], pk[0][1][:4096], 65536)
+        g.sync(); g.reset(); g.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i, b in enumerate(steps):
+            if pk is not None:
+                g.add_packed_dev(0, *pk[i])
+            else:
+                g.add_stream_dev(0, b, b.numel())
+        g.sync()
+        dt = time.perf_counter() - t0
+        st = g.device_stats()
+        cs, nk = g.checksum()
+        g.close()
+        torch.cuda.empty_cache()
+        out["inprocess_2_shards_1gpu"] = {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(steps),
+                                          "distinct_kmers": int(st.num_kmers_novel), "graph_checksum": "%016x" % cs,
+                                          "what": "mcx_graph_create_multi with devices [0, 0]: two hash-prefix shards on ONE GPU, exchange v2 through "
+                                                  "hipMemcpyPeerAsync (device-local); the graph checksum must equal config.graph_checksum"}
+    except Exception as e:
+        out["inprocess_2_shards_1gpu"] = {"error": str(e)[:300]}
     # (b) the same reads handed over in HOST memory through mcx_graph_add_reads (pinned buffers):
     # staging, PCIe and the kernels inside the clock
     nh = len(steps)
@@ -545,7 +573,7 @@ def main():
             graph.close()
             torch.cuda.empty_cache()
             ex = extras(mcx, batches, packed, nsteps, args.table_slots)
-            for key in ("host_fed", "e2e", "default_defer", "ascii_resident", "other_configs"):
+            for key in ("host_fed", "e2e", "default_defer", "ascii_resident", "other_configs", "inprocess_2_shards_1gpu"):
                 if key in ex:
                     out[key] = ex[key]
         if not args.no_cpu_baseline and not sharded:

@@ -269,3 +269,29 @@ def test_w1_fast_path_equals_generic_code(orc):
             g.add_reads(0, bases, offs)
             g.add_reads(1, bases[:int(offs[1000])], offs[:1001], nthreads=4)
         assert a.ctx_bytes(True) == b.ctx_bytes(True)
+
+
+def test_timed_baseline_helpers_build_the_same_graph(orc, tmp_path):
+    """orc_graph_tune (prefault, per-worker node tallies) and orc_build_file (1 reader thread ->
+    2048-slot pool -> workers: async_read_io.c:145-175,283-310) are bench.py's CPU baseline; the
+    graphs they build are the plain oracle's."""
+    import synth
+    bases, offs = synth.reads(3000, 120, genome_len=20000, seed=5, n_frac=0.05)
+    ref = orc.Graph(31, 1, 1 << 20)
+    st0 = ref.add_reads(0, bases, offs)
+    want = ref.ctx_bytes(True)
+    g = orc.Graph(31, 1, 1 << 20)
+    g.tune(3)
+    st = g.add_reads(0, bases, offs, nthreads=3)
+    assert g.nkmers == ref.nkmers and g.ctx_bytes(True) == want
+    assert st.as_dict() == st0.as_dict()
+    fq = tmp_path / "r.fq"
+    with open(fq, "wb") as f:
+        for i in range(len(offs) - 1):
+            r = bytes(bases[int(offs[i]):int(offs[i + 1])])
+            f.write(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    g2 = orc.Graph(31, 1, 1 << 20)
+    g2.tune(2)
+    tot, ins, st2 = g2.build_file(str(fq), 4)
+    assert tot >= ins > 0 and g2.nkmers == ref.nkmers and g2.ctx_bytes(True) == want
+    assert st2.num_kmers_loaded == st0.num_kmers_loaded and st2.contigs_parsed == st0.contigs_parsed
