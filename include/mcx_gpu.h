@@ -282,8 +282,9 @@ int mcx_sort_records(void *recs, uint64_t nrecs, int kmer_size, int ncols, int d
 int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_size, int ncols, int device,
                        int64_t *first_unsorted);
 
-/* Sharded build, exchange format v3 ("reads travel, not occurrences"; one-word keys with odd k in
- * 29..31, mcx_superk_supported()).  The owner of a k-mer is a function of its canonical minimizer
+/* Sharded build, exchange format v3 ("reads travel, not occurrences"; odd k in 29..63,
+ * mcx_superk_supported(); records are mcx_superk_record_bytes(k) = 16 bytes for one-word keys, 32
+ * for two-word keys: an 80-base window).  The owner of a k-mer is a function of its canonical minimizer
  * (smallest hashed canonical 13-mer), so consecutive k-mers of a read mostly share an owner and
  * are sent as one 16-byte record: the 48-base window of 16 consecutive positions plus the start and
  * length of the run -- about 2.3 bytes per occurrence instead of 8.5.  Every rank holds an ordinary
@@ -298,6 +299,7 @@ int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_size, int ncol
  *                              d_counts[nseg] in device memory) into the region bins; applied at the
  *                              next flush */
 int mcx_superk_supported(int kmer_size);
+int mcx_superk_record_bytes(int kmer_size);
 uint32_t mcx_superk_owner(const uint64_t *key_words, int kmer_size, int nparts);
 int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positions_per_call, uint32_t *segs_per_owner,
                             uint64_t *seg_cap);

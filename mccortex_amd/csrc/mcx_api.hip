@@ -937,13 +937,14 @@ extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *
 // ---------------------------------------------------------------------------
 static const uint32_t kSuperkRep = 8;
 
-extern "C" int mcx_superk_supported(int kmer_size) { return kmer_size >= kSuperkMinK && kmer_size <= 31 && (kmer_size & 1); }
+extern "C" int mcx_superk_supported(int kmer_size) { return kmer_size >= kSuperkMinK && kmer_size <= 63 && (kmer_size & 1); }
+extern "C" int mcx_superk_record_bytes(int kmer_size) { return mcx_superk_supported(kmer_size) ? 16 * words_for_k(kmer_size) : 0; }
 
 extern "C" uint32_t mcx_superk_owner(const uint64_t *key_words, int kmer_size, int nparts)
 {
   uint32_t lbo = 0;
   while ((1 << lbo) < nparts) lbo++;
-  return superk_owner(key_words[0], kmer_size, lbo);
+  return words_for_k(kmer_size) == 1 ? superk_owner(0, key_words[0], kmer_size, lbo) : superk_owner(key_words[0], key_words[1], kmer_size, lbo);
 }
 
 extern "C" int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positions_per_call, uint32_t *segs_per_owner,
@@ -964,7 +965,7 @@ extern "C" int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uin
 {
   NO_GROUP(g, "mcx_graph_superk_bins_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
-  if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..31 (got %d)", kSuperkMinK, g->k);
+  if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..63 (got %d)", kSuperkMinK, g->k);
   if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1))) return fail(MCX_ERR_ARG, "shards must be a power of two <= 32");
   if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
   if (!nbytes) return MCX_OK;
@@ -975,33 +976,34 @@ extern "C" int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uin
   const StreamArgs a = make_args(g, L);
   const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
   if (!nt) return MCX_OK;
-  SuperkOut out{(ulonglong2 *)d_recs, (unsigned long long *)d_counts, seg_cap, lbo, kSuperkRep};
+  SuperkOut out{d_recs, (unsigned long long *)d_counts, seg_cap, lbo, kSuperkRep};
   SpanGuard sp(g, "k_stream_superk");
-  hipLaunchKernelGGL(k_stream_superk, dim3((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid)), dim3(kThreads), 0, g->stream, a, out);
+  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
+  if (g->W == 1) hipLaunchKernelGGL(k_stream_superk<1>, grid, dim3(kThreads), 0, g->stream, a, out);
+  else hipLaunchKernelGGL(k_stream_superk<2>, grid, dim3(kThreads), 0, g->stream, a, out);
   HIP_TRY(hipGetLastError());
   return MCX_OK;
 }
 
 template <int W, bool ONECOL> static void launch_superk_bin(mcx_graph *g, SuperkIn in, int colour, BinSpec bs, BinOut out)
 {
-  if (W != 1) return;
   const uint64_t nunits = (in.seg_cap + kSkChunk - 1) / kSkChunk * in.nseg;  // chunks of records, one block walks one at a time
-  InsertSink<1, ONECOL> is{g->t, (uint32_t)colour};
-  const size_t lds512 = ((sizeof(BinLds<1, 512, false>) + 15) & ~(size_t)15) + kSkMapBytes;
-  const size_t ldsmax = ((sizeof(BinLds<1, kMaxBins, false>) + 15) & ~(size_t)15) + kSkMapBytes;
+  InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
+  const size_t lds512 = ((sizeof(BinLds<W, 512, false>) + 15) & ~(size_t)15) + kSkMapBytes;
+  const size_t ldsmax = ((sizeof(BinLds<W, kMaxBins, false>) + 15) & ~(size_t)15) + kSkMapBytes;
   static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
   bool &once = once_dev[g->device & 63];
   if (!once) {
-    allow_lds(k_superk_bin<ONECOL, 512>, lds512);
-    allow_lds(k_superk_bin<ONECOL, kMaxBins>, ldsmax);
+    allow_lds(k_superk_bin<W, ONECOL, 512>, lds512);
+    allow_lds(k_superk_bin<W, ONECOL, kMaxBins>, ldsmax);
     once = true;
   }
   SpanGuard sp(g, "k_superk_bin");
   const dim3 grid((unsigned)std::min<uint64_t>(nunits, (uint64_t)g->grid * 4));
   if (bs.nlocal <= 512)
-    hipLaunchKernelGGL((k_superk_bin<ONECOL, 512>), grid, dim3(kThreads), lds512, g->stream, in, g->k, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_superk_bin<W, ONECOL, 512>), grid, dim3(kThreads), lds512, g->stream, in, g->k, bs, out, is, g->d_ctr);
   else
-    hipLaunchKernelGGL((k_superk_bin<ONECOL, kMaxBins>), grid, dim3(kThreads), ldsmax, g->stream, in, g->k, bs, out, is, g->d_ctr);
+    hipLaunchKernelGGL((k_superk_bin<W, ONECOL, kMaxBins>), grid, dim3(kThreads), ldsmax, g->stream, in, g->k, bs, out, is, g->d_ctr);
 }
 
 extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_recs, const void *d_counts, uint32_t nseg,
@@ -1010,7 +1012,7 @@ extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_
   NO_GROUP(g, "mcx_graph_add_superk_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (colour < 0 || colour >= g->ncols_vis) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
-  if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..31 (got %d)", kSuperkMinK, g->k);
+  if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..63 (got %d)", kSuperkMinK, g->k);
   if (g->t.lbo) return fail(MCX_ERR_ARG, "super-k-mer shards use ordinary (unsharded) tables");
   if (!nseg || !seg_cap) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
@@ -1019,11 +1021,10 @@ extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_
   if (!g->defer) return fail(MCX_ERR_ARG, "super-k-mer records need the deferred insert path (table too small or defer=0)");
   rc = defer_reserve(g, colour, kmers_upper_bound);
   if (rc != MCX_OK) return rc;
-  SuperkIn in{(const ulonglong2 *)d_recs, (const unsigned long long *)d_counts, seg_cap, nseg};
+  SuperkIn in{d_recs, (const unsigned long long *)d_counts, seg_cap, nseg};
   BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
   BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
-  if (g->ncols == 1) launch_superk_bin<1, true>(g, in, colour, bs, out);
-  else launch_superk_bin<1, false>(g, in, colour, bs, out);
+  DISPATCH_WC(g, launch_superk_bin, g, in, colour, bs, out);
   HIP_TRY(hipGetLastError());
   g->pending += kmers_upper_bound;
   return MCX_OK;

@@ -6,8 +6,11 @@
 // carries the lane's 48-base window plus (start, length, two flags) of one run of up to 16
 // consecutive k-mers with the same owner -- ~2.3 records per 16 positions = ~2.3 B per occurrence
 // on the links instead of 8.5.  The owner k-merises what it receives and feeds the same region
-// bins as the single-GPU path.  Restricted to one-word keys with k >= 29 (M = 13, so that all 16
-// minimizer windows of a lane share a common middle part); other k use format v2.
+// bins as the single-GPU path.  Two-word keys (k = 33..63) use a 32-byte record with an 80-base
+// window: their minimizer windows are long (k - 12 m-mers), so most runs are the lane's whole 16
+// positions and a record carries ~3 B per occurrence against the 17 of format v2.  Restricted to
+// k >= 29 (M = 13, so that all 16 minimizer windows of a lane share a common middle part); smaller
+// k use format v2.
 //
 // Reference semantics are unaffected: which GPU holds a k-mer is free, the tuples
 // (canonical key, colour, edge byte) an owner derives are exactly those of mcx_defer.h.
@@ -33,13 +36,16 @@ MCX_HD uint32_t owner_of_minimizer(uint32_t min_hash, uint32_t lbo)
   return lbo ? ((min_hash * 0x85EBCA6Bu) ^ (min_hash >> 13)) * 0xC2B2AE35u >> (32u - lbo) : 0u;
 }
 
-// Host/device reference: owner of a k-mer given as its 2-bit value (one word, k <= 31).  The
-// kernels compute the same thing incrementally; tests compare shard contents against this.
-MCX_HD uint32_t superk_owner(uint64_t kmer, int k, uint32_t lbo)
+// Host/device reference: owner of a k-mer given as its 2-bit value (w0 = top word, unused for
+// k <= 31).  The kernels compute the same thing incrementally; tests compare shard contents
+// against this.
+MCX_HD uint32_t superk_owner(uint64_t w0, uint64_t w1, int k, uint32_t lbo)
 {
   uint32_t best = 0xFFFFFFFFu;
   for (int p = 0; p + kMmer <= k; p++) {
-    const uint32_t f = (uint32_t)(kmer >> (2 * (k - kMmer - p))) & kMmerMask;
+    const int sh = 2 * (k - kMmer - p);  // the m-mer's low bit inside the 2k-bit number w0 : w1
+    const uint64_t low = sh >= 64 ? (w0 >> (sh - 64)) : (sh ? (w1 >> sh) | (w0 << (64 - sh)) : w1);
+    const uint32_t f = (uint32_t)low & kMmerMask;
     uint32_t r = 0;
     for (int i = 0; i < kMmer; i++) r |= (3u - ((f >> (2 * i)) & 3u)) << (2 * (kMmer - 1 - i));
     const uint32_t h = mmer_hash(f < r ? f : r);
@@ -50,12 +56,34 @@ MCX_HD uint32_t superk_owner(uint64_t kmer, int k, uint32_t lbo)
 
 #if defined(__HIPCC__)
 
-// record: word 0 = bases -1 .. 30 of the lane's window (2 bits each, first on top); word 1 =
-// bases 31 .. 46 in the high half, header in the low half
+// record, one-word keys (16 bytes): a.x = bases -1 .. 30 of the lane's window (2 bits each, first on
+// top); a.y = bases 31 .. 46 in the high half, header in the low half.
+// two-word keys (32 bytes): a.x = bases -1 .. 30, a.y = bases 31 .. 62, b.x = bases 63 .. 78 in the
+// high half, header in the low half; b.y unused.
 constexpr uint32_t kSkStartMask = 0xFu, kSkLenShift = 4, kSkPrevOk = 1u << 8, kSkNextOk = 1u << 9;
+template <int W> struct SkRec;
+template <> struct SkRec<1> { ulonglong2 a; };
+template <> struct SkRec<2> { ulonglong2 a, b; };
+template <int W> __device__ __forceinline__ uint32_t sk_hdr(const SkRec<W> &r);
+template <> __device__ __forceinline__ uint32_t sk_hdr<1>(const SkRec<1> &r) { return (uint32_t)r.a.y; }
+template <> __device__ __forceinline__ uint32_t sk_hdr<2>(const SkRec<2> &r) { return (uint32_t)r.b.x; }
+template <int W> __device__ __forceinline__ SkRec<W> sk_make(uint64_t w0, uint64_t w1, uint64_t w2, uint32_t hdr);
+template <> __device__ __forceinline__ SkRec<1> sk_make<1>(uint64_t w0, uint64_t w1, uint64_t, uint32_t hdr)
+{
+  SkRec<1> r;
+  r.a = make_ulonglong2(w0, (w1 & 0xFFFFFFFF00000000ULL) | hdr);
+  return r;
+}
+template <> __device__ __forceinline__ SkRec<2> sk_make<2>(uint64_t w0, uint64_t w1, uint64_t w2, uint32_t hdr)
+{
+  SkRec<2> r;
+  r.a = make_ulonglong2(w0, w1);
+  r.b = make_ulonglong2((w2 & 0xFFFFFFFF00000000ULL) | hdr, 0);
+  return r;
+}
 
 struct SuperkOut {
-  ulonglong2 *recs;             // [nparts][rep][cap]
+  void *recs;                   // [nparts][rep][cap] records of SkRec<W>
   // fills, REPLICA-major [rep][nparts] (zeroed by the caller; > cap: records were dropped): the
   // blocks of one replica reserve from one 64-byte line, other replicas from other lines
   unsigned long long *counts;
@@ -63,19 +91,22 @@ struct SuperkOut {
   uint32_t lbo, rep;
 };
 
-constexpr int kSkStage = 2048;  // records staged per tile in LDS (a tile of random reads makes ~600)
+template <int W> struct SkCfg { static constexpr int kStage = 2048 / W; };  // records staged per tile in LDS (a tile of random reads makes ~600, ~350 at k = 63)
 
 // ---------------------------------------------------------------------------
 // sender: reads -> per-owner bins of super-k-mer records
 // ---------------------------------------------------------------------------
+template <int W>
 __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, SuperkOut out)
 {
+  constexpr int kSkStage = SkCfg<W>::kStage;
   __shared__ uint32_t s_code[kChunks + 4];
   __shared__ uint32_t s_inv[kChunks / 2 + 4];
-  __shared__ ulonglong2 s_rec[kSkStage];
+  __shared__ SkRec<W> s_rec[kSkStage];
   __shared__ uint8_t s_own[kSkStage];
   __shared__ uint32_t s_cnt[32], s_rank[32], s_total;
   __shared__ unsigned long long s_base[32];
+  SkRec<W> *recs_out = reinterpret_cast<SkRec<W> *>(out.recs);
 
   const int tid = threadIdx.x;
   const int k = a.k;
@@ -84,63 +115,57 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
   const uint32_t rep = blockIdx.x % out.rep;
 
   // the chunks of the NEXT tile are fetched into registers while the current one is processed
-  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+  TileSrc pre;
+  pre.a = make_uint4(0, 0, 0, 0); pre.b = make_uint4(0, 0, 0, 0);
   {
     const uint64_t t0 = a.tile0 + blockIdx.x;
-    if (t0 < a.ntiles) {
-      const int64_t r0 = (int64_t)(t0 * kTile) - 16;
-      pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
-      if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
-    }
+    if (t0 < a.ntiles) tile_fetch<false>(a, t0, tid, pre);
   }
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
-    {
-      uint32_t code, inv;
-      encode_words(pre0, code, inv);
-      s_code[tid] = code;
-      reinterpret_cast<uint16_t *>(s_inv)[tid ^ 1] = (uint16_t)inv;
-      if (tid < kChunks - kThreads) {
-        encode_words(pre1, code, inv);
-        s_code[tid + kThreads] = code;
-        reinterpret_cast<uint16_t *>(s_inv)[(tid + kThreads) ^ 1] = (uint16_t)inv;
-      }
-    }
+    tile_stage<false>(a, pre, tid, s_code, s_inv);
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     if (tid < 32) { s_cnt[tid] = 0; s_rank[tid] = 0; }
     if (tid == 0) s_total = 0;
     {
       const uint64_t tn = tile + gridDim.x;
-      if (tn < a.ntiles) {
-        const int64_t r0 = (int64_t)(tn * kTile) - 16;
-        pre0 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)tid);
-        if (tid < kChunks - kThreads) pre1 = load_chunk(a.stream, a.nbytes, r0 + 16 * (int64_t)(tid + kThreads));
-      }
+      if (tn < a.ntiles) tile_fetch<false>(a, tn, tid, pre);
     }
     __syncthreads();
 
     const uint32_t pl = 16u * (uint32_t)(tid + 1);
     const uint64_t Vh = inv_win64(s_inv, pl);
+    const uint64_t Vl = (W == 2) ? inv_win64(s_inv, pl + 64) : 0;
     const uint32_t prev_chunk_inv = (s_inv[(pl - 1) >> 5] >> (31 - ((pl - 1) & 31))) & 1u;
     const uint64_t P0 = tile * kTile + 16ull * (uint64_t)tid;
     const int j_lo = a.pos_lo > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_lo - P0) : 0;
     const int j_hi = a.pos_hi > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_hi - P0) : 0;
     uint32_t ok16, nok16, pok16;  // as in k_stream_bin
     {
-      uint64_t Mh = Vh;
-      for (int c = 1; c < k;) { const int s = min(c, k - c); Mh |= Mh << s; c += s; }
+      uint64_t Mh = Vh, Ml = Vl;
+      for (int c = 1; c < k;) {
+        const int s = min(c, k - c);
+        if (W == 2) Mh |= (Mh << s) | (Ml >> (64 - s));
+        else Mh |= Mh << s;
+        if (W == 2) Ml |= Ml << s;
+        c += s;
+      }
       const uint32_t range = ((0x10000u >> j_lo) - 1u) & ~((0x10000u >> j_hi) - 1u);
       ok16 = ~(uint32_t)(Mh >> 48) & range;
-      nok16 = ~(uint32_t)(Vh >> (48 - k)) & 0xFFFFu;
+      const int sh = 112 - k;  // base j + k: field of 16 flags starting at bit 112 - k of Vh : Vl
+      const uint64_t nx = sh >= 64 ? (Vh >> (sh - 64)) : ((Vh << (64 - sh)) | (W == 2 ? (Vl >> sh) : 0));
+      nok16 = ~(uint32_t)nx & 0xFFFFu;
       pok16 = ~((prev_chunk_inv << 15) | (uint32_t)(Vh >> 49)) & 0xFFFFu;
     }
     if (ok16) {
       n_kmers += __popc(ok16);
       n_contigs += __popc(ok16 & ~pok16);
-      // window: base i (relative to the lane's first position) is base i + 1 of (hiW : loW)
-      const uint64_t hiW = code_win64(s_code, pl - 1), loW = code_win64(s_code, pl + 31);
-      auto nuc_at = [&](int t) -> uint32_t {  // t = i + 1
-        return t < 32 ? (uint32_t)(hiW >> (62 - 2 * t)) & 3u : (uint32_t)(loW >> (126 - 2 * t)) & 3u;
+      // window: base i (relative to the lane's first position) is base t = i + 1 of w0 : w1 : w2
+      const uint64_t w0 = code_win64(s_code, pl - 1), w1 = code_win64(s_code, pl + 31);
+      const uint64_t w2 = (W == 2) ? code_win64(s_code, pl + 63) : 0;
+      auto nuc_at = [&](int t) -> uint32_t {
+        if (W == 2 && t >= 64) return (uint32_t)(w2 >> (190 - 2 * t)) & 3u;
+        return t < 32 ? (uint32_t)(w0 >> (62 - 2 * t)) & 3u : (uint32_t)(w1 >> (126 - 2 * t)) & 3u;
       };
       // canonical minimizer hash of every k-mer start j: min over m-mers p = j .. j + k - M.
       // All 16 windows contain p = 15 .. k - M; left of it a suffix minimum, right a prefix one.
@@ -164,16 +189,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
 #pragma unroll
       for (int p = 13; p >= 0; p--) h[p] = min(h[p], h[p + 1]);       // suffix minima over p .. 14
       uint32_t own[16];
-      uint32_t pre = 0xFFFFFFFFu;
+      uint32_t pre_min = 0xFFFFFFFFu;
       own[0] = owner_of_minimizer(min(common, h[0]), out.lbo);
 #pragma unroll
       for (int j = 1; j < 16; j++) {
-        pre = min(pre, push(nuc_at(k + j)));                          // m-mer k - M + j ends at base k + j - 1
+        pre_min = min(pre_min, push(nuc_at(k + j)));                  // m-mer k - M + j ends at base k + j - 1
         const uint32_t left = j < 15 ? h[j] : 0xFFFFFFFFu;
-        own[j] = owner_of_minimizer(min(min(common, left), pre), out.lbo);
+        own[j] = owner_of_minimizer(min(min(common, left), pre_min), out.lbo);
       }
       // runs of consecutive valid k-mers with one owner -> records staged in LDS
-      const uint64_t w1hi = loW & 0xFFFFFFFF00000000ULL;
       int start = -1;
       uint32_t cur = 0;
 #pragma unroll
@@ -186,11 +210,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
           if (pok16 >> (15 - start) & 1u) hdr |= kSkPrevOk;
           if (nok16 >> (15 - last) & 1u) hdr |= kSkNextOk;
           const uint32_t slot = atomicAdd(&s_total, 1u);
-          const ulonglong2 rec = make_ulonglong2(hiW, w1hi | hdr);
+          const SkRec<W> rec = sk_make<W>(w0, w1, w2, hdr);
           if (slot < (uint32_t)kSkStage) { s_rec[slot] = rec; s_own[slot] = (uint8_t)cur; }
           else {  // staging full (pathological input): straight to the bin, one global atomic
             const unsigned long long pos = atomicAdd(&out.counts[rep * nparts + cur], 1ULL);
-            if (pos < out.cap) out.recs[((uint64_t)cur * out.rep + rep) * out.cap + pos] = rec;
+            if (pos < out.cap) recs_out[((uint64_t)cur * out.rep + rep) * out.cap + pos] = rec;
             else dropped = 1;
           }
           start = -1;
@@ -208,7 +232,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
     for (uint32_t q = tid; q < nst; q += kThreads) {
       const uint32_t o = s_own[q];
       const unsigned long long pos = s_base[o] + atomicAdd(&s_rank[o], 1u);
-      if (pos < out.cap) out.recs[((uint64_t)o * out.rep + rep) * out.cap + pos] = s_rec[q];
+      if (pos < out.cap) recs_out[((uint64_t)o * out.rep + rep) * out.cap + pos] = s_rec[q];
       else dropped = 1;
     }
   }
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
 // owner: super-k-mer records -> region bins of packed tuples (same output as k_stream_bin)
 // ---------------------------------------------------------------------------
 struct SuperkIn {
-  const ulonglong2 *recs;            // [nseg][seg_cap]
+  const void *recs;                  // [nseg][seg_cap] records of SkRec<W>
   const unsigned long long *counts;  // [nseg]; a fill above seg_cap is read as seg_cap
   uint64_t seg_cap;
   uint32_t nseg;
@@ -232,7 +256,7 @@ struct SuperkIn {
 // K-MERS -- not the records -- are dealt out to the lanes.  A block walks a chunk of a segment and
 // takes, per tile, as many records (in fours: one 64-byte load per lane) as hold <= kTile k-mers;
 // k-mer q of the tile (records in order, their k-mers in order) goes to lane q % kThreads as its
-// (q / kThreads)-th, and every lane extracts its k-mers straight from the record's 48-base
+// (q / kThreads)-th, and every lane extracts its k-mers straight from the record's
 // window.  All lanes carry the same number of k-mers (+-1) and tiles are full (>= kTile - 63
 // k-mers) except at a chunk's end, so the cost per k-mer does not depend on the run lengths.
 constexpr int kSkPerLane = 4;                      // candidate records per lane and tile
@@ -240,18 +264,17 @@ constexpr int kSkCand = kSkPerLane * kThreads;     // 1024
 constexpr uint32_t kSkChunk = 1u << 13;            // records per unit of work (a block's walk)
 constexpr size_t kSkMapBytes = (size_t)kTile * 2;  // s_map behind the BinLds block in dynamic LDS
 
-template <bool ONECOL, int NB>
-__global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, BinSpec bs, BinOut out,
-                                                            InsertSink<1, ONECOL> isink, Counters *ctr)
+template <int W, bool ONECOL, int NB>
+__global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(SuperkIn in, int k, BinSpec bs, BinOut out,
+                                                                         InsertSink<W, ONECOL> isink, Counters *ctr)
 {
-  constexpr int W = 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   using LDS = BinLds<W, NB, false>;
   LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
   // the taken records sit in the staging area (not written before bin_place); the k-mer -> (record,
   // index in run) map has its own 8 KB
-  static_assert(sizeof(L.skey) >= (size_t)kSkCand * 16, "records fit the staging area");
-  ulonglong2 *s_rec = reinterpret_cast<ulonglong2 *>(L.skey);
+  static_assert(sizeof(L.skey) >= (size_t)kSkCand * sizeof(SkRec<W>), "records fit the staging area");
+  SkRec<W> *s_rec = reinterpret_cast<SkRec<W> *>(L.skey);
   uint16_t *s_map = reinterpret_cast<uint16_t *>(dyn_lds + ((sizeof(LDS) + 15) & ~(size_t)15));  // record | index << 10
   __shared__ uint32_t s_incl[kThreads + 1];
   __shared__ uint32_t s_wsum[kThreads / 64];
@@ -268,22 +291,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, 
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (c0 >= cnt) continue;  // uniform
     const uint64_t c1 = min(cnt, c0 + (uint64_t)kSkChunk);
-    const ulonglong2 *recs = in.recs + (uint64_t)seg * in.seg_cap;
+    const SkRec<W> *recs = reinterpret_cast<const SkRec<W> *>(in.recs) + (uint64_t)seg * in.seg_cap;
     for (uint64_t pos = c0; pos < c1;) {  // uniform
       __syncthreads();
       for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
       // four candidate records per lane, their k-mer counts, inclusive scan over the block
-      ulonglong2 ra = make_ulonglong2(0, 0), rb = ra, rc4 = ra, rd = ra;
-      uint32_t la = 0, lb = 0, lc = 0, ld = 0;
+      SkRec<W> rr[kSkPerLane];
+      uint32_t ll[kSkPerLane];
+      uint32_t lsum = 0;
       {
         const uint64_t i = pos + (uint64_t)kSkPerLane * (uint64_t)tid;
-        auto rlen = [](const ulonglong2 &r) { return (((uint32_t)r.y >> kSkLenShift) & 0xFu) + 1u; };
-        if (i + 0 < c1) { ra = recs[i + 0]; la = rlen(ra); }
-        if (i + 1 < c1) { rb = recs[i + 1]; lb = rlen(rb); }
-        if (i + 2 < c1) { rc4 = recs[i + 2]; lc = rlen(rc4); }
-        if (i + 3 < c1) { rd = recs[i + 3]; ld = rlen(rd); }
+#pragma unroll
+        for (int q = 0; q < kSkPerLane; q++) {
+          ll[q] = 0;
+          if (i + q < c1) { rr[q] = recs[i + q]; ll[q] = ((sk_hdr<W>(rr[q]) >> kSkLenShift) & 0xFu) + 1u; }
+          lsum += ll[q];
+        }
       }
-      const uint32_t lsum = la + lb + lc + ld;
       uint32_t x = lsum;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -304,11 +328,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, 
       if (take) {
         uint32_t o = x - lsum;
         const uint32_t r0 = (uint32_t)kSkPerLane * (uint32_t)tid;
-        s_rec[r0 + 0] = ra; s_rec[r0 + 1] = rb; s_rec[r0 + 2] = rc4; s_rec[r0 + 3] = rd;
-        for (uint32_t i = 0; i < la; i++) s_map[o++] = (uint16_t)((r0 + 0u) | (i << 10));
-        for (uint32_t i = 0; i < lb; i++) s_map[o++] = (uint16_t)((r0 + 1u) | (i << 10));
-        for (uint32_t i = 0; i < lc; i++) s_map[o++] = (uint16_t)((r0 + 2u) | (i << 10));
-        for (uint32_t i = 0; i < ld; i++) s_map[o++] = (uint16_t)((r0 + 3u) | (i << 10));
+#pragma unroll
+        for (int q = 0; q < kSkPerLane; q++) {
+          if (ll[q]) s_rec[r0 + q] = rr[q];
+          for (uint32_t i = 0; i < ll[q]; i++) s_map[o++] = (uint16_t)((r0 + (uint32_t)q) | (i << 10));
+        }
       }
       __syncthreads();
       const uint32_t T = s_T;
@@ -323,19 +347,31 @@ __global__ __launch_bounds__(kThreads, 4) void k_superk_bin(SuperkIn in, int k, 
         const uint32_t q = (uint32_t)j * kThreads + (uint32_t)tid;
         if (j < nj && q < T) {  // (j < nj is uniform: whole iterations are skipped)
           const uint32_t m = s_map[q];
-          const ulonglong2 rec = s_rec[m & 0x3ffu];
-          const uint64_t hiW = rec.x, loW = rec.y & 0xFFFFFFFF00000000ULL;
-          const uint32_t hdr = (uint32_t)rec.y;
+          const SkRec<W> rec = s_rec[m & 0x3ffu];
+          const uint32_t hdr = sk_hdr<W>(rec);
           const uint32_t i = m >> 10, rlen = ((hdr >> kSkLenShift) & 0xFu) + 1u;
           const uint32_t p = (hdr & kSkStartMask) + i;       // the k-mer is bases p+1 .. p+k of the window
           const uint32_t sft = 2u * (p + 1u);                // 2 .. 32
-          const uint64_t X = (hiW << sft) | (loW >> (64u - sft));  // bases p+1 .. p+32 on top
           Kmer<W> fw, rc;
-          fw.w[0] = X >> (64 - 2 * k);
+          uint32_t nuc_next;
+          const uint64_t w0 = rec.a.x;
+          if constexpr (W == 1) {
+            const uint64_t w1 = rec.a.y & 0xFFFFFFFF00000000ULL;
+            const uint64_t X = (w0 << sft) | (w1 >> (64u - sft));  // bases p+1 .. p+32 on top
+            fw.w[0] = X >> (64 - 2 * k);
+            // base after the k-mer = the one below the top k bases of X (k <= 31)
+            nuc_next = (uint32_t)(X >> (62 - 2 * k)) & 3u;
+          } else {
+            const uint64_t w1 = rec.a.y, w2 = rec.b.x & 0xFFFFFFFF00000000ULL;
+            const uint64_t A = (w0 << sft) | (w1 >> (64u - sft));  // bases p+1 .. p+32
+            const uint64_t B = (w1 << sft) | (w2 >> (64u - sft));  // bases p+33 .. p+64
+            const int s = 128 - 2 * k;                               // 2 .. 62: the k-mer is the top 2k bits of A : B
+            fw.w[0] = A >> s;
+            fw.w[W - 1] = (B >> s) | (A << (64 - s));
+            nuc_next = (uint32_t)(B >> (s - 2)) & 3u;                // the base below them
+          }
           rc = revcomp<W>(fw, k);
-          // base after the k-mer = the one below the top k bases of X (k <= 31); base before it = window base p
-          const uint32_t nuc_next = (uint32_t)(X >> (62 - 2 * k)) & 3u;
-          const uint32_t prev_nuc = (uint32_t)(hiW >> (62u - 2u * p)) & 3u;
+          const uint32_t prev_nuc = (uint32_t)(w0 >> (62u - 2u * p)) & 3u;  // base before it = window base p
           const bool next_ok = (i + 1u < rlen) || (hdr & kSkNextOk);
           const bool prev_ok = (i > 0u) || (hdr & kSkPrevOk);
           uint32_t o;

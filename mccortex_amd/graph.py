@@ -14,7 +14,7 @@ SYMBOLS = [
     "mcx_last_error", "mcx_version", "mcx_device_count", "mcx_device_memory", "mcx_graph_create", "mcx_graph_create_multi", "mcx_graph_ndevices",
     "mcx_graph_create_shard", "mcx_graph_shard_layout", "mcx_graph_shard_bins_dev", "mcx_graph_add_segments_dev",
     "mcx_graph_key_owner", "mcx_graph_insert_tuple_segments_dev", "mcx_graph_add_records", "mcx_graph_kmer_covg", "mcx_graph_covg_histogram", "mcx_sort_records",
-    "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_superk_supported", "mcx_superk_owner", "mcx_graph_checksum", "mcx_records_checksum",
+    "mcx_records_sorted", "mcx_graph_intersect_finish", "mcx_superk_supported", "mcx_superk_record_bytes", "mcx_superk_owner", "mcx_graph_checksum", "mcx_records_checksum",
     "mcx_graph_superk_layout", "mcx_graph_superk_bins_dev", "mcx_graph_add_superk_dev", "mcx_graph_destroy",
     "mcx_graph_reset", "mcx_graph_configure", "mcx_graph_profile", "mcx_graph_capacity", "mcx_graph_add_reads", "mcx_graph_add_reads_pcr", "mcx_graph_pcr_reset", "mcx_graph_add_stream_dev",
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
@@ -91,6 +91,7 @@ def lib():
     L.mcx_records_sorted.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.mcx_graph_intersect_finish.argtypes = [vp, u64p]
     L.mcx_superk_supported.argtypes = [C.c_int]
+    L.mcx_superk_record_bytes.argtypes = [C.c_int]
     L.mcx_superk_owner.restype = C.c_uint32
     L.mcx_superk_owner.argtypes = [u64p, C.c_int, C.c_int]
     L.mcx_graph_superk_layout.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(C.c_uint32), u64p]
@@ -408,6 +409,11 @@ def records_sorted(recs, kmer_size, ncols, device=0):
 
 def superk_supported(kmer_size):
     return bool(lib().mcx_superk_supported(kmer_size))
+
+
+def superk_record_words(kmer_size):
+    """64-bit words per super-k-mer record (2 for one-word keys, 4 for two-word keys)"""
+    return int(lib().mcx_superk_record_bytes(kmer_size)) // 8
 
 
 def superk_owner(words, kmer_size, nparts):

@@ -128,15 +128,15 @@ class BlockExchange:
 
 class SuperkExchange:
     """Exchange format v3 (mcx_graph_superk_bins_dev / mcx_graph_add_superk_dev): per-owner bins of
-    16-byte super-k-mer records, `segs` replica segments per owner.  A send set keeps its fills
+    16-byte (two-word keys: 32-byte) super-k-mer records, `segs` replica segments per owner.  A send set keeps its fills
     replica-major (fills[segs][world], what the kernel wants); a receive set per source
     (counts[world][segs], one fill per received segment).
     Only the filled part of every segment travels: the fills are exchanged first (one small
     all-to-all and one host read), then one all-to-all per replica segment moves the records."""
 
-    def __init__(self, world, segs, seg_cap, device):
-        self.world, self.segs, self.seg_cap = world, segs, seg_cap
-        self.recs = torch.empty((world, segs, seg_cap, 2), dtype=torch.int64, device=device)
+    def __init__(self, world, segs, seg_cap, device, rec_words=2):
+        self.world, self.segs, self.seg_cap, self.rec_words = world, segs, seg_cap, rec_words
+        self.recs = torch.empty((world, segs, seg_cap, rec_words), dtype=torch.int64, device=device)
         self.fills = torch.zeros((segs, world), dtype=torch.int64, device=device)    # sender side
         self.counts = torch.zeros((world, segs), dtype=torch.int64, device=device)   # receiver side
 
@@ -162,7 +162,7 @@ class SuperkExchange:
                 ins = [sc[p][s_] for p in range(world)]
                 outs = [rc[p][s_] for p in range(world)]
                 pk = torch.cat([self.recs[p, s_, :ins[p]] for p in range(world)])
-                tk = torch.empty((sum(outs), 2), dtype=self.recs.dtype, device=self.recs.device)
+                tk = torch.empty((sum(outs), self.rec_words), dtype=self.recs.dtype, device=self.recs.device)
                 dist.all_to_all_single(tk, pk, output_split_sizes=outs, input_split_sizes=ins, group=group)
                 o = 0
                 for p in range(world):
@@ -172,7 +172,7 @@ class SuperkExchange:
 
     def consume(self, graph, colour, nrecords):
         """owner: k-merise the received segments (this object is a receive set)"""
-        graph.add_superk_dev(colour, self.recs, self.counts, self.world * self.segs, self.seg_cap, nrecords * 16)
+        graph.add_superk_dev(colour, self.recs, self.counts, self.world * self.segs, self.seg_cap, nrecords * 16)  # <= 16 k-mers per record
 
     def overflowed(self):
         return bool((self.fills > self.seg_cap).any().item())
@@ -202,7 +202,7 @@ class ShardedInserter:
             # the owner k-merises what it receives.  Only filled parts travel, which costs one
             # host read of the fills per step.
             segs, seg_cap = graph.superk_layout(world, self.max_stream_bytes)
-            mk = lambda: SuperkExchange(world, segs, seg_cap, device)
+            mk = lambda: SuperkExchange(world, segs, seg_cap, device, rec_words=2 * graph.W)
         else:
             # every owner's block has a fixed size: one all-to-all per buffer, no count round trip
             segs, seg_cap, ov_cap = graph.shard_layout(self.max_tuples)

@@ -150,9 +150,57 @@ def test_c4_and_c5_full_size_paths_agree(mcx, c2_batches):
     a = _build(mcx, c2_batches, 63, 1, 1 << 30, {"defer_tuples": 5_000_000_000})
     b = _build(mcx, c2_batches, 63, 1, 1 << 30, {"defer": 0})
     assert a == b and a["covg_sum"][0] == a["loaded"] and a["hist0"] == 0 and a["loaded"] > 4.3e9
+    # C4 sharded, exchange format v3 with the 32-byte records of two-word keys: 4 owners, checksum == fused
+    import torch
+    N, K = 4, 63
+    owners = [mcx.Graph(K, 1, (1 << 30) // N) for _ in range(N)]
+    for o in owners:
+        o.configure("defer_tuples", 2_000_000_000)
+    segs, cap = owners[0].superk_layout(N, c2_batches[0].numel())
+    recs = torch.empty((N, segs, cap, mcx.superk_record_words(K)), dtype=torch.int64, device="cuda")
+    fills = torch.zeros((segs, N), dtype=torch.int64, device="cuda")
+    nrec = 0
+    for bt in c2_batches:
+        fills.zero_()
+        owners[0].superk_bins_dev(bt, bt.numel(), N, recs, fills, cap)
+        owners[0].sync()
+        counts = fills.t().contiguous()
+        assert int(fills.max()) <= cap
+        nrec += int(counts.sum())
+        for p, o in enumerate(owners):
+            o.add_superk_dev(0, recs[p], counts[p], segs, cap, int(counts[p].sum()) * 16)
+        torch.cuda.synchronize()
+        for o in owners:
+            o.sync()
+    assert owners[0].device_stats().num_kmers_loaded == a["loaded"]
+    parts = [o.checksum() for o in owners]
+    for o in owners:
+        o.close()
+    del recs
+    torch.cuda.empty_cache()
+    assert (sum(c for c, _ in parts) & M64, sum(n for _, n in parts)) == (a["checksum"], a["nodes"])
+    assert nrec * 32 < 5.0 * a["loaded"]  # bytes on the links: below 5 per occurrence (format v2: 17)
     # C5-like: the 10 batches spread over 4 colours
     cols = [0, 0, 0, 1, 1, 1, 2, 2, 3, 3]
     a = _build(mcx, c2_batches, 31, 4, 1 << 30, {}, cols)
     b = _build(mcx, c2_batches, 31, 4, 1 << 30, {"defer": 0}, cols)
     assert a == b and sum(a["covg_sum"]) == a["loaded"] and a["hist0"] == 0
     assert all(n > 0 for n in a["covg_nodes"])
+
+
+def test_c2_full_size_in_process_multi(mcx, c2_batches):
+    """mcx_graph_create_multi with two and four shards on the one GPU at C2 size: the facade's
+    checksum / node count / counters equal the single table's (csrc/mcx_multi.h)."""
+    ref = _build(mcx, c2_batches, 31, 1, 1 << 30, {"defer_tuples": 8_000_000_000})
+    for devs in ([0, 0], [0, 0, 0, 0]):
+        g = mcx.Graph(31, 1, 1 << 30, devices=devs)
+        g.configure("defer_tuples", 8_000_000_000 // len(devs))
+        for b in c2_batches:
+            g.add_stream_dev(0, b, b.numel())
+        g.sync()
+        st = g.device_stats()
+        cs, n = g.checksum()
+        nk, sc = g.kmer_covg()
+        g.close()
+        assert (cs, n, st.num_kmers_loaded, st.contigs_parsed) == (ref["checksum"], ref["nodes"], ref["loaded"], ref["contigs"]), devs
+        assert int(nk[0]) == ref["nodes"] and int(sc[0]) == ref["loaded"]

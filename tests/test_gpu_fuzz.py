@@ -81,7 +81,7 @@ def test_superkmer_records_on_arbitrary_bytes(mcx, orc, seed):
     alphabet = np.concatenate([np.frombuffer(b"ACGT" * 60 + b"acgtNn\n\r @+>", np.uint8), rng.integers(0, 256, 10).astype(np.uint8)])
     for n in (0, 1, 29, 31, 32, 47, 4095, 4096, 4097, 4096 * 3 + 7, 60001):
         s = bytes(rng.choice(alphabet, n)) if n else b""
-        for k, nparts in ((31, 4), (29, 2), (31, 32)):
+        for k, nparts in ((31, 4), (29, 2), (31, 32), (63, 4), (35, 8)):
             og, st, want = _oracle_body(orc, k, s)
             graphs = [mcx.Graph(k, 1, 1 << 20) for _ in range(nparts)]
             t = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
@@ -89,7 +89,8 @@ def test_superkmer_records_on_arbitrary_bytes(mcx, orc, seed):
             if n:
                 t[:n] = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
             segs, cap = graphs[0].superk_layout(nparts, max(n, 1))
-            recs = torch.zeros((nparts, segs, cap, 2), dtype=torch.int64, device="cuda")
+            W = (2 * k + 63) // 64
+            recs = torch.zeros((nparts, segs, cap, 2 * W), dtype=torch.int64, device="cuda")
             fills = torch.zeros((segs, nparts), dtype=torch.int64, device="cuda")
             graphs[0].superk_bins_dev(t, n, nparts, recs, fills, cap)
             graphs[0].sync()
@@ -100,4 +101,4 @@ def test_superkmer_records_on_arbitrary_bytes(mcx, orc, seed):
                 g.add_superk_dev(0, recs[o], counts[o], segs, cap, int(counts[o].sum()) * 16)
                 bodies.append(g.export(True))
                 g.close()
-            assert shard.merge_sorted_bodies(bodies, 13, 8) == want, (n, k, nparts)
+            assert shard.merge_sorted_bodies(bodies, 8 * W + 5, 8 * W) == want, (n, k, nparts)

@@ -309,14 +309,17 @@ def test_sharded_table_compact_exchange(mcx, orc, k, nparts):
     assert all(len(b) > 0 for b in bodies)
 
 
-@pytest.mark.parametrize("k,nparts", [(31, 4), (29, 8), (31, 2), (31, 1)])
+@pytest.mark.parametrize("k,nparts", [(31, 4), (29, 8), (31, 2), (31, 1), (63, 4), (33, 8), (47, 2), (63, 1)])
 def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
     """Exchange format v3: every 'rank' turns its reads into per-owner super-k-mer records, every
     owner k-merises the records addressed to it; the union of the (unsharded) owner tables is the
     oracle's graph and every key sits on the shard its canonical minimizer names."""
     import torch
     from mccortex_amd import shard
-    assert mcx.superk_supported(k) and not mcx.superk_supported(27) and not mcx.superk_supported(33)
+    assert mcx.superk_supported(k) and not mcx.superk_supported(27) and mcx.superk_supported(63) and not mcx.superk_supported(32)
+    rw = mcx.superk_record_words(k)
+    W = (2 * k + 63) // 64
+    assert rw == 2 * W
     g0 = synth.genome(50000, 77)
     graphs = [mcx.Graph(k, 1, 1 << 20) for _ in range(nparts)]
     all_reads = []
@@ -328,7 +331,7 @@ def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
         all_reads.append((bases, offs))
         stream = torch.from_numpy(synth.to_stream(bases, offs)).cuda()
         segs, seg_cap = graphs[r].superk_layout(nparts, stream.numel())
-        recs = torch.zeros((nparts, segs, seg_cap, 2), dtype=torch.int64, device="cuda")
+        recs = torch.zeros((nparts, segs, seg_cap, rw), dtype=torch.int64, device="cuda")
         fills = torch.zeros((segs, nparts), dtype=torch.int64, device="cuda")   # replica-major
         graphs[r].superk_bins_dev(stream, stream.numel(), nparts, recs, fills, seg_cap)
         graphs[r].sync()                       # a dropped record would raise here
@@ -341,7 +344,7 @@ def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
             graphs[o].sync()
         if r == 1:  # bytes on the wire: well below 8 bytes per occurrence
             st = graphs[r].device_stats()
-            assert nrec * 16 < 5.0 * max(1, st.num_kmers_loaded) or nparts == 1
+            assert nrec * 8 * rw < 5.0 * max(1, st.num_kmers_loaded) or nparts == 1
     og = orc.Graph(k, 1, 1 << 21)
     ost = orc.Stats()
     for b, o in all_reads:
@@ -357,7 +360,7 @@ def test_superkmer_exchange_simulated_shards(mcx, orc, k, nparts):
             assert mcx.superk_owner([int(x) for x in row], k, nparts) == p
         bodies.append(g.export(True))
         g.close()
-    assert shard.merge_sorted_bodies(bodies, 8 + 5, 8) == og.body_bytes(True)
+    assert shard.merge_sorted_bodies(bodies, 8 * W + 5, 8 * W) == og.body_bytes(True)
     if nparts > 1:
         sizes = [len(b) for b in bodies]
         assert min(sizes) > 0.5 * max(sizes)   # minimizer ownership is reasonably balanced
