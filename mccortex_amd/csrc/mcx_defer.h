@@ -69,6 +69,9 @@ struct BinOut {
   uint64_t ov_cap;
 };
 
+#ifndef MCX_PSCAN
+#define MCX_PSCAN 1   // 1: the histogram scan of a tile is shared by the block's four waves (0: wave 0 scans alone)
+#endif
 #ifndef MCX_VEC16
 #define MCX_VEC16 1    // 1: tuple segments are read with 16-byte loads where their alignment allows
 #endif
@@ -107,6 +110,7 @@ template <int W, int NB, bool FULL> struct BinLds {
   unsigned long long gbase[NB];
   uint32_t cnt[NB];
   uint32_t off[NB + 4];
+  uint32_t wsum[kThreads / 64];
   uint16_t sbin[kStage];
   uint8_t se[FULL ? kStage : 16];
 };
@@ -122,6 +126,43 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
 {
   const int tid = threadIdx.x;
   __syncthreads();
+#if MCX_PSCAN
+  {  // every thread scans NB / kThreads consecutive bins; the waves' totals meet in LDS.  (One wave
+     // scanning all bins while the other three wait at the barrier cost 8 % of the k-merising kernel.)
+    constexpr int PERB = NB / kThreads;
+    static_assert(NB % kThreads == 0, "bins per thread");
+    uint32_t c[PERB], x = 0;
+#pragma unroll
+    for (int i = 0; i < PERB; i++) {
+      const uint32_t b = (uint32_t)tid * PERB + i;
+      c[i] = b < bs.nlocal ? L.cnt[b] : 0;
+      x += c[i];
+    }
+    const uint32_t mine = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d, 64);
+      if ((tid & 63) >= d) x += y;
+    }
+    if ((tid & 63) == 63) L.wsum[tid >> 6] = x;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) {
+      const uint32_t ws = L.wsum[w];
+      if (w < (tid >> 6)) before += ws;
+      total += ws;
+    }
+    uint32_t o = before + x - mine;
+#pragma unroll
+    for (int i = 0; i < PERB; i++) {
+      const uint32_t b = (uint32_t)tid * PERB + i;
+      if (b < bs.nlocal) L.off[b] = o;
+      o += c[i];
+    }
+    if (tid == 0) L.off[bs.nlocal] = total;
+  }
+#else
   if (tid < 64) {
     uint32_t carry = 0;
     for (uint32_t b0 = 0; b0 < bs.nlocal; b0 += 64) {
@@ -138,6 +179,7 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     }
     if (tid == 0) L.off[bs.nlocal] = carry;
   }
+#endif
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
@@ -260,8 +302,11 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
 //    other shards take the direct insert), SH 2 of every shard (BIN_GLOBAL, exchange blocks).
 //    The variants are compiled apart: code of the rare paths costs the common one registers.
 // ---------------------------------------------------------------------------
+#ifndef MCX_SB_BLOCKS
+#define MCX_SB_BLOCKS 4
+#endif
 template <int W, bool ONECOL, int NB, bool FULL, int SH, bool PK>
-__global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
+__global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
                                                                          InsertSink<W, ONECOL> isink)
 {
   __shared__ uint32_t s_code[kChunks + 4];
