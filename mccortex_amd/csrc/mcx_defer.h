@@ -109,6 +109,7 @@ template <int W, int NB, bool FULL> struct BinLds {
   // value still fit the bin's segment (the rest overflows)
   unsigned long long gbase[NB];
   uint32_t cnt[NB];
+  uint32_t rnk[NB];  // rank counters of the placement (zeroed with cnt at the top of a tile)
   uint32_t off[NB + 4];
   uint32_t wsum[kThreads / 64];
   uint16_t sbin[kStage];
@@ -188,10 +189,9 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
       if (c) res.g0[q] = atomicAdd(&out.counts[out_seg(bs, ob0, b)], (unsigned long long)c);
-      L.cnt[b] = 0;
     }
   }
-  __syncthreads();
+  // (no barrier: the ranking that follows counts in rnk[], which was zeroed at the top of the tile)
 }
 
 constexpr unsigned long long kDstMask = (1ULL << 48) - 1;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void bin_commit(LDS &L, const BinSpec &bs, const BinO
 // Sorted position of a tuple inside the tile (taken once, kept in a register)
 template <class LDS> __device__ __forceinline__ uint32_t bin_rank(LDS &L, uint32_t local)
 {
-  return L.off[local] + atomicAdd(&L.cnt[local], 1u);
+  return L.off[local] + atomicAdd(&L.rnk[local], 1u);
 }
 
 // Placement: drop a tuple at its sorted position if that position belongs to this round
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
     tile_stage<PK>(a, pre, tid, s_code, s_inv);
-    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
+    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     {
       const uint64_t tn = tile + gridDim.x;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
     const uint32_t region = bs.region0 + lregion;
     const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? lregion * isink.t.spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
     __syncthreads();
-    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
+    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
     __syncthreads();
     const uint64_t *kin = in.keys + (pseg * in.seg_cap + start) * W;
     const uint8_t *ein = IN_FULL ? in.edges + pseg * in.seg_cap + start : nullptr;

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(Super
     const SkRec<W> *recs = reinterpret_cast<const SkRec<W> *>(in.recs) + (uint64_t)seg * in.seg_cap;
     for (uint64_t pos = c0; pos < c1;) {  // uniform
       __syncthreads();
-      for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
+      for (uint32_t b = tid; b < bs.nlocal; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
       // four candidate records per lane, their k-mer counts, inclusive scan over the block
       SkRec<W> rr[kSkPerLane];
       uint32_t ll[kSkPerLane];
