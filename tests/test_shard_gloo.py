@@ -114,7 +114,7 @@ def test_block_exchange_routes_fixed_blocks(mcx, world):
     mp.spawn(_block_worker, args=(world, _free_port()), nprocs=world, join=True)
 
 
-def _superk_worker(rank, world, port):
+def _superk_worker(rank, world, port, rec_words=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -126,10 +126,10 @@ def _superk_worker(rank, world, port):
         cnt = torch.randint(0, seg_cap + 1, (segs,), generator=g)
         cnt[0] = 0
         cnt[1] = seg_cap
-        return cnt, torch.randint(-2**62, 2**62, (segs, seg_cap, 2), generator=g)
+        return cnt, torch.randint(-2**62, 2**62, (segs, seg_cap, rec_words), generator=g)
 
-    send = shard.SuperkExchange(world, segs, seg_cap, "cpu")
-    recv = shard.SuperkExchange(world, segs, seg_cap, "cpu")
+    send = shard.SuperkExchange(world, segs, seg_cap, "cpu", rec_words=rec_words)
+    recv = shard.SuperkExchange(world, segs, seg_cap, "cpu", rec_words=rec_words)
     for p in range(world):
         send.fills[:, p], send.recs[p] = stamp(rank, p)
     n = send.exchange_into(recv)
@@ -145,6 +145,7 @@ def _superk_worker(rank, world, port):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_superk_exchange_routes_filled_parts(mcx, world):
-    mp.spawn(_superk_worker, args=(world, _free_port()), nprocs=world, join=True)
+@pytest.mark.parametrize("world,rec_words", [(2, 2), (4, 2), (2, 4)])
+def test_superk_exchange_routes_filled_parts(mcx, world, rec_words):
+    """rec_words 2: 16-byte records of one-word keys; 4: the 32-byte records of two-word keys"""
+    mp.spawn(_superk_worker, args=(world, _free_port(), rec_words), nprocs=world, join=True)
