@@ -1041,7 +1041,7 @@ extern "C" uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_
   } else {
     m = region_mix<2>(key_quot<2>(Kmer<2>{{key_words[0], key_words[1]}}, lbq, r));
   }
-  return (r ^ (m & ((1u << lbq) - 1u))) >> g->t.lb1;
+  return (r ^ mix_g(m, lbq)) >> g->t.lb1;
 }
 
 extern "C" uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts)

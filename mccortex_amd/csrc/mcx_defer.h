@@ -69,6 +69,12 @@ struct BinOut {
   uint64_t ov_cap;
 };
 
+#ifndef MCX_TOP_BARRIER
+#define MCX_TOP_BARRIER 0
+#endif
+#ifndef MCX_RANK_GROUP
+#define MCX_RANK_GROUP 4  // returning LDS atomics of the ranking in flight per lane (4, 8; other = the compiler's choice)
+#endif
 #ifndef MCX_PSCAN
 #define MCX_PSCAN 1   // 1: the histogram scan of a tile is shared by the block's four waves (0: wave 0 scans alone)
 #endif
@@ -108,13 +114,24 @@ template <int W, int NB, bool FULL> struct BinLds {
   // tile) - (its sorted position in the tile), mod 2^48; bits 48..63 = sorted positions below this
   // value still fit the bin's segment (the rest overflows)
   unsigned long long gbase[NB];
-  uint32_t cnt[NB];
-  uint32_t rnk[NB];  // rank counters of the placement (zeroed with cnt at the top of a tile)
-  uint32_t off[NB + 4];
+  uint32_t cnt[NB + 64];  // [nlocal + lane] = the trash bins (positions without a tuple), one per lane
+  uint32_t rnk[NB + 64];  // rank counters of the placement (zeroed with cnt at the top of a tile)
+  uint32_t off[NB + 64];
   uint32_t wsum[kThreads / 64];
   uint16_t sbin[kStage];
   uint8_t se[FULL ? kStage : 16];
 };
+
+// The thread index, opaque to the optimiser: what is derived from it inside a tile loop (LDS
+// addresses, masks) is then recomputed per tile in an instruction or two -- hoisted out of the
+// loop these values were spilled to scratch, and a scratch reload waits for the next tile's
+// prefetch (vmcnt counts in order).
+__device__ __forceinline__ uint32_t tid_now()
+{
+  uint32_t t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
 
 // After the counting sweep: exclusive scan of the histogram (wave 0), then every thread issues
 // the global reservations of its bins (one returning atomic per non-empty bin).  The results
@@ -123,7 +140,8 @@ template <int W, int NB, bool FULL> struct BinLds {
 template <int NB> struct BinRes { unsigned long long g0[(NB + kThreads - 1) / kThreads]; };
 
 template <class LDS, int NB>
-__device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, BinRes<NB> &res)
+__device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, BinRes<NB> &res,
+                                            bool trash_beyond = false)
 {
   const int tid = threadIdx.x;
   __syncthreads();
@@ -161,7 +179,9 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
       if (b < bs.nlocal) L.off[b] = o;
       o += c[i];
     }
-    if (tid == 0) L.off[bs.nlocal] = total;
+    // [nlocal] = the tile's total; then where the trash bins start: behind the real tuples, or
+    // (trash_beyond) past the tile, where the placement never looks
+    if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)kTile : total;
   }
 #else
   if (tid < 64) {
@@ -178,7 +198,7 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
       if (b < bs.nlocal) L.off[b] = carry + x - c;
       carry += __shfl(x, 63, 64);
     }
-    if (tid == 0) L.off[bs.nlocal] = carry;
+    if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)kTile : carry;
   }
 #endif
   __syncthreads();
@@ -262,7 +282,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
       const Kmer<W> qq = tuple_q<W>(tq);
       const uint32_t lbq = lbq_of(isink.t);
       if (SH == 2) {  // BIN_GLOBAL ... appended to the owner's overflow bin (full format)
-        const Kmer<W> key = key_unquot<W>(qq, lbq, b ^ (region_mix<W>(qq) & ((1u << lbq) - 1u)));
+        const Kmer<W> key = key_unquot<W>(qq, lbq, b ^ mix_g(region_mix<W>(qq), lbq));
         const uint32_t owner = b >> bs.lb1;
         const unsigned long long pos = atomicAdd(&out.ov_counts[owner], 1ULL);
         if (pos < out.ov_cap) {
@@ -283,6 +303,43 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
     }
   }
   if (round + 1 < kRounds) __syncthreads();  // staging is reused by the next round
+}
+
+// The lane's 16 k-mers and their reverse complements as windows of two 96-bit registers (one-word
+// keys, k <= 31), LEFT-aligned: with A = the lane's bases 0..47 (base 0 on top) and R = the reverse
+// complement of bases 0..k+14, also top-aligned,
+//     fw_j = top 64 bits of A << 2 j,        rc_j = top 64 bits of R << 2 (15 - j)
+// hold the k-mer in their upper 2k bits and other bases below.  Comparing them picks the
+// canonical strand all the same (k is odd: the two k-mers differ, so the highest differing bit is
+// one of theirs), and ONE shift of the winner by 64 - 2k + lbq yields the quotient: no masks.
+// After unrolling the window shifts are constants: two v_alignbit per strand and no dependency
+// chain from one position to the next (rolling both strands cost 12 instructions per position).
+struct LaneWin { uint32_t a2, a1, a0, r2, r1, r0; };
+__device__ __forceinline__ uint32_t pairrev32(uint32_t x)  // order of the 16 two-bit groups reversed
+{
+  const uint32_t r = __builtin_bitreverse32(x);
+  return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+__device__ __forceinline__ LaneWin lane_win(const uint32_t *s_code, uint32_t pl, int k)
+{
+  LaneWin w;
+  w.a2 = s_code[pl >> 4];  // pl is a multiple of 16: whole code words
+  w.a1 = s_code[(pl >> 4) + 1];
+  w.a0 = s_code[(pl >> 4) + 2];
+  // reverse complement of the 48 bases: its first 33 - k bases belong to bases beyond k + 14
+  const uint32_t c2 = pairrev32(~w.a0), c1 = pairrev32(~w.a1), c0 = pairrev32(~w.a2);
+  const int t = 66 - 2 * k;  // 4..60 (uniform)
+  if (t < 32) {
+    w.r2 = (c2 << t) | (c1 >> (32 - t));
+    w.r1 = (c1 << t) | (c0 >> (32 - t));
+    w.r0 = c0 << t;
+  } else {
+    const uint64_t x = (((uint64_t)c1 << 32) | c0) << (t - 32);
+    w.r2 = (uint32_t)(x >> 32);
+    w.r1 = (uint32_t)x;
+    w.r0 = 0;
+  }
+  return w;
 }
 
 // A key owned by another shard cannot be packed for this one (its remainder would be rebuilt
@@ -306,17 +363,33 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
 #define MCX_SB_BLOCKS 4
 #endif
 template <int W, bool ONECOL, int NB, bool FULL, int SH, bool PK>
-__global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stream_bin(StreamArgs a, BinSpec bs, BinOut out,
-                                                                         InsertSink<W, ONECOL> isink)
+__global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stream_bin(StreamArgs a_arg, BinSpec bs, BinOut out_arg,
+                                                                         InsertSink<W, ONECOL> isink_arg)
 {
   __shared__ uint32_t s_code[kChunks + 4];
   __shared__ uint32_t s_inv[kChunks / 2 + 4];
+  // Arguments that are read once per tile (owned range), after the loop (counters), or
+  // only by the rare paths (the table's description: bin overflow, foreign keys), are read from
+  // LDS: held in scalar registers through the tile loop they exhausted the register file --
+  // every tile paid ~80 v_readlane, and uniform values that had been moved to vector registers
+  // were spilled to scratch, whose reloads wait for the next tile's prefetch (vmcnt is in order).
+  // (Not the stream and bin pointers: through LDS they would be generic pointers and their loads
+  // and stores FLAT operations, which every LDS wait would then wait for as well.)
+  struct Cold { StreamArgs a; InsertSink<W, ONECOL> isink; };
+  __shared__ Cold cold;
+  if (threadIdx.x == 0) { cold.a = a_arg; cold.isink = isink_arg; }
+  __syncthreads();  // (also for the blocks that have no tile: they read the counter pointers below)
+  const StreamArgs &a = cold.a;   // pos_lo, pos_hi, ctr, flag
+  const BinOut &out = out_arg;
+  const InsertSink<W, ONECOL> &isink = cold.isink;
+  const uint64_t a_tile0 = a_arg.tile0, a_ntiles = a_arg.ntiles;
+  const uint32_t t_lb1 = isink_arg.t.lb1, t_lbq = isink_arg.t.lb1 + isink_arg.t.lbo, t_part = isink_arg.t.part;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   using LDS = BinLds<W, NB, FULL>;
   LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
 
-  const int tid = threadIdx.x;
-  const int k = a.k;
+  const int tid0 = threadIdx.x;
+  const int k = a_arg.k;
   uint32_t n_kmers = 0, n_contigs = 0, n_novel = 0, full = 0;
   const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
   const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);
@@ -326,17 +399,26 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
   TileSrc pre;
   pre.a = make_uint4(0, 0, 0, 0); pre.b = make_uint4(0, 0, 0, 0);
   {
-    const uint64_t t0 = a.tile0 + blockIdx.x;
-    if (t0 < a.ntiles) tile_fetch<PK>(a, t0, tid, pre);
+    const uint64_t t0 = a_tile0 + blockIdx.x;
+    if (t0 < a_ntiles) tile_fetch<PK>(a_arg, t0, tid0, pre);
   }
-  for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  for (uint64_t tile = a_tile0 + blockIdx.x; tile < a_ntiles; tile += gridDim.x) {
+    // (opaque: what is derived from the thread index -- LDS addresses, masks -- is recomputed per
+    // tile in an instruction or two; hoisted out of the loop it was spilled to scratch)
+    const int tid = (int)tid_now();
+#if MCX_TOP_BARRIER
     __syncthreads();
-    tile_stage<PK>(a, pre, tid, s_code, s_inv);
-    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
+#endif
+    // (No barrier here: what is written before the next one -- the tile's codes and flags, the
+    // zeroed counters -- was last read before the write-out's entry barrier of the previous tile;
+    // what a slower wave may still be reading, the staging area and the bin bases, is next
+    // written after the three barriers of bin_reserve.)
+    tile_stage<PK>(a_arg, pre, tid, s_code, s_inv);
+    for (uint32_t b = tid; b < bs.nlocal + 64; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     {
       const uint64_t tn = tile + gridDim.x;
-      if (tn < a.ntiles) tile_fetch<PK>(a, tn, tid, pre);
+      if (tn < a_ntiles) tile_fetch<PK>(a_arg, tn, tid, pre);
     }
     __syncthreads();
 
@@ -374,70 +456,102 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
     }
 
     // One pass over the lane's 16 positions: the tuples stay in registers (static indices
-    // after unrolling) while the block histograms, reserves and then places them.
+    // after unrolling) while the block histograms, reserves and then places them.  No branch
+    // depends on whether a position holds a k-mer: a position without one (or whose key belongs
+    // to another shard) is "binned" into a trash bin after the last real one -- it is counted,
+    // ranked and placed like the others, at sorted positions beyond the tile's real tuples, which
+    // the write-out never reaches.  (With `if (valid)` around every step a position cost 8 more
+    // VALU instructions and five scalar ones, and the LDS atomics of the ranking were waited for
+    // one by one.)
     Kmer<W> tk[kPosPerLane];    // FULL: canonical key; packed: quotient | edges << 56
-    uint32_t tle[kPosPerLane];  // edge byte (FULL) | local bin << 8 | sorted position << 19
-    uint32_t vmask = 0;
-    if (ok16) {
-      n_kmers += __popc(ok16);
-      n_contigs += __popc(ok16 & ~pok16);
+    uint32_t tle[kPosPerLane];  // local bin | sorted position << 12 | edge byte << 24 (FULL)
+    // one trash bin per lane (no same-address LDS atomics), never [nlocal] itself: off[nlocal] is the tile's total
+    const uint32_t trash = bs.nlocal + 1u + ((uint32_t)tid & 31u);
+    n_kmers += __popc(ok16);
+    n_contigs += __popc(ok16 & ~pok16);
+    {
+      // base before position j: the last base of the previous chunk, then the lane's own codes
+      // (s_code[pl >> 4] holds the 16 bases of the lane, first base on top): constant shifts
+      const uint32_t own = s_code[pl >> 4];
+      const uint32_t before = s_code[(pl - 1) >> 4] & 3u;
+      const uint32_t lbq = t_lbq;
+      const uint32_t qmask = (1u << lbq) - 1u, lmask = (1u << t_lb1) - 1u;
       Kmer<W> fw, rc;
+      uint64_t feed;
+      LaneWin lw;
       if (W == 1) {
-        fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * k);
+        lw = lane_win(s_code, pl, k);
+        feed = code_win64(s_code, pl + (uint32_t)k);
       } else {
         const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
         const int s = 128 - 2 * k;
         fw.w[0] = hi >> s;
         fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
+        rc = revcomp<W>(fw, k);
+        feed = code_win64(s_code, pl + (uint32_t)k);
       }
-      rc = revcomp<W>(fw, k);
-      const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
-      // base before position j: the last base of the previous chunk, then the lane's own codes
-      // (s_code[pl >> 4] holds the 16 bases of the lane, first base on top): constant shifts
-      const uint32_t own = s_code[pl >> 4];
-      const uint32_t before = s_code[(pl - 1) >> 4] & 3u;
+      const uint32_t feed32 = (uint32_t)(feed >> 32);  // the bases after the lane's 16 k-mers
+      const uint32_t key_sh = 64u - 2u * (uint32_t)k;  // one-word keys: left-aligned -> key
+      const uint32_t mix_sh = (32u - lbq) & 31u;
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++) {
         const uint32_t prev_nuc = j == 0 ? before : ((own >> (32 - 2 * j)) & 3u);
-        const uint32_t bit = 0x8000u >> j;
-        const bool valid = (ok16 & bit) != 0;
-        const bool next_ok = (nok16 & bit) != 0;
-        const bool prev_ok = (pok16 & bit) != 0;
-        const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
-        if (valid) {  // tk[j] / tle[j] are only read for positions that were binned (vmask)
-          uint32_t o, local;
-          const Kmer<W> key = canonical<W>(fw, rc, o);
-          uint32_t e = 0;
-          if (next_ok) e |= 1u << (nuc_next + 4u * o);
-          if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
-          if (FULL) {
-            uint32_t h2;
-            kmer_hash<W>(key, 0, &h2);
-            local = owner_of(h2, bs.nparts);
-            tk[j] = key;
-            tle[j] = (local << 8) | e;
+        const uint32_t nuc_next = (feed32 >> (30 - 2 * j)) & 3u;
+        // valid = all ones where a k-mer starts at j
+        const uint32_t valid = 0u - ((ok16 >> (15 - j)) & 1u);
+        const uint32_t nb = (nok16 >> (15 - j)) & 1u, pb = (pok16 >> (15 - j)) & 1u;
+        uint32_t o, local;
+        Kmer<W> key;
+        uint64_t sel = 0;  // one-word keys: the canonical strand, left-aligned
+        if (W == 1) {      // windows of the lane's 96-bit registers: constant shifts, no chain
+          const uint32_t fh = j ? __builtin_amdgcn_alignbit(lw.a2, lw.a1, 32 - 2 * j) : lw.a2;
+          const uint32_t fl = j ? __builtin_amdgcn_alignbit(lw.a1, lw.a0, 32 - 2 * j) : lw.a1;
+          const uint32_t rh = j < 15 ? __builtin_amdgcn_alignbit(lw.r2, lw.r1, 2 + 2 * j) : lw.r2;
+          const uint32_t rl = j < 15 ? __builtin_amdgcn_alignbit(lw.r1, lw.r0, 2 + 2 * j) : lw.r1;
+          const uint64_t f = ((uint64_t)fh << 32) | fl, r = ((uint64_t)rh << 32) | rl;
+          o = f < r ? 0u : 1u;
+          sel = f < r ? f : r;
+          key.w[0] = sel >> key_sh;
+        } else {
+          key = canonical<W>(fw, rc, o);
+        }
+        // edge byte: successor bit nuc_next + 4 o, predecessor bit (3 - prev_nuc) + 4 (1 - o)
+        const uint32_t o4 = o << 2;
+        const uint32_t e = (nb << (nuc_next | o4)) | (pb << ((prev_nuc ^ 7u) ^ o4));
+        if (FULL) {
+          uint32_t h2;
+          kmer_hash<W>(key, 0, &h2);
+          local = owner_of(h2, bs.nparts);
+          tk[j] = key;
+          local = (local & valid) | (trash & ~valid);
+          tle[j] = local | (e << 24);
+        } else {
+          uint32_t G;
+          Kmer<W> q;
+          if (W == 1) {  // key, then quotient and remainder, from the left-aligned strand
+            const uint64_t kk = sel >> key_sh;
+            q.w[0] = kk >> lbq;
+            G = ((uint32_t)kk ^ (region_mix<W>(q) >> mix_sh)) & qmask;  // = r ^ mix_g(): (owner, region)
           } else {
             uint32_t r;
-            const uint32_t lbq = lbq_of(isink.t);
-            const Kmer<W> q = key_quot<W>(key, lbq, r);
-            const uint32_t G = r ^ (region_mix<W>(q) & ((1u << lbq) - 1u));  // (owner, region) of the key
-            local = SH == 2 ? G : (G & ((1u << isink.t.lb1) - 1u));
-            tk[j] = tuple_pack<W>(q, e);
-            tle[j] = local << 8;
-            if (SH == 1 && (G >> isink.t.lb1) != isink.t.part) {
-              foreign_insert<W, ONECOL>(isink, key, e, n_novel, full);
-              local = kMaxBins;  // not binned
-            }
+            q = key_quot<W>(key, lbq, r);
+            G = r ^ mix_g(region_mix<W>(q), lbq);
           }
-          if (local < (uint32_t)kMaxBins) {
-            vmask |= 1u << j;
-            atomicAdd(&L.cnt[local], 1u);
+          local = SH == 1 ? (G & lmask) : G;  // (SH 0: no owner bits; SH 2: bins of every shard)
+          tk[j] = tuple_pack<W>(q, e);
+          if (SH == 1 && valid && (G >> t_lb1) != t_part) {
+            foreign_insert<W, ONECOL>(isink, key, e, n_novel, full);
+            local = trash;  // not binned
           }
+          local = (local & valid) | (trash & ~valid);
+          tle[j] = local;
         }
-        if (W == 1) {
-          fw.w[0] = ((fw.w[0] << 2) | nuc_next) & top_mask;
-          rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
-        } else {
+        atomicAdd(&L.cnt[local], 1u);
+        // one position at a time: VALU work gains nothing from interleaving positions, and their
+        // temporaries together pushed tuples out to scratch
+        if (W == 1) asm volatile("" : "+v"(tle[j]), "+v"(tk[j].w[0]));
+        else asm volatile("" : "+v"(tle[j]), "+v"(tk[j].w[0]), "+v"(tk[j].w[W - 1]));
+        if (W == 2) {
           fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
           fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
           rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
@@ -446,16 +560,24 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
       }
     }
     BinRes<NB> res;
-    bin_reserve<LDS, NB>(L, bs, out, ob0, res);
+    bin_reserve<LDS, NB>(L, bs, out, ob0, res, !FULL);
 #pragma unroll
-    for (int j = 0; j < kPosPerLane; j++)  // sorted position goes into bits 19..30 of tle
-      if (vmask & (1u << j)) tle[j] |= bin_rank<LDS>(L, (tle[j] >> 8) & 0x7ffu) << 19;
+    for (int j = 0; j < kPosPerLane; j++) {  // sorted position goes into bits 12..24 of tle (FULL: 12..23)
+      tle[j] |= bin_rank<LDS>(L, tle[j] & 0xfffu) << 12;
+      // four returning atomics in flight, then their results are folded into tle (the opaque
+      // statement also keeps the compiler from holding on to the bin index for the placement:
+      // it spilled sixteen of them)
+#if MCX_RANK_GROUP == 4
+      if ((j & 3) == 3) asm volatile("" : "+v"(tle[j - 3]), "+v"(tle[j - 2]), "+v"(tle[j - 1]), "+v"(tle[j]));
+#elif MCX_RANK_GROUP == 8
+      if ((j & 7) == 7) asm volatile("" : "+v"(tle[j - 7]), "+v"(tle[j - 6]), "+v"(tle[j - 5]), "+v"(tle[j - 4]), "+v"(tle[j - 3]), "+v"(tle[j - 2]), "+v"(tle[j - 1]), "+v"(tle[j]));
+#endif
+    }
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
-        if (vmask & (1u << j))
-          bin_place<W, FULL, LDS>(L, round, tle[j] >> 19, (tle[j] >> 8) & 0x7ffu, tk[j], tle[j] & 0xffu);
+        bin_place<W, FULL, LDS>(L, round, FULL ? (tle[j] >> 12) & 0xfffu : tle[j] >> 12, tle[j] & 0xfffu, tk[j], tle[j] >> 24);
       bin_writeout<W, ONECOL, FULL, SH, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
     }
   }
@@ -594,7 +716,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
         const uint32_t lbq = lbq_of(isink.t);
         const Kmer<W> key = tk[q];
         const Kmer<W> qq = key_quot<W>(key, lbq, r);
-        const uint32_t G = r ^ (region_mix<W>(qq) & ((1u << lbq) - 1u));
+        const uint32_t G = r ^ mix_g(region_mix<W>(qq), lbq);
         hb = 0;
         loc[q] = G & lmask;
         tk[q] = tuple_pack<W>(qq, ev[q]);
@@ -1013,8 +1135,8 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
       e = (uint32_t)(tp.w[0] >> 56);
       const Kmer<W> qq = tuple_q<W>(tp);
       const uint32_t m = region_mix<W>(qq);
-      key = key_unquot<W>(qq, lbq_of(t), ((t.part << t.lb1) | region) ^ (m & ((1u << lbq_of(t)) - 1u)));
-      bucket = (m >> lbq_of(t)) & (Sub<W>::kBuckets - 1);
+      key = key_unquot<W>(qq, lbq_of(t), ((t.part << t.lb1) | region) ^ mix_g(m, lbq_of(t)));
+      bucket = mix_bucket(m, lbq_of(t), Sub<W>::kBuckets);
     };
     auto apply_slow = [&](const Kmer<W> &key, uint32_t bucket, uint32_t e) {
       if (!lds_apply<W>(lds, key, bucket, e, n_novel, full))  // sub-table full: overflow area, in HBM

@@ -77,11 +77,11 @@ template <int W, bool ONECOL> __device__ __forceinline__ uint64_t *val_ptr_t(con
 // Table addressing: a quotient hash; Lookup3 picks the sub-table and the bucket
 // ---------------------------------------------------------------------------
 // key = (q << lbq) | r with lbq = lb1 + lbo.
-//     m       = mix(q)                           upper half of q times an odd constant (5 instructions)
-//     G       = r ^ (m & (2^lbq - 1))            one Feistel round: uniform whatever r is
+//     m       = mix(q)                           folded q times an odd constant (2 instructions)
+//     G       = r ^ (m >> (32 - lbq))            one Feistel round: uniform whatever r is
 //     owner   = G >> lb1                         shard (GPU) that holds the key: a hash prefix
 //     region  = G & (2^lb1 - 1)                  region of that shard's table
-//     bucket  = (m >> lbq) & 1023                start bucket inside the sub-table
+//     bucket  = (m >> (22 - lbq)) & 1023         start bucket inside the sub-table
 // and with b = second result word of lookup3(q) (the reference's bklk3 hash):
 //     sub     = region * spb + mulhi(b, spb)     sub-table
 // The k-merising kernel (needs the region) and the LDS insert (needs r and the bucket) are bound by
@@ -92,13 +92,27 @@ template <int W, bool ONECOL> __device__ __forceinline__ uint64_t *val_ptr_t(con
 // word (2k - lbq <= 56 bits of q in the top word, edges in bits 56..63) -- mcx_defer.h.
 template <int W> __device__ __host__ __forceinline__ uint32_t region_mix(const Kmer<W> &q)
 {
-  uint64_t x = q.w[0] * 0x9E3779B97F4A7C15ULL;
-  if (W == 2) x ^= q.w[W - 1] * 0xC2B2AE3D27D4EB4FULL;
-  return (uint32_t)(x >> 32);
+  // multiplicative hash of the folded quotient: the quality sits in the HIGH bits of the product
+  // (2 instructions for a one-word key; the upper half of the 64-bit product cost 4)
+  uint32_t x = (uint32_t)q.w[0] ^ (uint32_t)(q.w[0] >> 32);
+  if (W == 2) x ^= ((uint32_t)q.w[W - 1] ^ (uint32_t)(q.w[W - 1] >> 32)) * 0x85EBCA6Bu;
+  return x * 0x9E3779B1u;
+}
+// the lbq bits that are XOR-ed onto the remainder: the top ones (0 when lbq == 0)
+__device__ __host__ __forceinline__ uint32_t mix_g(uint32_t m, uint32_t lbq) { return (uint32_t)(((uint64_t)m << lbq) >> 32); }
+// start bucket inside the sub-table: the bits below them (lbq <= 22 - log2(buckets))
+__device__ __host__ __forceinline__ uint32_t mix_bucket(uint32_t m, uint32_t lbq, uint32_t nbuckets)
+{
+  return (m >> (22u - lbq)) & (nbuckets - 1u);
 }
 template <int W> __device__ __host__ __forceinline__ Kmer<W> key_quot(const Kmer<W> &key, uint32_t lb1 /* bits to split off */, uint32_t &r)
 {
   Kmer<W> q = key;
+  if (W == 1) {  // (no special case for lb1 == 0: the mask is empty and the shift is by 0)
+    r = (uint32_t)key.w[0] & ((1u << lb1) - 1u);
+    q.w[0] = key.w[0] >> lb1;
+    return q;
+  }
   r = 0;
   if (lb1) {
     r = (uint32_t)key.w[W - 1] & ((1u << lb1) - 1u);
@@ -127,10 +141,10 @@ template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t
   kmer_hash<W>(q, 0, &b);
   const uint32_t lbq = lbq_of(t), m = region_mix<W>(q);
   TableAddr a;
-  a.G = r ^ (m & ((1u << lbq) - 1u));
+  a.G = r ^ mix_g(m, lbq);
   a.region = a.G & ((1u << t.lb1) - 1u);
   a.sub = a.region * t.spb + __umulhi(b, t.spb);
-  a.bucket = (m >> lbq) & (Sub<W>::kBuckets - 1);
+  a.bucket = mix_bucket(m, lbq, Sub<W>::kBuckets);
   return a;
 }
 // shard (GPU) that holds `key` in a table split over 2^lbo shards
@@ -138,12 +152,12 @@ template <int W> __device__ __forceinline__ uint32_t key_owner(const TableView &
 {
   uint32_t r;
   const Kmer<W> q = key_quot<W>(key, lbq_of(t), r);
-  return (r ^ (region_mix<W>(q) & ((1u << lbq_of(t)) - 1u))) >> t.lb1;
+  return (r ^ mix_g(region_mix<W>(q), lbq_of(t))) >> t.lb1;
 }
 // remainder of a key of THIS shard from its quotient and its region
 template <int W> __device__ __forceinline__ uint32_t r_of(const TableView &t, uint32_t region, const Kmer<W> &q)
 {
-  return ((t.part << t.lb1) | region) ^ (region_mix<W>(q) & ((1u << lbq_of(t)) - 1u));
+  return ((t.part << t.lb1) | region) ^ mix_g(region_mix<W>(q), lbq_of(t));
 }
 template <int W> __device__ __forceinline__ uint64_t key_slot(const TableView &t, const Kmer<W> &key)
 {

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(Super
           uint32_t r;
           const uint32_t lbq = lbq_of(isink.t);
           const Kmer<W> qq = key_quot<W>(key, lbq, r);
-          const uint32_t G = r ^ (region_mix<W>(qq) & ((1u << lbq) - 1u));
+          const uint32_t G = r ^ mix_g(region_mix<W>(qq), lbq);
           const uint32_t local = G & ((1u << isink.t.lb1) - 1u);
           tk[j] = tuple_pack<W>(qq, e);
           tle[j] = local << 8;

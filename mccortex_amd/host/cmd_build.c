@@ -799,7 +799,7 @@ int ctx_build(int argc, char **argv)
   if (fflush(fout) != 0) die("Cannot write to file");
   struct stat ost;
   if (fout != stdout && fstat(fileno(fout), &ost) == 0 && S_ISREG(ost.st_mode)) {
-    pwrite_sink_ctx pc = {fileno(fout), (off_t)hdr, (int)(nthreads < 2 ? 2 : nthreads > 8 ? 8 : nthreads), false};
+    pwrite_sink_ctx pc = {fileno(fout), (off_t)hdr, (int)(nthreads < 2 ? 2 : nthreads > 16 ? 16 : nthreads), false};
     mcx_check(mcx_graph_export(g, sort_kmers ? 1 : 0, pwrite_sink, &pc), "export");
     if (fseeko(fout, pc.off, SEEK_SET) != 0) die("Cannot write to file");
   } else {
