@@ -76,6 +76,7 @@ struct mcx_graph {
   hipStream_t stream = nullptr;
   TableView t{};
   uint64_t table_bytes = 0;
+  uint64_t touch_bytes = 0;  // TableView::touch
   Counters *d_ctr = nullptr;
   Counters *h_ctr = nullptr;  // pinned
   // host staging (double buffered)
@@ -252,7 +253,10 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   }
   CREATE_TRY(hipMalloc((void **)&g->d_ctr, sizeof(Counters)));
   CREATE_TRY(hipHostMalloc((void **)&g->h_ctr, sizeof(Counters), hipHostMallocDefault));
+  g->touch_bytes = (1 + ((g->t.nmain >> sub_shift_for_words(g->W)) + 31) / 32) * 4;
+  CREATE_TRY(hipMalloc((void **)&g->t.touch, g->touch_bytes));
   CREATE_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
+  CREATE_TRY(hipMemsetAsync(g->t.touch, 0, g->touch_bytes, g->stream));
   CREATE_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
   CREATE_TRY(hipStreamSynchronize(g->stream));
 #undef CREATE_TRY
@@ -274,6 +278,7 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
   free_defer(g);
   for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (g->t.rec) (void)hipFree(g->t.rec);
+  if (g->t.touch) (void)hipFree(g->t.touch);
   if (g->d_ctr) (void)hipFree(g->d_ctr);
   if (g->d_readstrt) (void)hipFree(g->d_readstrt);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
@@ -291,6 +296,7 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
+  HIP_TRY(hipMemsetAsync(g->t.touch, 0, g->touch_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
   if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->l2_regions * g->subs_per_bin * 8, g->stream));

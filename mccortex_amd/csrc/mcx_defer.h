@@ -294,6 +294,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
           full = 2;
         }
       } else {                      // ... lock-free insert into the HBM table
+        table_mark_written(isink.t);
         const uint32_t region = bs.mode == BIN_GROUP ? b : region_of_seg;
         const Kmer<W> key = key_unquot<W>(qq, lbq, r_of<W>(isink.t, region, qq));
         const uint64_t slot = key_slot<W>(isink.t, key);
@@ -348,6 +349,7 @@ template <int W, bool ONECOL>
 __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, Kmer<W> key, uint32_t e,
                                             uint32_t &novel, uint32_t &full)
 {
+  table_mark_written(isink.t);
   const uint64_t slot = key_slot<W>(isink.t, key);
   const uint64_t cur = *key_ptr_t<W, ONECOL>(isink.t, slot);
   probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
           okm &= ~(1u << q);
         }
       } else {        // packed tuple of a known region -> sub-table inside the region
-        kmer_hash<W>(tuple_q<W>(tk[q]), 0, &hb);
+        hb = sub_hash<W>(tuple_q<W>(tk[q]));
         loc[q] = __umulhi(hb, isink.t.spb);
       }
       if (loc[q] >= bs.nlocal) loc[q] = bs.nlocal - 1;  // cannot happen for well-formed bins
@@ -992,6 +994,19 @@ __device__ __forceinline__ void slice_load(const TableView &t, uint32_t sub, uin
   }
 }
 
+// The same, unless the sub-table still holds only zeros (TableView::touch): then nothing is read.
+template <int W, bool ONECOL, int T>
+__device__ __forceinline__ void slice_fetch(const TableView &t, uint32_t sub, uint32_t col, int tid, SliceRegs &v, bool zeros_known)
+{
+  if (zeros_known && !((t.touch[1 + (sub >> 5)] >> (sub & 31u)) & 1u)) {  // (uniform)
+#define MCX_Z(m) { v.m.x = 0; v.m.y = 0; }
+    MCX_Z(a) MCX_Z(b) MCX_Z(c) MCX_Z(d) MCX_Z(e) MCX_Z(f) MCX_Z(g) MCX_Z(h)
+#undef MCX_Z
+    return;
+  }
+  slice_load<W, ONECOL, T>(t, sub, col, tid, v);
+}
+
 // registers -> LDS image: slots of W key words + this colour's value word
 template <int W, bool ONECOL, int T>
 __device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, const SliceRegs &v)
@@ -1086,7 +1101,10 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
   };
   uint32_t bi = next_bin(blockIdx.x);
   SliceRegs v{};
-  if (bi < nsub) slice_load<W, ONECOL, kLdsThreads>(t, sub0 + bi, col, tid, v);
+  // sub-tables that nothing has written since the table was zeroed are not read (the first flush
+  // of a build reads none of the table: 16 of its 50 bytes per slot)
+  const bool zeros_known = t.touch && t.touch[0] == 0;
+  if (bi < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + bi, col, tid, v, zeros_known);
   while (bi < nsub) {
     const uint32_t sub = sub0 + bi;
     uint64_t n = bins.counts[bi];
@@ -1173,7 +1191,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
       Kmer<W> ta[kLdsBatch], tb[kLdsBatch];
       load_batch(0, ta);
       load_batch(kStep, tb);
-      if (decltype(has_next)::value) slice_load<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v);
+      if (decltype(has_next)::value) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v, zeros_known);
       for (uint64_t j0 = 0; j0 < n; j0 += 2 * kStep) {
         apply_batch(j0, ta);
         load_batch(j0 + 2 * kStep, ta);
@@ -1187,7 +1205,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
        // batch does not wait for the 64 KiB behind it
       Kmer<W> tk[kLdsBatch];
       load_batch(0, tk);
-      if (nb < nsub) slice_load<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v);
+      if (nb < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v, zeros_known);
       apply_batch(0, tk);
     }
     for (uint64_t j0 = kStep; j0 < n; j0 += kStep) {
@@ -1213,6 +1231,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
     }
 #endif
     slice_store<W, ONECOL, kLdsThreads>(t, sub, col, tid, lds);
+    if (tid == 0 && t.touch) atomicOr(&t.touch[1 + (sub >> 5)], 1u << (sub & 31u));
     bi = nb;
   }
   block_add(&ctr->novel, n_novel);

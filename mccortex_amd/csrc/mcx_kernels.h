@@ -57,7 +57,17 @@ struct TableView {
   uint32_t VS;       // words between the values of consecutive slots (W + 1, or 1)
   uint64_t *val;     // value word of (slot 0, colour 0)
   uint64_t VC;       // words between the value arrays of consecutive colours (0, or nslots)
+  // touch[0] != 0: some kernel other than the LDS insert may have written hash-addressed slots
+  // since the table was zeroed; touch[1 + s / 32] bit s % 32: the LDS insert has written sub-table
+  // s.  While touch[0] == 0, a sub-table whose bit is clear still holds only zeros and the LDS
+  // insert does not read it (the first flush of a build reads none of the table).
+  uint32_t *touch;
 };
+// Called by every kernel that writes hash-addressed slots outside the LDS insert.
+__device__ __forceinline__ void table_mark_written(const TableView &t)
+{
+  if (t.touch) t.touch[0] = 1u;
+}
 __device__ __forceinline__ uint64_t *key_ptr(const TableView &t, uint64_t slot) { return t.rec + slot * t.KS; }
 __device__ __forceinline__ uint64_t *val_ptr(const TableView &t, uint64_t slot, uint32_t col)
 {
@@ -82,11 +92,10 @@ template <int W, bool ONECOL> __device__ __forceinline__ uint64_t *val_ptr_t(con
 //     owner   = G >> lb1                         shard (GPU) that holds the key: a hash prefix
 //     region  = G & (2^lb1 - 1)                  region of that shard's table
 //     bucket  = (m >> (22 - lbq)) & 1023         start bucket inside the sub-table
-// and with b = second result word of lookup3(q) (the reference's bklk3 hash):
+// and with b = sub_hash(q), a second multiplicative hash of q:
 //     sub     = region * spb + mulhi(b, spb)     sub-table
-// The k-merising kernel (needs the region) and the LDS insert (needs r and the bucket) are bound by
-// their instruction counts; the split kernel, which needs the sub-table, is HBM-bound and has VALU
-// to spare for the 24 instructions of Lookup3.
+// All three build kernels are bound by their instruction counts (60-70 % VALU-busy at 4 waves
+// per SIMD), so each hash is as cheap as uniformity allows.
 // Given (owner, region), r = G ^ (mix(q) & mask) is recoverable from q alone, so a k-mer occurrence
 // that has been binned by region travels as q plus its edge byte in ONE 64-bit word per key
 // word (2k - lbq <= 56 bits of q in the top word, edges in bits 56..63) -- mcx_defer.h.
@@ -97,6 +106,20 @@ template <int W> __device__ __host__ __forceinline__ uint32_t region_mix(const K
   uint32_t x = (uint32_t)q.w[0] ^ (uint32_t)(q.w[0] >> 32);
   if (W == 2) x ^= ((uint32_t)q.w[W - 1] ^ (uint32_t)(q.w[W - 1] >> 32)) * 0x85EBCA6Bu;
   return x * 0x9E3779B1u;
+}
+// Second hash of the quotient: picks the sub-table inside the region (through mulhi: its top bits
+// count).  A different fold of the words than region_mix's, two multiplications with a shift-xor
+// between them: 7 instructions.  (Until round 2 this was the second word of Lookup3 -- 30 of the
+// split kernel's 78 instructions per tuple, and that kernel is not the HBM-bound one it was when
+// the choice was made.  Lookup3 still decides what it decides in the reference's terms: the shard
+// of a key in the hash-prefix exchange, mcx_key_owner, and it addresses the overflow area.)
+template <int W> __device__ __host__ __forceinline__ uint32_t sub_hash(const Kmer<W> &q)
+{
+  uint32_t x = (uint32_t)q.w[0] + (uint32_t)(q.w[0] >> 32) * 0xC2B2AE35u;
+  if (W == 2) x += (uint32_t)q.w[W - 1] * 0x27D4EB2Fu + (uint32_t)(q.w[W - 1] >> 32) * 0x165667B1u;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 15;
+  return x * 0x2C1B3C6Du;
 }
 // the lbq bits that are XOR-ed onto the remainder: the top ones (0 when lbq == 0)
 __device__ __host__ __forceinline__ uint32_t mix_g(uint32_t m, uint32_t lbq) { return (uint32_t)(((uint64_t)m << lbq) >> 32); }
@@ -137,8 +160,7 @@ struct TableAddr { uint32_t G, region, sub, bucket; };
 // address from the quotient q and remainder r (r = low lbq bits of the key)
 template <int W> __device__ __forceinline__ TableAddr addr_of(const TableView &t, const Kmer<W> &q, uint32_t r)
 {
-  uint32_t b;
-  kmer_hash<W>(q, 0, &b);
+  const uint32_t b = sub_hash<W>(q);
   const uint32_t lbq = lbq_of(t), m = region_mix<W>(q);
   TableAddr a;
   a.G = r ^ mix_g(m, lbq);
@@ -377,6 +399,7 @@ __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t
                                                       uint32_t nmap, uint32_t must_exist, int mask_col, int kmer_size,
                                                       Counters *ctr, RecordStats *st)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   const uint32_t rec_bytes = 8u * W + 5u * file_ncols;
   uint32_t novel = 0, full = 0, loaded = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrecs; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -683,6 +706,7 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t h2, uint32_t nparts)
 template <int W, bool ONECOL, bool PK>
 __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(isink.t);
   __shared__ uint32_t s_code[kChunks + 4];
   __shared__ uint32_t s_inv[kChunks / 2 + 4];
 
@@ -790,6 +814,7 @@ template <int W, bool ONECOL>
 __global__ __launch_bounds__(kThreads) void k_insert_tuples(InsertSink<W, ONECOL> sink, const uint64_t *keys,
                                                             const uint8_t *edges, uint64_t n, Counters *ctr)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(sink.t);
   uint32_t n_novel = 0, full = 0;
   const uint64_t stride = (uint64_t)gridDim.x * kThreads;
   for (uint64_t i0 = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i0 < n; i0 += stride * kBatch) {
@@ -988,6 +1013,7 @@ __global__ void k_pcr_starts(TableView t, const uint8_t *bases, const uint8_t *q
                              int k, uint32_t qcut1, uint32_t qcut2, uint32_t pmask, uint32_t hcut,
                              uint32_t *first, uint64_t *node_of, Counters *ctr)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nreads) return;
   const uint32_t qcut = ((uint32_t)r & pmask) ? qcut2 : qcut1;
@@ -1133,6 +1159,7 @@ template <int W>
 __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
                                    uint64_t nreads, int k, uint32_t qcut, uint32_t hcut, uint32_t col, Counters *ctr)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nreads) return;
   const uint8_t *seq = bases + off[r];
@@ -1184,6 +1211,7 @@ __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint
 __global__ __launch_bounds__(256) void k_intersect_finish(TableView t, uint32_t ncols_vis, uint32_t hidden, Counters *ctr,
                                                           unsigned long long *removed)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   unsigned long long gone = 0;
   for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < t.nslots; slot += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t *r = key_ptr(t, slot);

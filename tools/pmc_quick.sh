@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-extras"
+ARGS="--steps ${STEPS:-4} --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_VALU -d $OUT/sq -o sq --output-format csv -- python $REPO/bench.py $ARGS > $OUT/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM -d $OUT/lds -o lds --output-format csv -- python $REPO/bench.py $ARGS > $OUT/lds.log 2>&1
 python - $OUT ${KERNEL:-k_stream_bin} <<'PY'
