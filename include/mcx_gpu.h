@@ -98,6 +98,9 @@ int mcx_graph_reset(mcx_graph *g);
  *   "must_exist"   1: mcx_graph_add_reads only updates k-mers that are already in the graph and adds
  *                  an edge only between consecutive k-mers that were both found
  *                  (BuildGraphTask.prefs.must_exist_in_graph, src/tools/build_graph.c:99-150)
+ *   "prepare"      allocate now what the first mcx_graph_add_reads otherwise allocates (pinned staging
+ *                  buffers, the partition workspace): lets a host that parses with other threads hide
+ *                  ~0.1 s behind the parse of its first batch
  *   "profile"      1: time every kernel launch with HIP events (see mcx_graph_profile) */
 int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value);
 /* "kernel calls total_ms" per line for the launches recorded since "profile" was set. */

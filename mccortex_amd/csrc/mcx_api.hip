@@ -686,6 +686,8 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
   return MCX_OK;
 }
 
+static int ensure_stage(mcx_graph *g);
+
 extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value)
 {
   if (g && key && g->as_group) {
@@ -733,6 +735,11 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     g->must_exist = value != 0;
     if (g->must_exist) g->defer = false;
     return MCX_OK;
+  }
+  if (!strcmp(key, "prepare")) {  // allocate now what the first mcx_graph_add_reads would: pinned staging, bins
+    int rc = ensure_stage(g);
+    if (rc == MCX_OK && g->defer && !g->must_exist) rc = ensure_defer(g);
+    return rc;
   }
   if (!strcmp(key, "grid_stream")) { g->grid_stream = (int)value; return MCX_OK; }
   if (!strcmp(key, "grid_split")) { g->grid_split = (int)value; return MCX_OK; }

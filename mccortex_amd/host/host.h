@@ -73,10 +73,12 @@ int fq_offset_from_range(int qmin, int qmax);
 int fq_offset_probe(const char *path);
 
 /* Multi-threaded parse of an uncompressed regular file (par_ingest.c): `submit` is called on the
- * calling thread for every batch.  Returns 0 = done, 1 = not suitable (nothing submitted: use the
- * sequential parser), 2 = irregular record met after submission began. */
+ * calling thread for every batch; `started` (may be NULL) once, on the calling thread, after the
+ * parser threads have been started and before the first batch is waited for.  Returns 0 = done,
+ * 1 = not suitable (nothing submitted: use the sequential parser), 2 = irregular record met after
+ * submission began. */
 int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, size_t batch_bases,
-               void (*submit)(void *arg, read_batch *b, int fq_offset_guess), void *arg);
+               void (*submit)(void *arg, read_batch *b, int fq_offset_guess), void (*started)(void *arg), void *arg);
 
 /* ---- .ctx header: GraphInfo arithmetic, writer, reader
  * (src/basic/graph_info.c, src/graph/graph_writer.c:11-110, src/graph/graph_file_reader.c:78-340,

@@ -18,8 +18,7 @@ with open(fq, "wb") as f:
         rec.cpu().numpy().tofile(f); del rec, b
 del genome; torch.cuda.empty_cache()
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mccortex_amd", "bin", "mccortex31")
-for env, t in [({}, "32"), ({}, "32"), ({"MCX_PAR_BATCH": str(8 << 20)}, "32"), ({"MCX_PAR_BATCH": str(64 << 20)}, "32"), ({}, "8"), ({}, "64"),
-               ({"MCX_PACKED": "0"}, "32"), ({"MCX_KEEP_DESTROY": "1"}, "32")]:
+for env, t in [({}, "32"), ({}, "32"), ({}, "32"), ({}, "16"), ({}, "48"), ({"MCX_STAGE_THREADS": "8"}, "32")]:
     t0 = time.perf_counter()
     p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "1G", "-t", t, "--sort", "-s", "x", "--seq", fq, os.path.join(out, "o.ctx")],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MCX_TIMING="1", **env))
