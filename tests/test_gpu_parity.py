@@ -469,3 +469,55 @@ def test_packed_device_stream(mcx, orc, k, defer):
     assert g.nkmers == og.nkmers
     assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
     g.close()
+
+
+def _structured_kmer_reads(k, seed):
+    """k-mers a weak hash places badly: families that differ only in their last 9 bases, only in
+    their first 9 bases, and tandem repeats of short periods -- one k-base read per k-mer."""
+    rng = np.random.default_rng(seed)
+    fams = []
+    idx = np.arange(1 << 18, dtype=np.uint64)
+    var = np.stack([(idx >> np.uint64(2 * i)) & np.uint64(3) for i in range(9)], axis=1).astype(np.uint8)  # all 4^9 tails
+    for fam in range(2):
+        fixed = rng.integers(0, 4, k - 9, dtype=np.uint8)
+        rows = np.empty((len(idx), k), np.uint8)
+        if fam == 0:
+            rows[:, :k - 9] = fixed; rows[:, k - 9:] = var   # common prefix, every suffix
+        else:
+            rows[:, 9:] = fixed; rows[:, :9] = var           # common suffix, every prefix
+        fams.append(rows)
+    per = []
+    for period in range(1, 13):                              # tandem repeats, a few mutations each
+        for _ in range(2000):
+            unit = rng.integers(0, 4, period, dtype=np.uint8)
+            row = np.tile(unit, k // period + 1)[:k].copy()
+            pos = rng.integers(0, k, 2)
+            row[pos] = rng.integers(0, 4, 2)
+            per.append(row)
+    fams.append(np.array(per, np.uint8))
+    rows = np.concatenate(fams)
+    bases = np.frombuffer(b"ACGT", np.uint8)[rows].reshape(-1)
+    offs = np.arange(len(rows) + 1, dtype=np.uint64) * k
+    return bases, offs
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_structured_keys_spread_over_the_sub_tables(mcx, orc, k):
+    """The table's own hashes (region / bucket: one multiplication of the folded quotient; sub-table:
+    sub_hash) must spread keys that differ in few bits: 0.55 M such k-mers into 2^20 slots (256
+    sub-tables of 4096).  A sub-table 1.5 x over its share would spill, the overflow area holds 3 %
+    of the table: a skewed hash ends in "Hash table is full"."""
+    bases, offs = _structured_kmer_reads(k, seed=9)
+    og = orc.Graph(k, 1, 1 << 22)
+    og.add_reads(0, bases, offs)
+    assert og.nkmers > 500_000
+    # 0.62 M slots: load ~0.85 of the hash-addressed slots
+    cap = 5 << 17
+    for defer in (1, 0):
+        g = mcx.Graph(k, 1, cap)
+        g.configure("defer", defer)
+        g.add_reads(0, bases, offs)
+        g.sync()
+        assert g.nkmers == og.nkmers
+        assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+        g.close()
