@@ -147,6 +147,10 @@ template <int W> __device__ __host__ __forceinline__ Kmer<W> key_quot(const Kmer
 template <int W> __device__ __host__ __forceinline__ Kmer<W> key_unquot(const Kmer<W> &q, uint32_t lb1, uint32_t r)
 {
   Kmer<W> key = q;
+  if (W == 1) {  // (no special case for lb1 == 0: a shift by 0 and r == 0)
+    key.w[0] = (q.w[0] << lb1) | r;
+    return key;
+  }
   if (lb1) {
     key.w[0] = q.w[0] << lb1;
     if (W == 2) { key.w[0] |= q.w[W - 1] >> (64 - lb1); key.w[W - 1] = q.w[W - 1] << lb1; }
