@@ -126,6 +126,9 @@ template <int W, int NB, bool FULL> struct BinLds {
 // addresses, masks) is then recomputed per tile in an instruction or two -- hoisted out of the
 // loop these values were spilled to scratch, and a scratch reload waits for the next tile's
 // prefetch (vmcnt counts in order).
+// Used by k_stream_bin's tile loop only.  (In the write-out loop of bin_writeout the same trick
+// produced a kernel that faults -- `tools/`-built variant, round 2; the cause was not found, so the
+// shared helpers keep reading threadIdx.x.)
 __device__ __forceinline__ uint32_t tid_now()
 {
   uint32_t t = threadIdx.x;
