@@ -755,7 +755,22 @@ int ctx_build(int argc, char **argv)
     else if (bt->remove_pcr) { load_task_pcr(g, bt); prc = 0; }
     else if (nthreads > 1 && strcmp(bt->path, "-") != 0)
       prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, getenv("MCX_PAR_BATCH") ? (size_t)atol(getenv("MCX_PAR_BATCH")) : PAR_BATCH_BASES, submit_batch, t == 0 ? prepare_graph : NULL, &sc);
-    if (prc == 2) die("Irregular %s record in %s (multi-line FASTQ?): rerun with -t 1", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
+    if (prc == 2) {
+      /* A record the range parsers do not handle (multi-line FASTQ) beyond the part of the file that was
+       * probed: batches of this file are in the graph already.  When nothing else is (first input, no
+       * --graph), empty the graph and read the file again with the sequential parser; otherwise there
+       * is no way back. */
+      if (t == 0 && ngfiles == 0 && ngisec == 0) {
+        warn("Irregular %s record in %s: reading the file again with one parser thread", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
+        mcx_check(mcx_graph_reset(g), "reset");
+        memset(&bt->stats, 0, sizeof(bt->stats));
+        memset(&prev, 0, sizeof(prev));
+        sc.fq_abs = 0;
+        prc = 1;
+      } else {
+        die("Irregular %s record in %s (multi-line FASTQ?): rerun with -t 1", bt->fmt == SEQ_FMT_FASTQ ? "FASTQ" : "sequence", bt->path);
+      }
+    }
     if (prc == 1) {
       seq_in *in = seq_in_open(bt->path);
       if (!in) die("Cannot open -1 file: %s", bt->path);

@@ -242,6 +242,24 @@ def test_parallel_ingest_matches_sequential_and_oracle(built, orc, tmp_path):
     rc, _, err = run(31, "build", "-f", "-t", "4", "-k", "31", "-n", "4M", "-S", "-s", "s", "--seq", str(ml), out)
     assert rc == 0, err
     assert open(out, "rb").read() == want
+    # a regular head (4-line records beyond the 4 MB that are probed), wrapped records after it: the
+    # range parsers give up after batches were submitted; the graph is emptied and the file read again
+    head = []
+    for i in range(len(o) - 1):
+        r = bytes(b[int(o[i]):int(o[i + 1])])
+        head.append(b"@h%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    late = tmp_path / "late.fq"
+    late.write_bytes(b"".join(head) + b"".join(recs))
+    assert sum(map(len, head)) > (5 << 20)
+    og = orc.Graph(31, 1, 1 << 22)
+    og.set_sample(0, "s")
+    for _ in range(2):
+        og.update_stats(0, og.add_reads(0, b, o))
+    rc, _, err = run(31, "build", "-f", "-t", "4", "-k", "31", "-n", "4M", "-S", "-s", "s", "--seq", str(late), out)
+    assert rc == 0, err
+    assert "reading the file again with one parser thread" in err
+    assert open(out, "rb").read() == og.ctx_bytes(True)
+    assert "SE reads: 60,000" in err
 
 
 @pytest.mark.gpu
