@@ -140,6 +140,9 @@ struct mcx_graph {
   uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 (replica, bin) segment / per L2 (sub-table) bin
   uint32_t rep1 = 8;            // replicas of every L1 bin (one per XCD)
   uint64_t *l1_keys = nullptr, *l2_keys = nullptr;  // packed tuples: W words each
+  uint64_t l2_off = 0;            // first sub-table bin the next split / insert launch uses (flush overlap: two halves)
+  hipStream_t stream2 = nullptr;  // flush overlap: the LDS insert of group g runs beside the split of group g + 1
+  hipEvent_t ev_split[2] = {nullptr, nullptr}, ev_ins[2] = {nullptr, nullptr};
   unsigned long long *l1_cnt = nullptr, *l2_cnt = nullptr;
   uint64_t pending = 0;         // upper bound of tuples sitting in the L1 bins
   uint64_t pending_l2 = 0;      // tuples already split into the sub-table bins (sharded receive path)
@@ -269,6 +272,8 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   // one colour: records [key words, value]; several: key array, then one value array per colour
   g->t.max_probe = (uint32_t)sub_slots;  // a probe sequence never leaves its sub-table
   { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
+  { const char *e = getenv("MCX_GRID_SPLIT"); if (e) g->grid_split = atoi(e); }    // experiments (flush overlap)
+  { const char *e = getenv("MCX_GRID_INSERT"); if (e) g->grid_insert = atoi(e); }
   g->table_bytes = slots * g->t.S * 8;
 
   hipDeviceProp_t prop;
@@ -324,6 +329,10 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
   for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (g->t.rec) (void)hipFree(g->t.rec);
   if (g->t.touch) (void)hipFree(g->t.touch);
+  if (g->stream2) {
+    (void)hipStreamDestroy(g->stream2);
+    for (int i = 0; i < 2; i++) { (void)hipEventDestroy(g->ev_split[i]); (void)hipEventDestroy(g->ev_ins[i]); }
+  }
   if (g->d_ctr) (void)hipFree(g->d_ctr);
   if (g->d_readstrt) (void)hipFree(g->d_readstrt);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
@@ -502,7 +511,7 @@ template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int 
   static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
   bool &once = once_dev[g->device & 63];
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
-  BinOut bins{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
+  BinOut bins{g->l2_keys + g->l2_off * g->cap2 * W, nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
   SpanGuard sp(g, "k_lds_insert");
   hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nsub, (uint64_t)(g->grid_insert ? g->grid_insert : g->grid * 4))),
                      dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, sub0, nsub, g->d_ctr);
@@ -549,6 +558,12 @@ static int ensure_l2(mcx_graph *g, uint32_t regions)
   HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, nb * 8, g->stream));
   g->l2_regions = regions;
   return MCX_OK;
+}
+
+static bool flush_overlap()
+{
+  static const bool on = [] { const char *e = getenv("MCX_FLUSH_OVERLAP"); return e && atoi(e) != 0; }();
+  return on;
 }
 
 // regions per flush group: enough sub-tables for one full wave of LDS-insert workgroups, few
@@ -610,7 +625,7 @@ static int ensure_defer(mcx_graph *g)
     const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1;
     const bool ok = hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W) == hipSuccess &&
                     hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * g->rep1 * 8) == hipSuccess &&
-                    ensure_l2(g, flush_group(g)) == MCX_OK;
+                    ensure_l2(g, flush_overlap() ? std::min<uint32_t>(2 * flush_group(g), g->b1) : flush_group(g)) == MCX_OK;
     if (ok) break;
     free_defer(g);
     (void)hipGetLastError();  // clear the sticky out-of-memory error
@@ -628,18 +643,48 @@ static int flush_deferred(mcx_graph *g)
   // tuples that were split on arrival occupy bins of all regions: everything goes through them
   const uint32_t G = g->pending_l2 ? g->b1 : std::min(flush_group(g), g->l2_regions);
   if (g->pending_l2 && g->l2_regions < g->b1) return fail(MCX_ERR_ARG, "internal: split tuples without bins");
-  for (uint32_t r0 = 0; r0 < g->b1; r0 += G) {
+  // Flush overlap (MCX_FLUSH_OVERLAP=1, experiment): the split is HBM-bound, the LDS insert bound by
+  // instruction issue; with two halves of sub-table bins the insert of group g runs on a second
+  // stream beside the split of group g + 1 (grids sized to share the CUs: grid_split / grid_insert).
+  const bool overlap = flush_overlap() && g->pending && !g->pending_l2 && g->l2_regions >= 2 * G && G < g->b1;
+  hipStream_t s1 = g->stream;
+  if (overlap) {
+    if (!g->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+      for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_split[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_ins[i], hipEventDisableTiming));
+      }
+    }
+    HIP_TRY(hipEventRecord(g->ev_split[0], s1));  // the second stream starts behind everything queued so far
+    HIP_TRY(hipStreamWaitEvent(g->stream2, g->ev_split[0], 0));
+  }
+  uint32_t gi = 0;
+  for (uint32_t r0 = 0; r0 < g->b1; r0 += G, gi++) {
     const uint32_t ng = std::min(G, g->b1 - r0);
+    const int hb = overlap ? (int)(gi & 1u) : 0;
+    g->l2_off = (uint64_t)hb * G * g->subs_per_bin;
+    if (overlap && gi >= 2) HIP_TRY(hipStreamWaitEvent(s1, g->ev_ins[hb], 0));  // this half's previous insert has emptied it
     if (g->pending) {
       TupleIn in{g->l1_keys + (uint64_t)r0 * g->cap1 * g->W, nullptr, g->l1_cnt + r0, g->cap1, ng * g->rep1, ng, g->b1};
       BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, ng * g->subs_per_bin, ng, 0, r0};
-      BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
+      BinOut out{g->l2_keys + g->l2_off * g->cap2 * g->W, nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
       DISPATCH_WC(g, launch_split_regions, g, in, g->pending_colour, bs, out);
       HIP_TRY(hipGetLastError());
     }
+    if (overlap) {
+      HIP_TRY(hipEventRecord(g->ev_split[hb], s1));
+      HIP_TRY(hipStreamWaitEvent(g->stream2, g->ev_split[hb], 0));
+      g->stream = g->stream2;
+    }
     DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour, r0 * g->subs_per_bin, ng * g->subs_per_bin);
+    g->stream = s1;
     HIP_TRY(hipGetLastError());
+    if (overlap) HIP_TRY(hipEventRecord(g->ev_ins[hb], g->stream2));
   }
+  g->l2_off = 0;
+  if (overlap)
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(s1, g->ev_ins[i], 0));
   if (g->pending) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
   g->pending = 0;
   g->pending_l2 = 0;
