@@ -521,3 +521,26 @@ def test_structured_keys_spread_over_the_sub_tables(mcx, orc, k):
         assert g.nkmers == og.nkmers
         assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
         g.close()
+
+
+def test_untouched_sub_tables_are_not_read_only_while_that_is_safe(mcx, orc):
+    """TableView::touch: the LDS insert skips reading sub-tables nothing has written since the table
+    was zeroed.  Flush, then a direct insert (sets the flag), then another flush: every key of every
+    phase must survive; likewise after a reset."""
+    k = 31
+    parts = [synth.reads(4000, 120, genome_len=150000, seed=s) for s in (21, 22, 23)]
+    og = orc.Graph(k, 1, 1 << 22)
+    for b, o in parts:
+        og.add_reads(0, b, o)
+    g = mcx.Graph(k, 1, 1 << 20)
+    for rnd in range(2):
+        g.configure("defer", 1)
+        g.add_reads(0, *parts[0]); g.sync()          # first flush: nothing is read
+        g.configure("defer", 0)
+        g.add_reads(0, *parts[1]); g.sync()          # direct inserts into sub-tables the flush never touched
+        g.configure("defer", 1)
+        g.add_reads(0, *parts[2]); g.sync()          # this flush must read them
+        assert g.nkmers == og.nkmers
+        assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+        g.reset()
+    g.close()
