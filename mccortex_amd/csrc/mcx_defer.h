@@ -69,6 +69,9 @@ struct BinOut {
   uint64_t ov_cap;
 };
 
+#ifndef MCX_RANK_FROM_COUNT
+#define MCX_RANK_FROM_COUNT 1  // k_stream_bin: sorted position = bin offset + what the counting atomic returned
+#endif
 #ifndef MCX_TOP_BARRIER
 #define MCX_TOP_BARRIER 0
 #endif
@@ -431,9 +434,18 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
     const uint64_t Vh = inv_win64(s_inv, pl);
     const uint64_t Vl = (W == 2) ? inv_win64(s_inv, pl + 64) : 0;
     const uint32_t prev_chunk_inv = (s_inv[(pl - 1) >> 5] >> (31 - ((pl - 1) & 31))) & 1u;
-    const uint64_t P0 = tile * kTile + 16ull * (uint64_t)tid;
-    const int j_lo = a.pos_lo > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_lo - P0) : 0;
-    const int j_hi = a.pos_hi > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_hi - P0) : 0;
+    // positions owned by this launch: all 16 of every lane unless the tile straddles an end of the
+    // launch's range (uniform test; the per-lane 64-bit arithmetic cost 25 instructions a tile)
+    uint32_t range = 0xFFFFu;
+    {
+      const uint64_t plo = a.pos_lo, phi = a.pos_hi, T0 = tile * kTile;
+      if (T0 < plo || T0 + kTile > phi) {
+        const uint64_t P0 = T0 + 16ull * (uint64_t)tid;
+        const int j_lo = plo > P0 ? (int)min((uint64_t)kPosPerLane, plo - P0) : 0;
+        const int j_hi = phi > P0 ? (int)min((uint64_t)kPosPerLane, phi - P0) : 0;
+        range = ((0x10000u >> j_lo) - 1u) & ~((0x10000u >> j_hi) - 1u);
+      }
+    }
     // The lane's 16 positions as 16-bit masks, position j at bit 15 - j (base i of the lane's
     // window = bit 63 - i of Vh, then Vl):
     //   ok16   a whole k-mer of valid bases starts at j, and j is owned by this launch
@@ -451,7 +463,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
         if (W == 2) Ml |= Ml << s;
         c += s;
       }
-      const uint32_t range = ((0x10000u >> j_lo) - 1u) & ~((0x10000u >> j_hi) - 1u);
       ok16 = ~(uint32_t)(Mh >> 48) & range;
       // base j + k: bit 127 - k - j of Vh:Vl -> field of 16 starting at bit 112 - k
       const int sh = 112 - k;  // 49..109
@@ -496,6 +507,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
         feed = code_win64(s_code, pl + (uint32_t)k);
       }
       const uint32_t feed32 = (uint32_t)(feed >> 32);  // the bases after the lane's 16 k-mers
+      uint32_t arr_prev = 0;
       const uint32_t key_sh = 64u - 2u * (uint32_t)k;  // one-word keys: left-aligned -> key
       const uint32_t mix_sh = (32u - lbq) & 31u;
 #pragma unroll
@@ -551,7 +563,17 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
           local = (local & valid) | (trash & ~valid);
           tle[j] = local;
         }
+#if MCX_RANK_FROM_COUNT
+        // The counting atomic returns the tuple's arrival index in its bin: with the bin's offset that
+        // IS its sorted position, so the ranking needs no second atomic per tuple.  The result is
+        // folded into tle one position later: its LDS round trip overlaps the next position's work.
+        const uint32_t arr_now = atomicAdd(&L.cnt[local], 1u);
+        if (j > 0) { tle[j - 1] |= arr_prev << 12; asm volatile("" : "+v"(tle[j - 1])); }
+        arr_prev = arr_now;
+        if (j == kPosPerLane - 1) tle[j] |= arr_now << 12;
+#else
         atomicAdd(&L.cnt[local], 1u);
+#endif
         // one position at a time: VALU work gains nothing from interleaving positions, and their
         // temporaries together pushed tuples out to scratch
         if (W == 1) asm volatile("" : "+v"(tle[j]), "+v"(tk[j].w[0]));
@@ -568,7 +590,11 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
     bin_reserve<LDS, NB>(L, bs, out, ob0, res, !FULL);
 #pragma unroll
     for (int j = 0; j < kPosPerLane; j++) {  // sorted position goes into bits 12..24 of tle (FULL: 12..23)
+#if MCX_RANK_FROM_COUNT
+      tle[j] += L.off[tle[j] & 0xfffu] << 12;  // arrival index -> sorted position
+#else
       tle[j] |= bin_rank<LDS>(L, tle[j] & 0xfffu) << 12;
+#endif
       // four returning atomics in flight, then their results are folded into tle (the opaque
       // statement also keeps the compiler from holding on to the bin index for the placement:
       // it spilled sixteen of them)
