@@ -640,11 +640,17 @@ struct TupleIn {
 
 template <int W, bool ONECOL, int NB, bool IN_FULL, bool SHARD>
 __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
-                                                                         InsertSink<W, ONECOL> isink, Counters *ctr)
+                                                                         InsertSink<W, ONECOL> isink_arg, Counters *ctr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   using LDS = BinLds<W, NB, false>;
   LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
+  // (as in k_stream_bin: the table's description is read from LDS by the rare paths, so that its
+  // twenty arguments do not occupy scalar registers through the tile loop)
+  __shared__ InsertSink<W, ONECOL> isink;
+  if (threadIdx.x == 0) isink = isink_arg;
+  __syncthreads();
+  const uint32_t t_spb = isink_arg.t.spb, t_lb1 = isink_arg.t.lb1, t_lbq = isink_arg.t.lb1 + isink_arg.t.lbo, t_part = isink_arg.t.part;
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
   const uint64_t chunks_per_seg = (in.seg_cap + kTile - 1) / kTile;
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
   const uint32_t nwin = (bins_g + kWin - 1) / kWin;
   const uint64_t nchunks = xcd ? (uint64_t)nwin * chunks_per_seg * win_segs : chunks_per_seg * nseg_g;
   const uint64_t v0 = xcd ? blockIdx.x / 8 : blockIdx.x, vstep = xcd ? gridDim.x / 8 : gridDim.x;
-  const uint32_t lmask = (1u << isink.t.lb1) - 1u;
+  const uint32_t lmask = (1u << t_lb1) - 1u;
   for (uint64_t v = v0; v < nchunks; v += vstep) {
     uint32_t seg;
     uint64_t start;
@@ -689,10 +695,11 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
     const uint32_t n = (uint32_t)min((uint64_t)kTile, cnt - start);
     const uint32_t lregion = bs.mode == BIN_SUBLOCAL ? seg % bs.seg_mod : 0;  // block-uniform
     const uint32_t region = bs.region0 + lregion;
-    const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? lregion * isink.t.spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
+    const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? lregion * t_spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
     __syncthreads();
-    for (uint32_t b = tid; b < bs.nlocal; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
+    for (uint32_t b = tid; b < bs.nlocal + 64; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
     __syncthreads();
+    const uint32_t trash = bs.nlocal + 1u + ((uint32_t)tid & 31u);
     const uint64_t *kin = in.keys + (pseg * in.seg_cap + start) * W;
     const uint8_t *ein = IN_FULL ? in.edges + pseg * in.seg_cap + start : nullptr;
     // each lane keeps its kTile/kThreads tuples in registers: all loads are issued up front
@@ -744,37 +751,38 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
       uint32_t hb;
       if (IN_FULL) {  // full key -> region, packed tuple
         uint32_t r;
-        const uint32_t lbq = lbq_of(isink.t);
+        const uint32_t lbq = t_lbq;
         const Kmer<W> key = tk[q];
         const Kmer<W> qq = key_quot<W>(key, lbq, r);
         const uint32_t G = r ^ mix_g(region_mix<W>(qq), lbq);
         hb = 0;
         loc[q] = G & lmask;
         tk[q] = tuple_pack<W>(qq, ev[q]);
-        if (SHARD && (okm >> q & 1u) && (G >> isink.t.lb1) != isink.t.part) {
+        if (SHARD && (okm >> q & 1u) && (G >> t_lb1) != t_part) {
           foreign_insert<W, ONECOL>(isink, key, ev[q], n_novel, full);
           okm &= ~(1u << q);
         }
       } else {        // packed tuple of a known region -> sub-table inside the region
         hb = sub_hash<W>(tuple_q<W>(tk[q]));
-        loc[q] = __umulhi(hb, isink.t.spb);
+        loc[q] = __umulhi(hb, t_spb);
       }
       if (loc[q] >= bs.nlocal) loc[q] = bs.nlocal - 1;  // cannot happen for well-formed bins
-      if (okm >> q & 1u) atomicAdd(&L.cnt[loc[q]], 1u);
+      // no branches on "this lane holds a tuple" (the tail of a segment, foreign keys): such a
+      // slot goes to the lane's trash bin, whose sorted positions lie beyond the tile
+      loc[q] = (okm >> q & 1u) ? loc[q] : trash;
+      atomicAdd(&L.cnt[loc[q]], 1u);
       (void)i;
     }
     BinRes<NB> res;
-    bin_reserve<LDS, NB>(L, bs, out, ob0, res);
+    bin_reserve<LDS, NB>(L, bs, out, ob0, res, true);
 #pragma unroll
-    for (int q = 0; q < PER; q++) {  // sorted position goes into the high half of loc
-      if (okm >> q & 1u) loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
-    }
+    for (int q = 0; q < PER; q++)  // sorted position goes into the high half of loc
+      loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
-      for (int q = 0; q < PER; q++) {
-        if (okm >> q & 1u) bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);
-      }
+      for (int q = 0; q < PER; q++)
+        bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);
       bin_writeout<W, ONECOL, false, 0, LDS>(L, round, bs, out, ob0, region, isink, n_novel, full);
     }
   }
