@@ -272,7 +272,8 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   // one colour: records [key words, value]; several: key array, then one value array per colour
   g->t.max_probe = (uint32_t)sub_slots;  // a probe sequence never leaves its sub-table
   { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
-  { const char *e = getenv("MCX_GRID_SPLIT"); if (e) g->grid_split = atoi(e); }    // experiments (flush overlap)
+  { const char *e = getenv("MCX_GRID_STREAM"); if (e) g->grid_stream = atoi(e); }  // experiments
+  { const char *e = getenv("MCX_GRID_SPLIT"); if (e) g->grid_split = atoi(e); }
   { const char *e = getenv("MCX_GRID_INSERT"); if (e) g->grid_insert = atoi(e); }
   g->table_bytes = slots * g->t.S * 8;
 

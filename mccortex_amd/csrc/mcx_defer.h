@@ -663,8 +663,13 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
   const uint32_t group = xcd ? blockIdx.x % 8 : 0;
   const uint32_t nseg_g = xcd ? in.nseg / 8 : in.nseg;  // segments this block may take
   // ... and within an XCD only kWin regions are split at a time, so that their 512 write fronts
-  // each (64 B) stay resident in that XCD's L2 until the runs have filled whole lines.
-  constexpr uint32_t kWin = 8;
+  // each (64 B) stay resident in that XCD's L2 until the runs have filled whole lines.  Measured
+  // (C2, ms per 12 G occurrences, two runs each): 16 regions 51.7; 8: 44.7 / 43.8; 4: 45.6 / 45.4;
+  // 2: 42.5 / 41.3; 1: 43.7 / 41.7.
+#ifndef MCX_SPLIT_WIN
+#define MCX_SPLIT_WIN 2
+#endif
+  constexpr uint32_t kWin = MCX_SPLIT_WIN;
   const uint32_t bins_g = xcd ? bs.seg_mod / 8 : 1;      // regions of this group
   const uint32_t reps = xcd ? in.nseg / bs.seg_mod : 1;  // replicas per region
   const uint32_t win_segs = kWin * reps;
