@@ -472,19 +472,35 @@ static void launch_bin_stream_t(mcx_graph *g, const StreamLaunch &L, int colour,
 template <int W, bool ONECOL, bool IN_FULL, bool SHARD>
 static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs, BinOut out)
 {
-  const uint64_t nchunks = (in.seg_cap + kTile - 1) / kTile * in.nseg;
+  // the split of one-word tuples into <= 512 sub-table bins runs with 512-thread blocks and tiles of
+  // 8192 tuples (MCX_SPLIT_T=256 for the old geometry)
+  constexpr bool kWide = W == 1 && !IN_FULL;
+  static const bool wide = kWide && [] { const char *e = getenv("MCX_SPLIT_T"); return !e || atoi(e) == 512; }();
+  const bool use_wide = wide && bs.nlocal <= 512;
+  const uint64_t tile = use_wide ? 512 * 16 : kTile;
+  const uint64_t nchunks = (in.seg_cap + tile - 1) / tile * in.nseg;
   if (!nchunks) return;
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
+  using GeoW = Geo<512, 512 * 16>;
   static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
   bool &once = once_dev[g->device & 63];
   if (!once) {
     allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>, sizeof(BinLds<W, 512, false>));
     allow_lds(k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD>, sizeof(BinLds<W, 1024, false>));
     allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD>, sizeof(BinLds<W, kMaxBins, false>));
+    if constexpr (kWide) allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD, 512>, sizeof(BinLds<W, 512, false, GeoW>));
     once = true;
   }
   SpanGuard sp(g, "k_tuples_bin");
-  const dim3 grid((unsigned)std::min<uint64_t>(nchunks, (uint64_t)(g->grid_split ? g->grid_split : g->grid * 4)));
+  const uint64_t gmax = (uint64_t)(g->grid_split ? g->grid_split : g->grid * 4);
+  if constexpr (kWide) {
+    if (use_wide) {
+      const dim3 gridw((unsigned)std::min<uint64_t>(nchunks, g->grid_split ? gmax : gmax / 2));
+      hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD, 512>), gridw, dim3(512), sizeof(BinLds<W, 512, false, GeoW>), g->stream, in, bs, out, is, g->d_ctr);
+      return;
+    }
+  }
+  const dim3 grid((unsigned)std::min<uint64_t>(nchunks, gmax));
   if (bs.nlocal <= 512)
     hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD>), grid, dim3(kThreads), sizeof(BinLds<W, 512, false>), g->stream, in, bs, out, is, g->d_ctr);
   else if (bs.nlocal <= 1024)

@@ -110,9 +110,18 @@ template <int W> __device__ __forceinline__ Kmer<W> tuple_q(const Kmer<W> &t)
 constexpr int kRounds = MCX_ROUNDS;
 constexpr int kStage = kTile / kRounds;
 
+// Geometry of a binning block: T threads, TILE tuples per tile (staged in kRounds rounds).  The
+// k-merising kernel and the super-k-mer kernels use 256 x 16; the split uses 512 x 16: its runs per
+// sub-table bin are twice as long (128 B), so fewer of its lines are written in two halves.
+template <int T_, int TILE_> struct Geo {
+  static constexpr int kT = T_, kTileG = TILE_, kStageG = TILE_ / kRounds;
+};
+using Geo256 = Geo<kThreads, kTile>;
+
 // LDS working set of one binning block (NB = histogram capacity)
-template <int W, int NB, bool FULL> struct BinLds {
-  uint64_t skey[kStage * W];
+template <int W, int NB, bool FULL, class G = Geo256> struct BinLds {
+  using geo = G;
+  uint64_t skey[G::kStageG * W];
   // per bin, for the write-out: bits 0..47 = (output tuple index of the bin's first tuple of this
   // tile) - (its sorted position in the tile), mod 2^48; bits 48..63 = sorted positions below this
   // value still fit the bin's segment (the rest overflows)
@@ -120,9 +129,9 @@ template <int W, int NB, bool FULL> struct BinLds {
   uint32_t cnt[NB + 64];  // [nlocal + lane] = the trash bins (positions without a tuple), one per lane
   uint32_t rnk[NB + 64];  // rank counters of the placement (zeroed with cnt at the top of a tile)
   uint32_t off[NB + 64];
-  uint32_t wsum[kThreads / 64];
-  uint16_t sbin[kStage];
-  uint8_t se[FULL ? kStage : 16];
+  uint32_t wsum[G::kT / 64];
+  uint16_t sbin[G::kStageG];
+  uint8_t se[FULL ? G::kStageG : 16];
 };
 
 // The thread index, opaque to the optimiser: what is derived from it inside a tile loop (LDS
@@ -143,19 +152,20 @@ __device__ __forceinline__ uint32_t tid_now()
 // the global reservations of its bins (one returning atomic per non-empty bin).  The results
 // stay in registers: placement into the LDS staging area only needs off[], so the atomics'
 // round trip overlaps with it; bin_commit() publishes the bases before the write-out.
-template <int NB> struct BinRes { unsigned long long g0[(NB + kThreads - 1) / kThreads]; };
+template <int NB, int T = kThreads> struct BinRes { unsigned long long g0[(NB + T - 1) / T]; };
 
 template <class LDS, int NB>
-__device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, BinRes<NB> &res,
+__device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, BinRes<NB, LDS::geo::kT> &res,
                                             bool trash_beyond = false)
 {
+  constexpr int kT = LDS::geo::kT;
   const int tid = threadIdx.x;
   __syncthreads();
 #if MCX_PSCAN
-  {  // every thread scans NB / kThreads consecutive bins; the waves' totals meet in LDS.  (One wave
+  {  // every thread scans NB / kT consecutive bins; the waves' totals meet in LDS.  (One wave
      // scanning all bins while the other three wait at the barrier cost 8 % of the k-merising kernel.)
-    constexpr int PERB = NB / kThreads;
-    static_assert(NB % kThreads == 0, "bins per thread");
+    constexpr int PERB = NB / kT;
+    static_assert(NB % kT == 0, "bins per thread");
     uint32_t c[PERB], x = 0;
 #pragma unroll
     for (int i = 0; i < PERB; i++) {
@@ -173,7 +183,7 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     __syncthreads();
     uint32_t before = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kThreads / 64; w++) {
+    for (int w = 0; w < kT / 64; w++) {
       const uint32_t ws = L.wsum[w];
       if (w < (tid >> 6)) before += ws;
       total += ws;
@@ -187,7 +197,7 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     }
     // [nlocal] = the tile's total; then where the trash bins start: behind the real tuples, or
     // (trash_beyond) past the tile, where the placement never looks
-    if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)kTile : total;
+    if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)LDS::geo::kTileG : total;
   }
 #else
   if (tid < 64) {
@@ -204,13 +214,13 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
       if (b < bs.nlocal) L.off[b] = carry + x - c;
       carry += __shfl(x, 63, 64);
     }
-    if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)kTile : carry;
+    if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)LDS::geo::kTileG : carry;
   }
 #endif
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
-    const uint32_t b = (uint32_t)q * kThreads + tid;
+  for (int q = 0; q < (NB + kT - 1) / kT; q++) {
+    const uint32_t b = (uint32_t)q * kT + tid;
     res.g0[q] = 0;
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
@@ -223,11 +233,12 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
 constexpr unsigned long long kDstMask = (1ULL << 48) - 1;
 
 template <class LDS, int NB>
-__device__ __forceinline__ void bin_commit(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, const BinRes<NB> &res)
+__device__ __forceinline__ void bin_commit(LDS &L, const BinSpec &bs, const BinOut &out, uint32_t ob0, const BinRes<NB, LDS::geo::kT> &res)
 {
+  constexpr int kT = LDS::geo::kT;
 #pragma unroll
-  for (int q = 0; q < (NB + kThreads - 1) / kThreads; q++) {
-    const uint32_t b = (uint32_t)q * kThreads + threadIdx.x;
+  for (int q = 0; q < (NB + kT - 1) / kT; q++) {
+    const uint32_t b = (uint32_t)q * kT + threadIdx.x;
     if (b < bs.nlocal) {
       const uint32_t o0 = L.off[b], o1 = L.off[b + 1];
       const unsigned long long g0 = res.g0[q];                       // start of the run in its segment
@@ -249,8 +260,9 @@ template <class LDS> __device__ __forceinline__ uint32_t bin_rank(LDS &L, uint32
 template <int W, bool FULL, class LDS>
 __device__ __forceinline__ void bin_place(LDS &L, int round, uint32_t p, uint32_t local, const Kmer<W> &t, uint32_t e)
 {
-  if ((int)(p / kStage) != round) return;
-  const uint32_t q = p % kStage;
+  constexpr uint32_t kSt = LDS::geo::kStageG;
+  if ((int)(p / kSt) != round) return;
+  const uint32_t q = p % kSt;
   L.skey[q * W] = t.w[0];
   if (W == 2) L.skey[q * W + 1] = t.w[W - 1];
   L.sbin[q] = (uint16_t)local;
@@ -267,9 +279,10 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
 {
   __syncthreads();
   const uint32_t n = L.off[bs.nlocal];
-  const uint32_t lo = (uint32_t)round * kStage;
-  const uint32_t cnt = n > lo ? min(n - lo, (uint32_t)kStage) : 0;
-  for (uint32_t q = threadIdx.x; q < cnt; q += kThreads) {
+  constexpr uint32_t kSt = LDS::geo::kStageG;
+  const uint32_t lo = (uint32_t)round * kSt;
+  const uint32_t cnt = n > lo ? min(n - lo, kSt) : 0;
+  for (uint32_t q = threadIdx.x; q < cnt; q += LDS::geo::kT) {
     const uint32_t b = L.sbin[q];
     const unsigned long long gb = L.gbase[b];
     if (lo + q < (uint32_t)(gb >> 48)) {
@@ -638,12 +651,16 @@ struct TupleIn {
   uint32_t seg_group, seg_stride;
 };
 
-template <int W, bool ONECOL, int NB, bool IN_FULL, bool SHARD>
-__global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
+// T threads x 16 tuples per tile: 256 (4 blocks per CU), or 512 (2 blocks per CU, one-word keys; the launch
+// bound is waves per SIMD, 4 either way): runs of
+// 16 tuples = 128 bytes per sub-table bin and tile instead of 8.
+template <int W, bool ONECOL, int NB, bool IN_FULL, bool SHARD, int T = kThreads>
+__global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
                                                                          InsertSink<W, ONECOL> isink_arg, Counters *ctr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  using LDS = BinLds<W, NB, false>;
+  using LDS = BinLds<W, NB, false, Geo<T, T * 16>>;
+  constexpr int kThreads = T, kTile = T * 16;  // (shadow the 256 x 16 geometry of the other kernels)
   LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
   // (as in k_stream_bin: the table's description is read from LDS by the rare paths, so that its
   // twenty arguments do not occupy scalar registers through the tile loop)
@@ -778,7 +795,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_tuples_bin(Tuple
       atomicAdd(&L.cnt[loc[q]], 1u);
       (void)i;
     }
-    BinRes<NB> res;
+    BinRes<NB, T> res;
     bin_reserve<LDS, NB>(L, bs, out, ob0, res, true);
 #pragma unroll
     for (int q = 0; q < PER; q++)  // sorted position goes into the high half of loc
