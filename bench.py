@@ -344,7 +344,7 @@ def extras(mcx, batches, packed, nsteps, table_slots):
         best = None
         runs = []
         for _ in range(3):  # later runs: file in the page cache, HIP kernels' code objects loaded before
-            time.sleep(0.3)  # (this process has just freed its device memory: the driver is still scrubbing it)
+            time.sleep(2.0)  # (this process, then the previous run, has just freed tens of GB of device memory: the driver scrubs it)
             t0, w0 = time.perf_counter(), time.time()
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MCX_TIMING="1"))
             dt, w1 = time.perf_counter() - t0, time.time()
