@@ -120,6 +120,25 @@ def ref_lookup3():
     return _REF
 
 
+_REVCMP = {}
+
+
+def ref_revcmp(W):
+    """The reference's standalone dev/bkmer_revcmp/revcmp.c compiled with NUM_BKMER_WORDS = W (1 or 2)
+    into oracle/_ref (or None): ref_revcmp(method 1..4, in words, k, out words)."""
+    if W not in _REVCMP:
+        so = os.path.join(_HERE, "_ref", "librevcmp%d.so" % W)
+        if not os.path.exists(so):
+            return None
+        R = C.CDLL(so)
+        R.ref_revcmp_words.restype = C.c_int
+        R.ref_revcmp.restype = None
+        R.ref_revcmp.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        assert R.ref_revcmp_words() == W
+        _REVCMP[W] = R
+    return _REVCMP[W]
+
+
 def pack_reads(reads):
     """list of bytes/str -> (bases uint8[total], offsets uint64[n+1]) without separators."""
     bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]

@@ -11,7 +11,13 @@
    k-mer that is in the graph (db_graph_next_nodes asserts the lookup succeeds, db_graph.c:231-258).
    Checked here on the exported records, plus the reciprocal bit on the neighbour.
 
-Both run against the oracle (CPU) and, marked gpu, against the HIP path.
+3. Two-word keys (k = 33 and k = 63), record BYTES written out by hand from binary_kmer.c:156-186
+   (b[0] is the top word and holds k & 31 bases in its low bits; b[1] the last 32 bases),
+   graph_writer.c:116-127 (key words in index order, each little-endian; u32 coverage; u8 edges) and
+   the sort order of `build --sort` (hash_table.c:371: k-mers compared word 0 first).  Nothing in
+   these expectations comes from the oracle or from SURVEY.md.
+
+All run against the oracle (CPU) and, marked gpu, against the HIP path.
 """
 import numpy as np
 import pytest
@@ -125,6 +131,39 @@ def _check_next_nodes(build):
     assert n_edges >= 4 * 48  # two 59-mers per colour: at least 48 adjacent pairs each, both ends
 
 
+# --- 3. two-word keys: record bytes by hand ----------------------------------------------------------
+def _le64(v):
+    return bytes((v >> (8 * i)) & 0xFF for i in range(8))
+
+
+def _check_two_word_records(build):
+    """Read S = C A..A G T (k + 1 bases) holds two k-mers:
+         K1 = C A^(k-2) G     rc(K1) = C T^(k-2) G : equal first base, then A < T   -> key K1, forward
+         K2 = A^(k-2) G T     rc(K2) = A C T^(k-2) : equal first base, then A < C   -> key K2, forward
+       Edge K1 -> K2 (db_graph.c:152-166): on K1 (forward) the next base T = bit 3 -> 0x08; on K2 the
+       complement of K1's first base C, i.e. G = 2, in the reverse nibble -> bit 6 -> 0x40.
+       k = 33: b[0] holds 1 base, b[1] 32: K1 = {C = 1, A^31 G = 2}; K2 = {A = 0, A^30 G T = 0b1011}.
+       k = 63: b[0] holds 31 bases: K1 = {C A^30 = 1 << 60, A^31 G = 2}; K2 = {0, 0b1011}.
+       K2 < K1 (word 0 decides), so the sorted body is K2's record, then K1's.
+       The reverse complement of S holds rc(K2) -> rc(K1): same keys, both in reverse orientation, and
+       the same two edge bits (on K2, reverse: next base G -> bit 2 + 4; on K1, forward nibble: the
+       complement of rc(K2)'s first base A, T -> bit 3): coverage 2, edges unchanged."""
+    for k, k1w0 in ((33, 1), (63, 1 << 60)):
+        S = "C" + "A" * (k - 2) + "GT"
+        assert len(S) == k + 1
+        one = (_le64(0) + _le64(0xB) + bytes([1, 0, 0, 0]) + bytes([0x40]) +
+               _le64(k1w0) + _le64(2) + bytes([1, 0, 0, 0]) + bytes([0x08]))
+        assert len(one) == 2 * 21
+        assert build(k, 1, [(0, [S])]) == one, k
+        two = (_le64(0) + _le64(0xB) + bytes([2, 0, 0, 0]) + bytes([0x40]) +
+               _le64(k1w0) + _le64(2) + bytes([2, 0, 0, 0]) + bytes([0x08]))
+        assert build(k, 1, [(0, [S, revcomp(S)])]) == two, k
+        # two colours: W words, then covg[0], covg[1] (u32 each), then edges[0], edges[1]
+        got = build(k, 2, [(1, [S])])
+        assert got == (_le64(0) + _le64(0xB) + bytes(4) + bytes([1, 0, 0, 0]) + bytes([0, 0x40]) +
+                       _le64(k1w0) + _le64(2) + bytes(4) + bytes([1, 0, 0, 0]) + bytes([0, 0x08])), k
+
+
 def _oracle_build(orc):
     def build(k, ncols, jobs):
         g = orc.Graph(k, ncols, 1 << 12)
@@ -154,6 +193,16 @@ def test_inferedges_k5_edges_oracle(orc):
 
 def test_node_tests_next_nodes_oracle(orc):
     _check_next_nodes(_oracle_build(orc))
+
+
+def test_two_word_record_bytes_oracle(orc):
+    _check_two_word_records(_oracle_build(orc))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("defer", [0, 1])
+def test_two_word_record_bytes_gpu(mcx, orc, defer):
+    _check_two_word_records(_gpu_build(mcx, orc, defer))
 
 
 @pytest.mark.gpu

@@ -55,6 +55,48 @@ def test_hash_matches_reference_lookup3(orc):
             assert L.orc_kmer_hash(x, k, iv) == R.ref_lk3_hashlittle(a.ctypes.data, 8 * W, iv)
 
 
+@pytest.mark.parametrize("k", list(range(3, 64, 2)))
+def test_revcomp_matches_reference_revcmp(orc, mcx, k):
+    """orc_kmer_revcomp / orc_kmer_get_key and the product's host template mcx_kmer_canonical against
+    the reference's own code: dev/bkmer_revcmp/revcmp.c (all four binary_kmer_reverse_complement{1..4};
+    number 2 is src/graph/binary_kmer.c:102-133 line for line), compiled unmodified with
+    NUM_BKMER_WORDS = 1 and 2 into oracle/_ref.  Pins the b[0]-is-the-top-word layout, the base order
+    inside a word and the shift across words for every odd k up to 63."""
+    L = orc.lib()
+    W = L.orc_words_for_k(k)
+    R = orc.ref_revcmp(W)
+    if R is None:
+        pytest.skip("oracle/_ref/librevcmp%d.so not built (needs /root/reference at build time)" % W)
+    rng = np.random.default_rng(100 + k)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    buf = C.create_string_buffer(128)
+    cases = [_rand_kmer(rng, k) for _ in range(60)] + ["A" * k, "T" * k, "C" * k, "G" * k, "AC" * (k // 2) + "G"]
+    for s in cases:
+        x = L.orc_kmer_from_str(s.encode(), k)
+        a = np.array(_words(x, W), dtype=np.uint64)
+        want = None
+        for method in (1, 2, 3, 4):
+            out = np.zeros(W, dtype=np.uint64)
+            R.ref_revcmp(method, a.ctypes.data, k, out.ctypes.data)
+            got = [int(w) for w in out]
+            assert want is None or got == want  # the reference's four variants agree with each other
+            want = got
+        rc = L.orc_kmer_revcomp(x, k)
+        assert _words(rc, W) == want
+        # ... and the words the reference code produced spell the reverse complement
+        y = orc.BKmer()
+        for i in range(W):
+            y.b[i] = want[i]
+        L.orc_kmer_to_str(y, k, buf)
+        assert buf.value.decode() == "".join(comp[c] for c in reversed(s))
+        # canonical key = the smaller of the two, word 0 (the top word) first (binary_kmer.c:43-57)
+        fw = _words(x, W)
+        key = min(fw, want)
+        assert _words(L.orc_kmer_get_key(x, k), W) == key
+        kw, o = mcx.kmer_canonical(fw, k)
+        assert kw == key and o == (0 if key == fw else 1)
+
+
 def test_hash_table_cap_kats(orc):
     L = orc.lib()
     for n, nb, bs in KATS["hash_table_cap"]:
