@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K = 31
-READ_LEN = 150
+READ_LEN = int(os.environ.get("MCX_BENCH_READ_LEN", "150"))  # (experiments only: C2 is 150)
 BATCH_READS = 5_000_000
 GENOME_PER_GPU = 200_000_000
 TABLE_SLOTS = 1 << 30

@@ -253,6 +253,14 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   while (lb1 < lb1_max && (2ull << lb1) <= nsub) lb1++;             // up to 512 regions ...
   while (lb1 < 11 && ((nsub + (1ull << lb1) - 1) >> lb1) > (uint64_t)kMaxBins) lb1++;  // ... more for huge tables
   if (const char *e = getenv("MCX_LB1")) { const uint32_t v = (uint32_t)atoi(e); if (!lbo && v >= lb1 && v <= 11) lb1 = v; }  // experiments
+  if (lbo && lb1 + lbo > 11) {
+    // (owner, region) bins of the sender kernel: at most 2048, and mix_bucket() takes its bits below
+    // the lb1 + lbo <= 12 it assumes.  Per shard that is 2048 / shards regions x 2048 sub-tables.
+    const uint64_t max_slots = ((uint64_t)kMaxBins << (11 - lbo)) * sub_slots;
+    delete g;
+    return fail(MCX_ERR_ARG, "capacity per device too large for a table split over %d devices: %llu slots requested, at most %llu "
+                "(use more devices or a smaller -n / -m)", nparts, (unsigned long long)(nsub * sub_slots), (unsigned long long)max_slots);
+  }
   const uint64_t spb = (nsub + (1ull << lb1) - 1) >> lb1;
   nsub = spb << lb1;
   if (nsub >= (1ull << 31)) { delete g; return fail(MCX_ERR_ARG, "capacity too large"); }
@@ -535,12 +543,12 @@ template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int 
 }
 
 template <int W, bool ONECOL>
-static void launch_insert_tuples_t(mcx_graph *g, int colour, const uint64_t *keys, const uint8_t *edges, uint64_t n)
+static void launch_insert_tuples_t(mcx_graph *g, int colour, const uint64_t *keys, const uint8_t *edges, uint64_t n, uint32_t only_own = 0)
 {
   const int grid = (int)std::min<uint64_t>((n + kThreads * kBatch - 1) / (kThreads * kBatch), (uint64_t)g->grid);
   InsertSink<W, ONECOL> s{g->t, (uint32_t)colour};
   SpanGuard sp(g, "k_insert_tuples");
-  hipLaunchKernelGGL((k_insert_tuples<W, ONECOL>), dim3(grid), dim3(kThreads), 0, g->stream, s, keys, edges, n, g->d_ctr);
+  hipLaunchKernelGGL((k_insert_tuples<W, ONECOL>), dim3(grid), dim3(kThreads), 0, g->stream, s, keys, edges, n, g->d_ctr, only_own);
 }
 
 // ---- deferred path bookkeeping -------------------------------------------------------------
@@ -997,7 +1005,7 @@ extern "C" int mcx_graph_shard_layout(mcx_graph *g, uint64_t tuples_per_call, ui
 }
 
 static int shard_bins_launch(mcx_graph *g, const StreamLaunch &L, void *d_keys, void *d_counts, uint64_t seg_cap,
-                             void *d_ov_keys, void *d_ov_edges, void *d_ov_counts, uint64_t ov_cap);
+                             void *d_ov_keys, void *d_ov_edges, void *d_ov_counts, uint64_t ov_cap, bool spill = false);
 
 extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint64_t nbytes, void *d_keys,
                                         void *d_counts, uint64_t seg_cap, void *d_ov_keys, void *d_ov_edges,
@@ -1011,14 +1019,14 @@ extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint
 }
 
 static int shard_bins_launch(mcx_graph *g, const StreamLaunch &L, void *d_keys, void *d_counts, uint64_t seg_cap,
-                             void *d_ov_keys, void *d_ov_edges, void *d_ov_counts, uint64_t ov_cap)
+                             void *d_ov_keys, void *d_ov_edges, void *d_ov_counts, uint64_t ov_cap, bool spill)
 {
   if (!L.code && ((uintptr_t)L.stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
   if (g->t.lb1 + g->t.lbo > 11) return fail(MCX_ERR_ARG, "too many (owner, region) bins");
   if (seg_cap >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "segment capacity must be below 2^32 tuples");
   HIP_TRY(hipSetDevice(g->device));
   const uint32_t nparts = 1u << g->t.lbo, b1 = 1u << g->t.lb1;
-  BinSpec bs{BIN_GLOBAL, nparts, nparts * b1, kShardRep, b1, 1, g->t.lb1, 0};
+  BinSpec bs{BIN_GLOBAL, nparts, nparts * b1, kShardRep, b1, 1, g->t.lb1, spill ? 1u : 0u};
   BinOut out{(uint64_t *)d_keys, nullptr, (unsigned long long *)d_counts, seg_cap,
              (uint64_t *)d_ov_keys, (uint8_t *)d_ov_edges, (unsigned long long *)d_ov_counts, ov_cap};
   if (g->W == 1) launch_bin_stream_t<1, true, false, 2>(g, L, 0, bs, out);

@@ -44,7 +44,8 @@ struct BinSpec {
   uint32_t nout;     // output bins per replica
   uint32_t seg_mod;  // BIN_SUBLOCAL: input segment s holds region region0 + s % seg_mod
   uint32_t lb1;      // BIN_GLOBAL: log2 regions per owner
-  uint32_t region0;  // BIN_SUBLOCAL: first region of the group being split (output bins are group-local)
+  uint32_t region0;  // BIN_SUBLOCAL: first region of the group being split (output bins are group-local);
+                     // BIN_GLOBAL: 1 = a spill area follows the owners' overflow bins (BinOut::ov_counts)
 };
 
 // index of the output segment of local bin b
@@ -62,10 +63,11 @@ struct BinOut {
   uint8_t *edges;              // [rep][nbins][cap] (full format only)
   unsigned long long *counts;  // [rep][nbins] fill (may exceed cap: the excess went to the fallback)
   uint64_t cap;                // tuples per (replica, bin) segment
-  // BIN_GLOBAL only: per-owner overflow bins in full format for tuples beyond a segment's capacity
-  uint64_t *ov_keys;           // [nparts][ov_cap][W]
-  uint8_t *ov_edges;           // [nparts][ov_cap]
-  unsigned long long *ov_counts;
+  // BIN_GLOBAL only: per-owner overflow bins in full format for tuples beyond a segment's capacity,
+  // then the sender's spill area for tuples beyond an overflow bin's capacity (bin_writeout)
+  uint64_t *ov_keys;           // [nparts][ov_cap][W], then [spill capacity][W]
+  uint8_t *ov_edges;           // [nparts][ov_cap], then [spill capacity]
+  unsigned long long *ov_counts;  // [nparts] fills, [nparts] = spill fill, [nparts + 1] = spill capacity
   uint64_t ov_cap;
 };
 
@@ -310,7 +312,23 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
           if (W == 2) kd[1] = key.w[W - 1];
           out.ov_edges[(uint64_t)owner * out.ov_cap + pos] = (uint8_t)e;
         } else {
-          full = 2;
+          // The owner's overflow bin is full as well (one k-mer tens of thousands of times in a
+          // piece: poly-G reads, satellite repeats, a homopolymer contig).  Behind the nparts owner
+          // bins sits the sender's spill area (any owner, full format; fill in ov_counts[nparts],
+          // capacity in ov_counts[nparts + 1], 0 = none): it stays on the sender, and the host routes
+          // it to the owners when it next looks (mcx_multi.h, group_route_spill).  With a spill area
+          // as large as the piece nothing can be lost.
+          const unsigned long long sp_cap = bs.region0 ? out.ov_counts[bs.nparts + 1] : 0;  // (BIN_GLOBAL: region0 = "a spill area follows")
+          const unsigned long long sp = sp_cap ? atomicAdd(&out.ov_counts[bs.nparts], 1ULL) : 0;
+          if (sp < sp_cap) {
+            const uint64_t at = (uint64_t)bs.nparts * out.ov_cap + sp;
+            uint64_t *kd = out.ov_keys + at * W;
+            kd[0] = key.w[0];
+            if (W == 2) kd[1] = key.w[W - 1];
+            out.ov_edges[at] = (uint8_t)e;
+          } else {
+            full = 2;
+          }
         }
       } else {                      // ... lock-free insert into the HBM table
         table_mark_written(isink.t);

@@ -816,7 +816,8 @@ __global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a
 // ---------------------------------------------------------------------------
 template <int W, bool ONECOL>
 __global__ __launch_bounds__(kThreads) void k_insert_tuples(InsertSink<W, ONECOL> sink, const uint64_t *keys,
-                                                            const uint8_t *edges, uint64_t n, Counters *ctr)
+                                                            const uint8_t *edges, uint64_t n, Counters *ctr,
+                                                            uint32_t only_own /* skip the keys of other shards */)
 {
   if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(sink.t);
   uint32_t n_novel = 0, full = 0;
@@ -833,6 +834,7 @@ __global__ __launch_bounds__(kThreads) void k_insert_tuples(InsertSink<W, ONECOL
         x.key.w[0] = keys[i * W];
         if (W == 2) x.key.w[W - 1] = keys[i * W + 1];
         x.e = edges[i];
+        if (only_own && key_owner<W>(sink.t, x.key) != sink.t.part) ov[b] = false;
       }
     }
     flush_batch<W, ONECOL>(sink, occ, ov, n_novel, full);

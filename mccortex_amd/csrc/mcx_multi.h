@@ -28,9 +28,9 @@ namespace {
 struct XBuf {  // one block set: packed tuples by (owner, region) + per-owner overflow bins (full tuples)
   uint64_t *keys = nullptr;
   unsigned long long *counts = nullptr;
-  uint64_t *ov_keys = nullptr;
+  uint64_t *ov_keys = nullptr;    // send sets: [N][ov_cap], then the spill area [sp_cap] (BinOut::ov_keys)
   uint8_t *ov_edges = nullptr;
-  unsigned long long *ov_counts = nullptr;
+  unsigned long long *ov_counts = nullptr;  // send sets: [N] fills, [N] = spill fill, [N + 1] = spill capacity
 };
 
 }  // namespace
@@ -41,6 +41,9 @@ struct mcx_group {
   // geometry of one exchange piece (at most max_pos k-mer start positions)
   uint32_t segs = 0;
   uint64_t seg_cap = 0, ov_cap = 0, max_pos = 0;
+  uint64_t sp_cap = 0;  // spill area of a send set: every occurrence of a piece fits, so no input can overflow
+  std::vector<std::array<unsigned long long *, 2>> h_spill;  // [i][b] pinned: spill fill of the set's last piece
+  std::vector<std::array<int, 2>> spill_colour;               // colour of that piece
   // send[i][b]: blocks for all owners on shard i's device; recv[j][i][b]: shard i's block on shard j's device
   std::vector<std::array<XBuf, 2>> send;
   std::vector<std::vector<std::array<XBuf, 2>>> recv;
@@ -70,6 +73,7 @@ static void group_free_buffers(mcx_group *G)
         XBuf &x = G->send[i][b];
         (void)hipFree(x.keys); (void)hipFree(x.counts); (void)hipFree(x.ov_keys); (void)hipFree(x.ov_edges); (void)hipFree(x.ov_counts);
         x = XBuf();
+        if ((size_t)i < G->h_spill.size() && G->h_spill[i][b]) { (void)hipHostFree(G->h_spill[i][b]); G->h_spill[i][b] = nullptr; }
       }
       if ((size_t)i < G->recv.size())
         for (auto &r : G->recv[i]) {
@@ -98,7 +102,10 @@ static int group_ensure_buffers(mcx_group *G)
   // to the owner's overflow bin (hot k-mers), and beyond that raises MCX_ERR_FULL on the sender
   G->seg_cap = ((uint64_t)(mean + 8.0 * sqrt(mean + 1.0)) + 64 + 1) & ~1ull;
   G->ov_cap = std::max<uint64_t>(1u << 16, G->max_pos / (uint64_t)N / 16);
+  G->sp_cap = G->max_pos;
   G->send.resize(N);
+  G->h_spill.assign(N, {nullptr, nullptr});
+  G->spill_colour.assign(N, {0, 0});
   G->recv.assign(N, std::vector<std::array<XBuf, 2>>(N));
   const uint64_t blk = (uint64_t)G->segs * G->seg_cap;  // tuples of one owner's block
   for (int i = 0; i < N; i++) {
@@ -107,9 +114,12 @@ static int group_ensure_buffers(mcx_group *G)
       XBuf &s = G->send[i][b];
       GRP_TRY(hipMalloc((void **)&s.keys, (uint64_t)N * blk * 8 * W));
       GRP_TRY(hipMalloc((void **)&s.counts, (uint64_t)N * G->segs * 8));
-      GRP_TRY(hipMalloc((void **)&s.ov_keys, (uint64_t)N * G->ov_cap * 8 * W));
-      GRP_TRY(hipMalloc((void **)&s.ov_edges, (uint64_t)N * G->ov_cap));
-      GRP_TRY(hipMalloc((void **)&s.ov_counts, (uint64_t)N * 8));
+      GRP_TRY(hipMalloc((void **)&s.ov_keys, ((uint64_t)N * G->ov_cap + G->sp_cap) * 8 * W));
+      GRP_TRY(hipMalloc((void **)&s.ov_edges, (uint64_t)N * G->ov_cap + G->sp_cap));
+      GRP_TRY(hipMalloc((void **)&s.ov_counts, (uint64_t)(N + 2) * 8));
+      GRP_TRY(hipMemcpy(s.ov_counts + N + 1, &G->sp_cap, 8, hipMemcpyHostToDevice));
+      GRP_TRY(hipHostMalloc((void **)&G->h_spill[i][b], 8, hipHostMallocDefault));
+      *G->h_spill[i][b] = 0;
       for (int src = 0; src < N; src++) {
         XBuf &r = G->recv[i][src][b];
         GRP_TRY(hipMalloc((void **)&r.keys, blk * 8 * W));
@@ -121,6 +131,45 @@ static int group_ensure_buffers(mcx_group *G)
     }
   }
   G->buffers = true;
+  return MCX_OK;
+}
+
+// Hot k-mers.  A segment holds mean + 8 sigma, an owner's overflow bin max(64 K, piece / N / 16) more;
+// one k-mer tens of thousands of times in a piece (poly-G reads, satellite repeats, a homopolymer
+// contig) goes beyond both.  The sender then appends the occurrence to the spill area of its send set
+// (bin_writeout), which holds a whole piece, and copies the fill to pinned memory behind the kernel.
+// The host looks at that number when the send set is next used and when the group is drained --
+// moments at which the kernel has long finished, so the common case costs no wait -- and, if it is
+// not zero, hands the spilled tuples to every shard, which inserts the keys it owns with the
+// lock-free direct insert (k_insert_tuples, only_own).  The one-GPU path does the same on the spot
+// (bin_writeout -> probe_insert); here the table is on other devices, hence the detour.
+static int group_route_spill(mcx_group *G, int idx, int b)
+{
+  if (!G->used[idx][b]) return MCX_OK;
+  mcx_graph *me = G->part[idx];
+  GRP_TRY(hipSetDevice(me->device));
+  GRP_TRY(hipEventSynchronize(G->filled[idx][b]));
+  const uint64_t n = std::min<uint64_t>(*G->h_spill[idx][b], G->sp_cap);
+  if (!n) return MCX_OK;
+  *G->h_spill[idx][b] = 0;
+  const int N = G->n, W = me->W, colour = G->spill_colour[idx][b];
+  const XBuf &s = G->send[idx][b];
+  const uint64_t at = (uint64_t)N * G->ov_cap;
+  for (int j = 0; j < N; j++) {
+    mcx_graph *own = G->part[j];
+    GRP_TRY(hipSetDevice(own->device));
+    uint64_t *k = nullptr;
+    uint8_t *e = nullptr;
+    GRP_TRY(hipMalloc((void **)&k, n * 8 * W));
+    GRP_TRY(hipMalloc((void **)&e, n));
+    GRP_TRY(hipMemcpyPeerAsync(k, own->device, s.ov_keys + at * W, me->device, n * 8 * W, own->stream));
+    GRP_TRY(hipMemcpyPeerAsync(e, own->device, s.ov_edges + at, me->device, n, own->stream));
+    DISPATCH_WC(own, launch_insert_tuples_t, own, colour, (const uint64_t *)k, (const uint8_t *)e, n, 1u);
+    GRP_TRY(hipGetLastError());
+    GRP_TRY(hipStreamSynchronize(own->stream));
+    (void)hipFree(k); (void)hipFree(e);
+  }
+  GRP_TRY(hipSetDevice(me->device));
   return MCX_OK;
 }
 
@@ -139,15 +188,19 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
     const int b = G->cur[idx];
     G->cur[idx] ^= 1;
     XBuf &s = G->send[idx][b];
+    rc = group_route_spill(G, idx, b);  // what this set's previous piece spilled (nearly always nothing)
+    if (rc != MCX_OK) return rc;
     // 1. sender
     GRP_TRY(hipSetDevice(me->device));
     if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(me->stream, G->sent[idx][b], 0));  // its last copies have left
     GRP_TRY(hipMemsetAsync(s.counts, 0, (uint64_t)N * G->segs * 8, me->stream));
-    GRP_TRY(hipMemsetAsync(s.ov_counts, 0, (uint64_t)N * 8, me->stream));
+    GRP_TRY(hipMemsetAsync(s.ov_counts, 0, (uint64_t)(N + 1) * 8, me->stream));
     StreamLaunch P = L;
     P.pos_lo = lo; P.pos_hi = hi;
-    rc = shard_bins_launch(me, P, s.keys, s.counts, G->seg_cap, s.ov_keys, s.ov_edges, s.ov_counts, G->ov_cap);
+    rc = shard_bins_launch(me, P, s.keys, s.counts, G->seg_cap, s.ov_keys, s.ov_edges, s.ov_counts, G->ov_cap, true);
     if (rc != MCX_OK) return rc;
+    GRP_TRY(hipMemcpyAsync(G->h_spill[idx][b], s.ov_counts + N, 8, hipMemcpyDeviceToHost, me->stream));
+    G->spill_colour[idx][b] = colour;
     GRP_TRY(hipEventRecord(G->filled[idx][b], me->stream));
     // 2. one copy per (owner, buffer): fixed sizes, so the fills travel with the blocks and the host
     // never has to read them
@@ -281,6 +334,12 @@ extern "C" int mcx_graph_ndevices(const mcx_graph *g) { return !g ? 0 : g->as_gr
 // everything in flight between the shards has landed and been handed to its owner
 static int grp_drain(mcx_group *G)
 {
+  if (G->buffers)
+    for (int i = 0; i < G->n; i++)
+      for (int b = 0; b < 2; b++) {
+        int rc = group_route_spill(G, i, b);
+        if (rc != MCX_OK) return rc;
+      }
   for (int i = 0; i < G->n; i++) {
     GRP_TRY(hipSetDevice(G->part[i]->device));
     GRP_TRY(hipStreamSynchronize(G->part[i]->stream));

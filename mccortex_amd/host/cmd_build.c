@@ -841,6 +841,12 @@ int ctx_build(int argc, char **argv)
   /* The process ends here: the table and the workspace (tens of GB) go back with it.  Releasing
    * them one hipFree at a time first took 0.3 s of a 1.5 s run (MCX_KEEP_DESTROY=1 does it anyway). */
   if (getenv("MCX_KEEP_DESTROY")) mcx_graph_destroy(g);
+  else {
+    /* ... but only after the device has confirmed that nothing is in flight or went wrong late: a
+     * fault that would surface at destroy time must not be lost with the fast exit */
+    mcx_check(mcx_graph_sync(g), "final sync");
+    host_fast_exit_ok = 1;
+  }
   stage_time("device released");
   for (size_t t = 0; t < ntasks; t++) { pthread_mutex_destroy(&readers[t].mu); pthread_cond_destroy(&readers[t].cv); }
   free(readers);

@@ -23,6 +23,7 @@
 
 /* ---- logging (src/global/ctx_output.h:14-34) ---- */
 extern FILE *msg_out; /* NULL = quiet */
+extern int host_fast_exit_ok; /* set by a `build` that finished and saw its device idle: main() may _exit */
 void status(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void warn(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void die(const char *fmt, ...) __attribute__((format(printf, 1, 2), noreturn));

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 FILE *msg_out = NULL;
+int host_fast_exit_ok = 0;
 static char g_cmdline[4096] = "";
 static char g_runcode[4] = "xxx";
 

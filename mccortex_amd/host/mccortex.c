@@ -62,8 +62,12 @@ int main(int argc, char **argv)
   if (rc == 0) status("[time] %.2f seconds", secs);
   status(rc == 0 ? "  Done." : "  Fail.");
   /* Everything is written and closed.  Leaving through exit() would run the HIP runtime's teardown
-   * over tens of GB of device allocations (0.1-0.3 s); the kernel driver reclaims them anyway. */
+   * over tens of GB of device allocations (0.1-0.3 s); the kernel driver reclaims them anyway.
+   * Only a `build` that succeeded and has seen its device idle after the last call takes the
+   * short way out (it sets host_fast_exit_ok).  Every other command and every failure returns
+   * normally: atexit handlers, the HIP runtime's teardown and whatever profilers / sanitizers flush
+   * at exit (rocprofv3, ASan/LSan, gcov) run as usual.  MCX_KEEP_DESTROY=1 forces the normal path. */
   fflush(NULL);
-  if (!getenv("MCX_KEEP_DESTROY")) _exit(rc);
+  if (rc == 0 && host_fast_exit_ok && !getenv("MCX_KEEP_DESTROY")) _exit(0);
   return rc;
 }

@@ -7,6 +7,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #define IN_BUF (4u << 20)
@@ -123,10 +124,14 @@ int seq_in_guess_fq_offset(const seq_in *s) { return fq_offset_from_range(s->qmi
 
 /* The offset of a file, decided ONCE from the head of the file (the first 1000 records with
  * qualities) before anything of it is loaded, so that it depends neither on -t nor on which batch
- * is parsed first.  0 = not a FASTQ file / no qualities; -1 = cannot look ahead (stdin). */
+ * is parsed first.  0 = not a FASTQ file / no qualities; -1 = cannot look ahead: stdin, a FIFO,
+ * a process substitution (/dev/fd/N) -- anything that is not a regular file can only be read once,
+ * so probing it would swallow the head of the stream; the offset is then latched from the first
+ * batch of the real load (fq_abs_of / the ingest callback in cmd_build.c). */
 int fq_offset_probe(const char *path)
 {
-  if (strcmp(path, "-") == 0) return -1;
+  struct stat st;
+  if (strcmp(path, "-") == 0 || stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return -1;
   seq_in *s = seq_in_open(path);
   if (!s) return 0;
   int off = 0;

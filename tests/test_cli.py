@@ -423,3 +423,33 @@ def test_quality_offset_is_decided_once_per_file(built, orc, tmp_path):
         rc, _, err = run(31, "build", "-q", "-t", t, "-k", "21", "-n", "4M", "-S", "-s", "s", "-Q", "10", "--seq", fq, out)
         assert rc == 0, err
         assert open(out, "rb").read() == want, t
+
+
+@pytest.mark.gpu
+def test_quality_cutoff_on_a_fifo_keeps_the_head_of_the_stream(built, orc, tmp_path):
+    """`-Q` without --fq-offset on an input that can only be read once (a FIFO, <(zcat x.fq.gz)): the
+    offset probe must not open it -- it would swallow the first records -- and the offset is latched
+    from the first batch instead.  Same .ctx as from the regular file."""
+    import threading
+    bases, offs = synth.reads(20000, 100, genome_len=40000, seed=77)
+    quals = np.full(len(bases), ord("I"), dtype=np.uint8)
+    quals[5::53] = ord("#")
+    fq = _write_inputs(tmp_path, bases, offs, "ff", "fq", qual=quals)
+    og = orc.Graph(21, 1, 1 << 22)
+    og.set_sample(0, "s")
+    st = og.add_reads(0, bases, offs, quals=quals, fq_cutoff=43)
+    og.update_stats(0, st)
+    want = og.ctx_bytes(True)
+    fifo = str(tmp_path / "reads.fifo")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(open(fq, "rb").read())
+    th = threading.Thread(target=feed)
+    th.start()
+    out = str(tmp_path / "fifo.ctx")
+    rc, _, err = run(31, "build", "-q", "-t", "2", "-k", "21", "-n", "4M", "-S", "-s", "s", "-Q", "10", "--seq", fifo, out)
+    th.join()
+    assert rc == 0, err
+    assert open(out, "rb").read() == want

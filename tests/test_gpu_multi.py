@@ -129,3 +129,43 @@ def test_multi_add_records_and_stream(mcx, orc):
 def test_multi_needs_power_of_two(mcx):
     with pytest.raises(mcx.McxError):
         mcx.Graph(31, 1, 1 << 20, devices=[0, 0, 0])
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_multi_hot_kmers_spill_instead_of_failing(mcx, orc, k):
+    """Low-complexity input on a sharded table: a 3 Mbase poly-G read and 4000 poly-A reads put
+    millions of occurrences of ONE k-mer on one owner -- far beyond its (owner, region) segment
+    (mean + 8 sigma) and the owner's overflow bin (>= 64 K tuples).  One GPU handles that with a direct
+    insert on the spot; the multi-GPU sender spills what fits nowhere and the host routes it to the
+    owners (mcx_multi.h, group_route_spill).  Same graph as the oracle, in one piece and in many."""
+    rng = np.random.default_rng(5)
+    reads = [b"G" * 3_000_000]
+    reads += [b"A" * 150] * 4000
+    reads += [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 150)) for _ in range(2000)]
+    reads += [b"ACACACACAC" * 30000]
+    bases, offs = orc.pack_reads(reads)
+    og = orc.Graph(k, 1, 1 << 20)
+    ost = og.add_reads(0, bases, offs)
+    want = og.ctx_bytes(True)[og.header_size():]
+    for piece in (None, "300000"):
+        if piece:
+            os.environ["MCX_MULTI_PIECE"] = piece
+        try:
+            g = _multi(mcx, k, 1, [0, 0])
+            g.add_reads(0, bases, offs)
+            g.add_reads(0, bases, offs)  # the send sets are reused: what they spilled is routed first
+            g.sync()
+            st = g.device_stats()
+            assert st.num_kmers_loaded == 2 * ost.num_kmers_loaded
+            assert g.nkmers == og.nkmers
+            body = g.export(True)
+            g.close()
+        finally:
+            os.environ.pop("MCX_MULTI_PIECE", None)
+        rs = 8 * ((2 * k + 63) // 64) + 5
+        a = np.frombuffer(body, np.uint8).reshape(-1, rs).copy()
+        b = np.frombuffer(want, np.uint8).reshape(-1, rs)
+        assert (a[:, :rs - 5] == b[:, :rs - 5]).all() and (a[:, -1] == b[:, -1]).all()   # keys and edges
+        ca = a[:, rs - 5:rs - 1].copy().view("<u4")[:, 0].astype(np.int64)
+        cb = b[:, rs - 5:rs - 1].copy().view("<u4")[:, 0].astype(np.int64)
+        assert (ca == np.minimum(2 * cb, 0xFFFFFFFF)).all()                               # every read twice

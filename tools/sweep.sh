@@ -4,6 +4,7 @@
 # Usage: [STEPS=10] [ONLY="a b"] tools/sweep.sh [extra bench args]
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
+shopt -s nullglob
 for so in "" build/variants/lib_*.so; do
   name=${so:-default}
   if [ -n "$ONLY" ] && [ -n "$so" ]; then
