@@ -4,17 +4,22 @@
 Workload (BASELINE.json configs[1], "C2"): k=31, 1 colour, synthetic 150 bp reads drawn from a
 200 Mbp random genome (50% reverse strand, 0.1% substitutions, 1% of reads with an N), table of
 2^30 slots.  One step = one batch of 5,000,000 reads (600M k-mer occurrences) that is already
-resident in HBM as a '\\n'-separated ASCII byte stream (`value`: parse and H2D are outside the number);
-the default 10 steps are the 50M x 150bp set.  The same run also reports, as separate objects of the
+resident in HBM as a '\\n'-separated ASCII byte stream (`value`: the 2-bit packing of the bases is
+INSIDE the clock -- the kernel encodes the ASCII bytes in its tile prologue; parse and H2D are outside:
+see `host_fed` and `e2e`); 10 steps are the 50M x 150bp set.  The same run also reports, as separate objects of the
 JSON line: `host_fed` (the same reads handed over in host memory: staging + PCIe inside the clock),
 `e2e` (`mccortex31 build --sort` on a FASTQ file of the same shape: process start, parse, build, sort,
 .ctx write), `default_defer` (the library's own flush size instead of the bench's), `other_configs`
 (C4: k=63; C5-like: 4 colours) and `cpu_baseline` (the oracle on the host cores).
 
-N>1 (one process per GPU, torchrun): weak scaling -- every rank takes its own 5M-read batch per step
-(genome scaled to N x 200 Mbp so every shard sees the same load), cuts the reads into per-owner
-super-k-mer records (owner = hash of the k-mer's canonical minimizer), exchanges them with RCCL
-all-to-alls and k-merises + inserts what it owns (exchange format v3).
+N>1 (one process per GPU, torchrun).  Default `--scaling strong` = BASELINE config C3: the SAME reads
+as N=1 (step i is the same 5M-read batch, every rank takes reads [r B/N, (r+1) B/N) of it), the same
+200 Mbp genome, a table of 2^30 slots IN TOTAL (2^30 / N per GPU); the sum of the ranks' graph
+checksums must equal the N=1 `graph_checksum` (`config.checksum_matches_n1`).  `--scaling weak`: every
+rank takes its own 5M-read batch per step (genome scaled to N x 200 Mbp, 2^30 slots per GPU).  Either
+way a rank cuts its reads into per-owner super-k-mer records (owner = hash of the k-mer's canonical
+minimizer), exchanges them with RCCL all-to-alls and k-merises + inserts what it owns (exchange
+format v3).
 """
 import argparse
 import json
@@ -40,6 +45,11 @@ DEFER_TUPLES = 8_000_000_000  # k-mer occurrences buffered per flush of the part
 # algorithmic bytes per k-mer occurrence of every kernel of that path
 KERNEL_ALG_BYTES = {"k_stream": 21.25, "k_stream_bin": 1.25 + 8.0, "k_tuples_bin": 16.0, "k_lds_insert": 8.0,
                     "k_insert_tuples": 29.0, "k_stream_superk": 1.25 + 2.3, "k_superk_bin": 2.3 + 8.0}
+
+
+# graph_checksum of the default workload (B = 5M reads per step, 200 Mbp genome, err 0.001) after
+# `steps` steps, as N=1 runs of this file report it (BENCH_r02.json: 20 steps; profiles/r02g: 10)
+N1_CHECKSUMS = {10: "c72ff066d6a527ec", 20: "bc686b82dd898aa5"}
 
 
 def make_genome(n, device, seed):
@@ -255,10 +265,17 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, 0, pk)
     r["what"] = "as `value`, but with the library's default flush size instead of %d occurrences" % DEFER_TUPLES
     out["default_defer"] = r
-    if pk is not None:  # the same build from the ASCII form of the stream (what `value` was in round 1)
+    if pk is not None:  # the same build from the ASCII form of the stream (what `value` is by default)
         r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, DEFER_TUPLES, None)
         r["what"] = "as `value`, but the resident stream is ASCII (1 byte per position; the kernel encodes it in its tile prologue)"
         out["ascii_resident"] = r
+    else:               # ... and from the packed form the host entry stages (packing outside the clock: round 2's `value`)
+        pk2 = pack_batches(mcx, steps)
+        r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, DEFER_TUPLES, pk2)
+        r["what"] = "as `value`, but the resident stream is already packed (2-bit codes + invalid flags, 3 bits per position): the packing is OUTSIDE this clock"
+        out["packed_resident"] = r
+        del pk2
+        torch.cuda.empty_cache()
     # (e) C4: k = 63 (two-word keys); C5-like: 4 colours on one GPU
     r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, 5_000_000_000, pk)
     r["workload"] = "C4: k=63 (2-word BinaryKmer), 1 colour, %d reads x %d bp per step, table %d slots, 1 GPU" % (B, READ_LEN, table_slots)
@@ -267,6 +284,10 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000, pk)
     r["workload"] = "C5-like: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
     out["other_configs"]["C5_like_4_colours_1gpu"] = r
+    cols = [i % 4 for i in range(len(steps))]  # a population build alternates samples: colour switches at every step
+    r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000, pk)
+    r["workload"] = "C5-like, colours interleaved: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
+    out["other_configs"]["C5_like_interleaved_colours_1gpu"] = r
     # (f) the multi-GPU table of the C ABI (mcx_graph_create_multi) with BOTH shards on this one GPU:
     # sender kernel -> peer copy (device-local here) -> owner split -> LDS insert; a check of the
     # code path and of its overheads, not a scaling figure
@@ -275,6 +296,8 @@ def extras(mcx, batches, packed, nsteps, table_slots):
         g.configure("defer_tuples", 3_000_000_000)
         if pk is not None:
             g.add_packed_dev(0, pk[0][0][:4096], pk[0][1][:4096], 65536)
+        else:
+            g.add_stream_dev(0, steps[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
         g.sync(); g.reset(); g.sync()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -342,7 +365,7 @@ def extras(mcx, batches, packed, nsteps, table_slots):
         nthreads = min(32, os.cpu_count() or 1)
         cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-t", str(nthreads), "--sort", "--sample", "bench", "--seq", fq, ctx]
         best = None
-        runs = []
+        runs, recs = [], []
         for _ in range(3):  # later runs: file in the page cache, HIP kernels' code objects loaded before
             if os.path.exists(ctx):
                 os.unlink(ctx)  # (overwriting 3 GB of dirty page cache is not part of the command)
@@ -353,8 +376,8 @@ def extras(mcx, batches, packed, nsteps, table_slots):
             if p.returncode != 0:
                 raise RuntimeError("mccortex31 build failed: " + p.stderr.decode(errors="replace")[-400:])
             runs.append(round(dt, 3))
-            if best is None or dt < best[0]:
-                best = (dt, p.stderr.decode(errors="replace"), w0, w1)
+            recs.append((dt, p.stderr.decode(errors="replace"), w0, w1))
+        best = sorted(recs, key=lambda r: r[0])[len(recs) // 2]  # the MEDIAN run (all three are listed in runs_s)
         kmers = ne * B * (READ_LEN - K + 1)  # upper bound; the exact figure: reads with an N lose a few
         for line in best[1].splitlines():
             if "kmers" in line and "Loaded" in line:
@@ -368,7 +391,7 @@ def extras(mcx, batches, packed, nsteps, table_slots):
         out["e2e"] = {"value": kmers / best[0], "unit": "k-mers/s (upper bound on k-mers: %d per read)" % (READ_LEN - K + 1),
                       "seconds": best[0], "fastq_bytes": os.path.getsize(fq), "ctx_bytes": os.path.getsize(ctx),
                       "command": "mccortex31 build -k %d -n %d -t %d --sort --seq <%d-read FASTQ> out.ctx" % (K, table_slots, nthreads, ne * B),
-                      "what": "wall clock of the whole process (start, HIP init, parse, build, device sort, .ctx write), best of 3 runs",
+                      "what": "wall clock of the whole process (start, HIP init, parse, build, device sort, .ctx write), MEDIAN of 3 runs (all in runs_s; stages are the median run's)",
                       "runs_s": runs,
                       "process": outside, "stages": [x for x in stages if "epoch_" not in x][-14:]}
         out["_fastq_sample"] = fq_small
@@ -387,8 +410,11 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the device-resident figure (profiling passes)")
-    ap.add_argument("--input", choices=("packed", "ascii"), default="packed",
-                    help="form of the resident stream: 2-bit codes + invalid flags (what the host entry stages), or ASCII")
+    ap.add_argument("--input", choices=("packed", "ascii"), default="ascii",
+                    help="form of the resident stream: ASCII (default: the 2-bit packing is inside the clock), or the packed "
+                         "form the host entry stages (2-bit codes + invalid flags; reported as packed_resident by default)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = the same reads and the same total table as N = 1 (config C3); weak = per-GPU work fixed")
     ap.add_argument("--table-slots", type=int, default=TABLE_SLOTS, help="experiments only")
     ap.add_argument("--genome", type=int, default=GENOME_PER_GPU, help="experiments only")
     ap.add_argument("--err", type=float, default=0.001, help="experiments only")
@@ -430,8 +456,21 @@ def main():
 
     B = args.batch_reads
     nsteps, nwarm = args.steps, args.warmup
+    sharded = world > 1 or force_shard
+    strong = world > 1 and args.scaling == "strong" and not args.iid
     if args.iid:
         batches = [make_batch_iid(B, seed=1000 * (rank + 1) + i, device=device) for i in range(nsteps + nwarm)]
+    elif strong:
+        # C3: the reads of the N = 1 run.  Step i is the batch N = 1 uses for step i (same seed);
+        # this rank takes reads [rank B / N, (rank + 1) B / N) of it.
+        genome = make_genome(args.genome, device, seed=42)
+        r_lo, r_hi = B * rank // world, B * (rank + 1) // world
+        batches = []
+        for i in range(nsteps + nwarm):
+            full = make_batch(genome, B, seed=1000 + i, device=device, err_rate=args.err)
+            batches.append(full.reshape(B, READ_LEN + 1)[r_lo:r_hi].reshape(-1).clone())
+            del full
+        del genome
     else:
         genome = make_genome(args.genome * world, device, seed=42)
         batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device, err_rate=args.err)
@@ -440,21 +479,22 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()  # hand the generator's temporaries back before the graph allocates
 
-    sharded = world > 1 or force_shard
-    # N > 1: every rank holds a table of the same per-GPU size (weak scaling).  Exchange format: v3 (super-k-mer records, minimizer ownership, ordinary per-rank tables) when
+    # N > 1, weak: every rank holds a table of the same per-GPU size; strong: the N = 1 table split N ways.
+    # Exchange format: v3 (super-k-mer records, minimizer ownership, ordinary per-rank tables) when
     # k allows it, else v2 (packed tuples, table sharded by quotient-hash prefix); MCX_EXCHANGE=v2 forces v2
+    slots_per_gpu = max(1 << 20, args.table_slots // world) if strong else args.table_slots
     use_v3 = sharded and mcx.superk_supported(K) and os.environ.get("MCX_EXCHANGE", "v3") != "v2"
     if use_v3:
-        graph = mcx.Graph(K, 1, args.table_slots, device=local_rank)
+        graph = mcx.Graph(K, 1, slots_per_gpu, device=local_rank)
     else:
-        graph = mcx.Graph(K, 1, args.table_slots, device=local_rank, nparts=world, part=rank)
+        graph = mcx.Graph(K, 1, slots_per_gpu, device=local_rank, nparts=world, part=rank)
     if args.direct:
         graph.configure("defer", 0)
     else:
         graph.configure("defer_tuples", args.defer_tuples)
         # the bin workspace is allocated on first use (the library halves the flush size by itself
         # if HBM is short): touch it outside the timed region
-        graph.add_stream_dev(0, batches[0][:1024 * 151], 1024 * 151)
+        graph.add_stream_dev(0, batches[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
         graph.sync()
         graph.reset()
     use_packed = args.input == "packed" and not sharded
@@ -462,12 +502,23 @@ def main():
     ext = torch.cuda.ExternalStream(graph.stream, device=device)
     W = graph.W
 
+    def exchange_steps(idx):
+        """the streams one all-to-all step moves: a rank's own batch (weak), or -- strong, where a
+        rank's share of a step is B / N reads -- its shares of N consecutive steps in one piece, so that an
+        exchange step carries as many reads as at N = 1"""
+        idx = list(idx)
+        if not strong:
+            return [batches[i] for i in idx]
+        return [torch.cat([batches[i] for i in idx[j:j + world]]) for j in range(0, len(idx), world)]
+
     if sharded:
         # partition -> all-to-all -> insert, double buffered (mccortex_amd/shard.py: ShardedInserter)
-        inserter = shard.ShardedInserter(graph, world, device, batches[0].numel(), use_v3,
-                                         max_tuples=B * (READ_LEN - K + 1))
+        x_timed, x_warm = exchange_steps(range(nsteps)), exchange_steps(range(nsteps, nsteps + nwarm))
+        xmax = max(x.numel() for x in x_timed + x_warm)
+        inserter = shard.ShardedInserter(graph, world, device, xmax, use_v3,
+                                         max_tuples=xmax // (READ_LEN + 1) * (READ_LEN - K + 1))
 
-    def run_steps(idx):
+    def run_steps(idx, xs=None):
         idx = list(idx)
         if not idx:
             return
@@ -479,7 +530,7 @@ def main():
                     graph.add_stream_dev(0, batches[i], batches[i].numel())
             return
         try:
-            inserter.insert(0, [(batches[i], batches[i].numel()) for i in idx])
+            inserter.insert(0, [(x, x.numel()) for x in xs])
         except RuntimeError as e:
             raise SystemExit(str(e))
 
@@ -490,7 +541,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_steps(range(nsteps, nsteps + nwarm))
+    run_steps(range(nsteps, nsteps + nwarm), x_warm if sharded else None)
     fence()
     graph.reset()
     fence()
@@ -499,7 +550,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(ext)
-    run_steps(range(nsteps))
+    run_steps(range(nsteps), x_timed if sharded else None)
     fence()
     ev1.record(ext)
     dt = time.perf_counter() - t0
@@ -526,47 +577,73 @@ def main():
 
     if rank == 0:
         value = kmers_total / dt
+        scaling = "strong" if strong else "weak"
+        if world == 1:
+            shape = "%d reads x %d bp per step from a %d Mbp random genome, table %d slots" % (B, READ_LEN, args.genome // 1_000_000, args.table_slots)
+        elif strong:
+            shape = ("C3: the N=1 reads (%d reads x %d bp per step from a %d Mbp random genome) dealt out to %d GPUs, %d reads per step per GPU, "
+                     "table %d slots in total = %d per GPU" % (B, READ_LEN, args.genome // 1_000_000, world, B // world, args.table_slots, slots_per_gpu))
+        else:
+            shape = ("%d reads x %d bp per step per GPU from a %d Mbp random genome, table %d slots per GPU" %
+                     (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots))
         out = {
             "metric": "k-mers/s inserted (build), k=31, 50M x 150bp synthetic reads",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": nsteps, "warmup": nwarm,
-            "ms_per_step": 1e3 * dt / nsteps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / nsteps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("C2-stress: k=31, 1 colour, %d iid random reads x %d bp per step per GPU, table %d slots per GPU; "
                                     "input resident in HBM as an ASCII byte stream" % (B, READ_LEN, args.table_slots)) if args.iid else
-                                   "C2: k=31, 1 colour, %d reads x %d bp per step per GPU from a %d Mbp random genome, "
-                                   "table %d slots per GPU; input already resident in HBM as %s (parse and H2D "
-                                   "outside `value`: see host_fed and e2e)" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots,
-                                                                                "the packed stream mcx_graph_add_reads stages (2-bit codes + invalid flags, 3 bits per position)"
-                                                                                if use_packed else "an ASCII byte stream"),
+                                   "C2: k=31, 1 colour, %s; input already resident in HBM as %s (parse and H2D "
+                                   "outside `value`: see host_fed and e2e)" % (shape,
+                                                                                "the packed stream mcx_graph_add_reads stages (2-bit codes + invalid flags, 3 bits per position: packing OUTSIDE the clock)"
+                                                                                if use_packed else "an ASCII byte stream (1 byte per position: the 2-bit packing is inside the clock)"),
                        "input": "device-resident packed stream (3 bits per position)" if use_packed else "device-resident ASCII stream",
-                       "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
-                       "table_slots_per_gpu": args.table_slots, "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
+                       "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": (B // world) if strong else B, "read_len": READ_LEN,
+                       "table_slots_per_gpu": slots_per_gpu, "table_slots_total": slots_per_gpu * world,
+                       "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel),
                        "distinct_kmers_total": nodes_total, "graph_checksum": "%016x" % cs_total},
         }
+        # the same reads must give the same graph whatever N is (strong scaling and N = 1): the sum of the
+        # ranks' order-independent checksums against what N = 1 runs of this file report for `steps` steps
+        if (world == 1 or strong) and not args.iid and B == BATCH_READS and args.genome == GENOME_PER_GPU and args.err == 0.001 \
+                and READ_LEN == 150 and nsteps in N1_CHECKSUMS:
+            out["config"]["checksum_matches_n1"] = ("%016x" % cs_total) == N1_CHECKSUMS[nsteps]
         gpu_ms = ev0.elapsed_time(ev1)
         dom = max(prof, key=lambda n: prof[n][1])
         calls, tot_ms = prof[dom]
         avg_ms = tot_ms / calls
-        # algorithmic bytes of ONE launch of the dominant kernel: its per-occurrence figure
-        #  x the occurrences one launch processes
+        # ROOFLINE, as SURVEY.md 8(d) defines it: algorithmic bytes of the path -- 21.25 B per k-mer occurrence
+        # (1.25 input + 8 key read + 8 coverage RMW + ~4 edge RMW) + 8 B per novel key -- over the GPU time of
+        # the whole timed region (HIP events on the handle's stream), against 8 TB/s.  The path is three kernels
+        # of comparable length, so the figure is taken over all of them; each kernel's own design bytes over its
+        # own time are under `kernels` (dominant kernel: `dominant`).
         in_b = (0.375 if use_packed else 1.0) * (READ_LEN + 1) / (READ_LEN - K + 1.0)  # stream bytes per occurrence
         kalg = dict(KERNEL_ALG_BYTES, k_stream_bin=in_b + 8.0)
         alg_bytes = kalg[dom] * kmers_local / calls
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         pipe_bytes = ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel
-        traffic, traffic_src = pmc_traffic(dom, kmers_local / calls)
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "avg_kernel_ms": avg_ms, "launches": calls, "alg_bytes_per_launch": alg_bytes,
-                           # every kernel of the path: its own algorithmic bytes per occurrence (tuples and bases
-                           # only; k_lds_insert also streams the table once per flush) over its time
-                           "kernels": kernel_table(prof, kmers_local, 1, in_b),
-                           "pipeline": {"gpu_ms": gpu_ms, "alg_bytes": pipe_bytes,
-                                        "achieved": pipe_bytes / (gpu_ms * 1e-3) / 1e9,
-                                        "frac": pipe_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "note": "SURVEY 8(d) 21.25 B per occurrence (+8 B per novel key) over the whole timed region"}}
+        pipe_ach = pipe_bytes / (gpu_ms * 1e-3) / 1e9
+        ktab = kernel_table(prof, kmers_local, 1, in_b)
+        # HBM bytes of the whole path per occurrence from the newest PMC summary taken on these kernel sources
+        tr_total, tr_src = 0.0, None
+        for kn in ktab:
+            t_k, src_k = pmc_traffic(kn, kmers_local)
+            if t_k is None:
+                tr_total, tr_src = None, src_k
+                break
+            tr_total += t_k
+            tr_src = src_k
+        out["roofline"] = {"bound": "hbm", "achieved": pipe_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pipe_ach / HBM_PEAK_GBS,
+                           "traffic": tr_total, "traffic_source": tr_src,
+                           "what": "SURVEY 8(d): (21.25 B x k-mer occurrences + 8 B x novel keys) / GPU time of the timed region; "
+                                   "traffic = PMC HBM bytes of the three kernels over the same region (null: no summary for these sources)",
+                           "alg_bytes": pipe_bytes, "gpu_ms": gpu_ms, "alg_bytes_per_kmer": ALG_BYTES_PER_KMER, "alg_bytes_per_novel_key": ALG_BYTES_PER_NOVEL,
+                           "kernels": ktab,
+                           "dominant": {"kernel": dom, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_kernel_ms": avg_ms, "launches": calls,
+                                        "alg_bytes_per_launch": alg_bytes,
+                                        "note": "the dominant kernel's OWN design bytes (stream + packed tuples) over its average launch"}}
         # SURVEY 8(d)'s second ceiling: one random 64-byte sector RMW per occurrence is what the
         # reference's algorithm (and the direct path here) costs; the chip does 17.3 G of those per
         # second on a 16 GiB table (tools/ubench_atomics*.hip, profiles/r01_ubench_atomics*.log).
@@ -579,7 +656,7 @@ def main():
             graph.close()
             torch.cuda.empty_cache()
             ex = extras(mcx, batches, packed, nsteps, args.table_slots)
-            for key in ("host_fed", "e2e", "default_defer", "ascii_resident", "other_configs", "inprocess_2_shards_1gpu"):
+            for key in ("host_fed", "e2e", "default_defer", "ascii_resident", "packed_resident", "other_configs", "inprocess_2_shards_1gpu"):
                 if key in ex:
                     out[key] = ex[key]
         if not args.no_cpu_baseline and not sharded:

@@ -101,6 +101,7 @@ class StagePool {
 };
 
 constexpr uint64_t kCarry = 128;  // context bytes carried between chunks
+constexpr uint32_t kL1Sets = 32;  // L1 bin sets of a graph with several colours (mcx_graph::nsets; <= TupleIn::set_map)
 // New stream bytes per staged chunk (MCX_STAGE_BYTES overrides, for tests of the chunk seams).
 static uint64_t stage_bytes()
 {
@@ -144,7 +145,18 @@ struct mcx_graph {
   hipStream_t stream2 = nullptr;  // flush overlap: the LDS insert of group g runs beside the split of group g + 1
   hipEvent_t ev_split[2] = {nullptr, nullptr}, ev_ins[2] = {nullptr, nullptr};
   unsigned long long *l1_cnt = nullptr, *l2_cnt = nullptr;
-  uint64_t pending = 0;         // upper bound of tuples sitting in the L1 bins
+  // L1 bin sets.  A one-colour graph has one set: the L1 bins.  A graph with several colours cuts the
+  // same workspace into kL1Sets smaller sets, each [rep1][b1][cap1]; a set is bound to the colour that
+  // first writes to it and takes set_cap occurrences (upper bound), a colour takes as many sets as it
+  // needs, and nothing is flushed until the pool is exhausted -- so the samples of a population build
+  // may alternate (db_node.h:240-241: coverage and edges are per colour) without a table pass per
+  // switch.  A flush then makes ONE pass per colour: all sets of a colour are split in one launch
+  // (TupleIn::set_map) and applied by one LDS insert.
+  uint32_t nsets = 1;
+  uint64_t set_cap = 0;                 // occurrences (upper bound) one set takes
+  std::vector<int> set_colour;          // colour a set is bound to, -1 = free
+  std::vector<uint64_t> set_pending;    // upper bound of the tuples in the set
+  uint64_t pending = 0;         // upper bound of tuples sitting in the L1 bins (all sets)
   uint64_t pending_l2 = 0;      // tuples already split into the sub-table bins (sharded receive path)
   uint32_t l2_regions = 0;      // regions the L2 (sub-table) bins cover: a flush splits and applies
                                 // the L1 bins in groups of this many regions, reusing the same bins
@@ -168,6 +180,11 @@ struct mcx_graph {
 
 static int flush_deferred(mcx_graph *g);
 static void free_defer(mcx_graph *g);
+static void sets_release(mcx_graph *g)
+{
+  std::fill(g->set_colour.begin(), g->set_colour.end(), -1);
+  std::fill(g->set_pending.begin(), g->set_pending.end(), 0);
+}
 struct StreamLaunch;
 static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int colour);
 static void group_destroy(mcx_group *G);
@@ -361,10 +378,11 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->t.touch, 0, g->touch_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
-  if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
+  if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->nsets * g->b1 * g->rep1 * 8, g->stream));
   if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->l2_regions * g->subs_per_bin * 8, g->stream));
   if (g->d_readstrt) HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
   g->pending = g->pending_l2 = 0;  // buffered tuples are discarded with the table
+  sets_release(g);
   return MCX_OK;
 }
 
@@ -559,6 +577,7 @@ static void free_defer(mcx_graph *g)
   g->l1_keys = g->l2_keys = nullptr; g->l1_cnt = g->l2_cnt = nullptr;
   g->cap1 = g->cap2 = 0;
   g->l2_regions = 0;
+  g->set_colour.clear(); g->set_pending.clear();
 }
 
 // The sub-table (L2) bins cover `regions` regions at a time.  A flush walks the L1 bins in groups
@@ -642,21 +661,33 @@ static int ensure_defer(mcx_graph *g)
   for (;; tcap /= 2) {
     if (tcap < (1ull << 20)) { g->defer = false; g->defer_tuples = 0; (void)hipGetLastError(); return MCX_OK; }
     g->defer_tuples = tcap;
-    g->cap1 = (uint64_t)((double)tcap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + 8192;
+    g->nsets = g->ncols > 1 ? kL1Sets : 1;
+    if (const char *e = getenv("MCX_L1_SETS")) { const int v = atoi(e); if (v >= 1 && v <= 32) g->nsets = (uint32_t)v; }  // tests / experiments
+    g->set_cap = tcap / g->nsets;
+    g->cap1 = (uint64_t)((double)g->set_cap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + (g->nsets > 1 ? 2048 : 8192);
     g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
     g->cap1 = (g->cap1 + 1) & ~1ull;  // even: every segment starts 16-byte aligned (vector loads)
     g->cap2 = (g->cap2 + 1) & ~1ull;
     if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) continue;
-    const uint64_t n1 = (uint64_t)g->b1 * g->rep1 * g->cap1;
+    const uint64_t n1 = (uint64_t)g->nsets * g->b1 * g->rep1 * g->cap1;
     const bool ok = hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W) == hipSuccess &&
-                    hipMalloc((void **)&g->l1_cnt, (size_t)g->b1 * g->rep1 * 8) == hipSuccess &&
+                    hipMalloc((void **)&g->l1_cnt, (size_t)g->nsets * g->b1 * g->rep1 * 8) == hipSuccess &&
                     ensure_l2(g, flush_overlap() ? std::min<uint32_t>(2 * flush_group(g), g->b1) : flush_group(g)) == MCX_OK;
     if (ok) break;
     free_defer(g);
     (void)hipGetLastError();  // clear the sticky out-of-memory error
   }
-  HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
+  HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->nsets * g->b1 * g->rep1 * 8, g->stream));
+  g->set_colour.assign(g->nsets, -1);
+  g->set_pending.assign(g->nsets, 0);
   return MCX_OK;
+}
+
+// the L1 bins of set `set` as the output of a binning kernel
+static BinOut l1_out(const mcx_graph *g, int set)
+{
+  const uint64_t segs = (uint64_t)g->b1 * g->rep1;
+  return BinOut{g->l1_keys + (uint64_t)set * segs * g->cap1 * g->W, nullptr, g->l1_cnt + (uint64_t)set * segs, g->cap1, nullptr, nullptr, nullptr, 0};
 }
 
 // Split the L1 bins by sub-table and let one workgroup per sub-table apply its tuples in LDS,
@@ -684,45 +715,101 @@ static int flush_deferred(mcx_graph *g)
     HIP_TRY(hipEventRecord(g->ev_split[0], s1));  // the second stream starts behind everything queued so far
     HIP_TRY(hipStreamWaitEvent(g->stream2, g->ev_split[0], 0));
   }
+  // One pass over the table per colour that has tuples pending: the colour whose tuples already sit
+  // in the sub-table bins (split on arrival) first -- that empties them --, then the colours of the
+  // L1 sets in the order in which they first took a set.
+  std::vector<int> colours;
+  if (g->pending_l2) colours.push_back(g->pending_colour);
+  for (uint32_t s = 0; s < g->nsets && g->pending; s++) {
+    const int c = g->set_colour[s];
+    if (c >= 0 && g->set_pending[s] && std::find(colours.begin(), colours.end(), c) == colours.end()) colours.push_back(c);
+  }
   uint32_t gi = 0;
-  for (uint32_t r0 = 0; r0 < g->b1; r0 += G, gi++) {
-    const uint32_t ng = std::min(G, g->b1 - r0);
-    const int hb = overlap ? (int)(gi & 1u) : 0;
-    g->l2_off = (uint64_t)hb * G * g->subs_per_bin;
-    if (overlap && gi >= 2) HIP_TRY(hipStreamWaitEvent(s1, g->ev_ins[hb], 0));  // this half's previous insert has emptied it
-    if (g->pending) {
-      TupleIn in{g->l1_keys + (uint64_t)r0 * g->cap1 * g->W, nullptr, g->l1_cnt + r0, g->cap1, ng * g->rep1, ng, g->b1};
-      BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, ng * g->subs_per_bin, ng, 0, r0};
-      BinOut out{g->l2_keys + g->l2_off * g->cap2 * g->W, nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
-      DISPATCH_WC(g, launch_split_regions, g, in, g->pending_colour, bs, out);
+  for (size_t ci = 0; ci < colours.size(); ci++) {
+    const int colour = colours[ci];
+    TupleIn in{};
+    uint32_t nmine = 0;  // sets of this colour
+    for (uint32_t s = 0; s < g->nsets && g->pending; s++)
+      if (g->set_colour[s] == colour && g->set_pending[s]) in.set_map[nmine++] = (uint8_t)s;
+    for (uint32_t r0 = 0; r0 < g->b1; r0 += G, gi++) {
+      const uint32_t ng = std::min(G, g->b1 - r0);
+      const int hb = overlap ? (int)(gi & 1u) : 0;
+      g->l2_off = (uint64_t)hb * G * g->subs_per_bin;
+      if (overlap && gi >= 2) HIP_TRY(hipStreamWaitEvent(s1, g->ev_ins[hb], 0));  // this half's previous insert has emptied it
+      if (nmine) {
+        // segment s = (replica q of the colour's sets, region r0 + s % ng): physical replica through set_map
+        in.keys = g->l1_keys + (uint64_t)r0 * g->cap1 * g->W;
+        in.edges = nullptr;
+        in.counts = g->l1_cnt + r0;
+        in.seg_cap = g->cap1;
+        in.nseg = ng * g->rep1 * nmine;
+        in.seg_group = ng;
+        in.seg_stride = g->b1;
+        in.set_rep = g->nsets > 1 ? g->rep1 : 0;
+        BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, ng * g->subs_per_bin, ng, 0, r0};
+        BinOut out{g->l2_keys + g->l2_off * g->cap2 * g->W, nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
+        DISPATCH_WC(g, launch_split_regions, g, in, colour, bs, out);
+        HIP_TRY(hipGetLastError());
+      }
+      if (overlap) {
+        HIP_TRY(hipEventRecord(g->ev_split[hb], s1));
+        HIP_TRY(hipStreamWaitEvent(g->stream2, g->ev_split[hb], 0));
+        g->stream = g->stream2;
+      }
+      DISPATCH_WC(g, launch_lds_insert_t, g, colour, r0 * g->subs_per_bin, ng * g->subs_per_bin);
+      g->stream = s1;
       HIP_TRY(hipGetLastError());
+      if (overlap) HIP_TRY(hipEventRecord(g->ev_ins[hb], g->stream2));
     }
-    if (overlap) {
-      HIP_TRY(hipEventRecord(g->ev_split[hb], s1));
-      HIP_TRY(hipStreamWaitEvent(g->stream2, g->ev_split[hb], 0));
-      g->stream = g->stream2;
-    }
-    DISPATCH_WC(g, launch_lds_insert_t, g, g->pending_colour, r0 * g->subs_per_bin, ng * g->subs_per_bin);
-    g->stream = s1;
-    HIP_TRY(hipGetLastError());
-    if (overlap) HIP_TRY(hipEventRecord(g->ev_ins[hb], g->stream2));
   }
   g->l2_off = 0;
   if (overlap)
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(s1, g->ev_ins[i], 0));
-  if (g->pending) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->b1 * g->rep1 * 8, g->stream));
+  if (g->pending) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->nsets * g->b1 * g->rep1 * 8, g->stream));
   g->pending = 0;
   g->pending_l2 = 0;
+  sets_release(g);
   return MCX_OK;
 }
 
-// make room for `ub` more tuples of `colour` in the L1 bins
-static int defer_reserve(mcx_graph *g, int colour, uint64_t ub)
+// Make room for `ub` more tuples of `colour` in the L1 bins: -> the set that takes them.  A set
+// that is bound to the colour and has room, else a free set, else a flush (which frees them all).
+// `ub` beyond a set's capacity is accepted for an EMPTY set (callers that only know an upper bound
+// of what a device-side fill holds): a segment that overflows falls back to the direct insert.
+static int defer_reserve(mcx_graph *g, int colour, uint64_t ub, int *set_out = nullptr)
+{
+  if (set_out) *set_out = 0;
+  int rc = ensure_defer(g);
+  if (rc != MCX_OK || !g->defer) return rc;
+  for (int pass = 0; pass < 2; pass++) {
+    int free_set = -1;
+    for (uint32_t s = 0; s < g->nsets; s++) {
+      if (g->set_colour[s] == colour && g->set_pending[s] + ub <= g->set_cap) {
+        g->set_pending[s] += ub; g->pending += ub;
+        if (set_out) *set_out = (int)s;
+        return MCX_OK;
+      }
+      if (g->set_colour[s] < 0 && free_set < 0) free_set = (int)s;
+    }
+    if (free_set >= 0) {
+      g->set_colour[free_set] = colour;
+      g->set_pending[free_set] = ub; g->pending += ub;
+      if (set_out) *set_out = free_set;
+      return MCX_OK;
+    }
+    rc = flush_deferred(g);
+    if (rc != MCX_OK) return rc;
+  }
+  return fail(MCX_ERR_ARG, "internal: no L1 bin set after a flush");
+}
+
+// the sub-table bins take tuples of one colour at a time (sharded receive path: split on arrival)
+static int l2_reserve(mcx_graph *g, int colour, uint64_t ub)
 {
   int rc = ensure_defer(g);
   if (rc != MCX_OK || !g->defer) return rc;
-  if ((g->pending || g->pending_l2) &&
-      (colour != g->pending_colour || g->pending + g->pending_l2 + ub > g->defer_tuples)) {
+  if ((g->pending_l2 && colour != g->pending_colour) ||
+      ((g->pending_l2 || g->pending) && g->pending_l2 + g->pending + ub > g->defer_tuples)) {
     rc = flush_deferred(g);
     if (rc != MCX_OK) return rc;
   }
@@ -741,16 +828,21 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
   }
   // pieces of at most defer_tuples start positions (an upper bound of the tuples they yield)
   for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
-    const uint64_t hi = std::min(L.pos_hi, lo + g->defer_tuples);
-    int rc = defer_reserve(g, colour, hi - lo);
+    // a piece goes to ONE set: what is left of the colour's current set, or a fresh set
+    uint64_t room = g->set_cap;
+    for (uint32_t s = 0; s < g->nsets; s++)
+      if (g->set_colour[s] == colour && g->set_pending[s] < g->set_cap) { room = g->set_cap - g->set_pending[s]; break; }
+    if (room < (uint64_t)kTile * 16 && room < L.pos_hi - lo) room = g->set_cap;  // (not worth a launch: take a fresh set)
+    const uint64_t hi = std::min(L.pos_hi, lo + room);
+    int set = 0;
+    int rc = defer_reserve(g, colour, hi - lo, &set);
     if (rc != MCX_OK) return rc;
     StreamLaunch P = L;
     P.pos_lo = lo; P.pos_hi = hi;
     BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
-    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
+    BinOut out = l1_out(g, set);
     DISPATCH_WC(g, launch_bin_region_stream, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
-    g->pending += hi - lo;
     lo = hi;
   }
   return MCX_OK;
@@ -946,15 +1038,15 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
     return MCX_OK;
   }
   for (uint64_t lo = 0; lo < n;) {
-    const uint64_t cnt = std::min(n - lo, g->defer_tuples);
-    int rc = defer_reserve(g, colour, cnt);
+    const uint64_t cnt = std::min(n - lo, g->set_cap);
+    int set = 0;
+    int rc = defer_reserve(g, colour, cnt, &set);
     if (rc != MCX_OK) return rc;
     TupleIn in{(const uint64_t *)d_keys + lo * g->W, (const uint8_t *)d_edges + lo, nullptr, cnt, 1, 1, 1};
     BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
-    BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
+    BinOut out = l1_out(g, set);
     DISPATCH_WC(g, launch_bin_received, g, in, colour, bs, out);
     HIP_TRY(hipGetLastError());
-    g->pending += cnt;
     lo += cnt;
   }
   return MCX_OK;
@@ -972,15 +1064,15 @@ extern "C" int mcx_graph_insert_tuple_segments_dev(mcx_graph *g, int colour, con
   int rc = ensure_defer(g);
   if (rc != MCX_OK) return rc;
   if (!g->defer) return fail(MCX_ERR_ARG, "tuple segments need the deferred insert path (table too small or defer=0)");
-  const uint64_t ub = (uint64_t)nseg * seg_cap;  // the fills are only known on the device
-  rc = defer_reserve(g, colour, ub);
+  const uint64_t ub = std::min<uint64_t>((uint64_t)nseg * seg_cap, g->set_cap);  // the fills are only known on the device
+  int set = 0;
+  rc = defer_reserve(g, colour, ub, &set);
   if (rc != MCX_OK) return rc;
   TupleIn in{(const uint64_t *)d_keys, (const uint8_t *)d_edges, (const unsigned long long *)d_counts, seg_cap, nseg, nseg, nseg};
   BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
-  BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
+  BinOut out = l1_out(g, set);
   DISPATCH_WC(g, launch_bin_received, g, in, colour, bs, out);
   HIP_TRY(hipGetLastError());
-  g->pending += ub;
   return MCX_OK;
 }
 
@@ -1047,7 +1139,7 @@ extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *
   if (rc != MCX_OK) return rc;
   if (!g->defer) return fail(MCX_ERR_ARG, "packed segments need the deferred insert path (table too small or defer=0)");
   if (nseg % g->b1) return fail(MCX_ERR_ARG, "segments must cover whole sets of %u regions", g->b1);
-  rc = defer_reserve(g, colour, ntuples);
+  rc = l2_reserve(g, colour, ntuples);
   if (rc != MCX_OK) return rc;
   rc = ensure_l2(g, g->b1);  // split on arrival: bins for every region
   if (rc != MCX_OK) return rc;
@@ -1147,14 +1239,14 @@ extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_
   int rc = ensure_defer(g);
   if (rc != MCX_OK) return rc;
   if (!g->defer) return fail(MCX_ERR_ARG, "super-k-mer records need the deferred insert path (table too small or defer=0)");
-  rc = defer_reserve(g, colour, kmers_upper_bound);
+  int set = 0;
+  rc = defer_reserve(g, colour, std::min(kmers_upper_bound, g->set_cap), &set);
   if (rc != MCX_OK) return rc;
   SuperkIn in{d_recs, (const unsigned long long *)d_counts, seg_cap, nseg};
   BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
-  BinOut out{g->l1_keys, nullptr, g->l1_cnt, g->cap1, nullptr, nullptr, nullptr, 0};
+  BinOut out = l1_out(g, set);
   DISPATCH_WC(g, launch_superk_bin, g, in, colour, bs, out);
   HIP_TRY(hipGetLastError());
-  g->pending += kmers_upper_bound;
   return MCX_OK;
 }
 

@@ -86,6 +86,11 @@ struct BinOut {
 #ifndef MCX_VEC16
 #define MCX_VEC16 1    // 1: tuple segments are read with 16-byte loads where their alignment allows
 #endif
+// Timing experiments only (tools/variants.sh): switch parts of the L1 binning kernel off to see what they
+// cost.  The graph that comes out is wrong by construction (the bins stay empty).
+#ifndef MCX_EXP_L1
+#define MCX_EXP_L1 0  // 1: no global write-out; 2: also no LDS placement; 3: also no histogram / rank atomics
+#endif
 #define MCX_LDS_AS __attribute__((address_space(3)))
 constexpr int kMaxBins = 2048;
 constexpr uint64_t kQMask = (1ull << 56) - 1;  // quotient bits of the top tuple word
@@ -226,7 +231,7 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     res.g0[q] = 0;
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
-      if (c) res.g0[q] = atomicAdd(&out.counts[out_seg(bs, ob0, b)], (unsigned long long)c);
+      if (c) res.g0[q] = atomicAdd(&out.counts[out_seg(bs, ob0, b)], (unsigned long long)(MCX_EXP_L1 ? 0 : c));
     }
   }
   // (no barrier: the ranking that follows counts in rnk[], which was zeroed at the top of the tile)
@@ -287,6 +292,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
   for (uint32_t q = threadIdx.x; q < cnt; q += LDS::geo::kT) {
     const uint32_t b = L.sbin[q];
     const unsigned long long gb = L.gbase[b];
+    if (MCX_EXP_L1 && bs.mode == BIN_GROUP) { if (L.skey[q * W] == 0x123456789ULL && gb == 77) full = 1; continue; }
     if (lo + q < (uint32_t)(gb >> 48)) {
       const uint64_t at = (gb + (lo + q)) & kDstMask;
       uint64_t *kd = out.keys + at * W;
@@ -594,7 +600,12 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
           local = (local & valid) | (trash & ~valid);
           tle[j] = local;
         }
-#if MCX_RANK_FROM_COUNT
+#if MCX_EXP_L1 >= 3
+        const uint32_t arr_now = local & 7u;
+        if (j > 0) { tle[j - 1] |= arr_prev << 12; }
+        arr_prev = arr_now;
+        if (j == kPosPerLane - 1) tle[j] |= arr_now << 12;
+#elif MCX_RANK_FROM_COUNT
         // The counting atomic returns the tuple's arrival index in its bin: with the bin's offset that
         // IS its sorted position, so the ranking needs no second atomic per tuple.  The result is
         // folded into tle one position later: its LDS round trip overlaps the next position's work.
@@ -637,9 +648,13 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
     }
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
     for (int round = 0; round < kRounds; round++) {
+#if MCX_EXP_L1 >= 2
+      if (round == 0) { uint64_t acc = 0; for (int j = 0; j < kPosPerLane; j++) acc ^= tk[j].w[0] + tle[j]; if (acc == 0x123456789ULL) full = 1; }
+#else
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
         bin_place<W, FULL, LDS>(L, round, FULL ? (tle[j] >> 12) & 0xfffu : tle[j] >> 12, tle[j] & 0xfffu, tk[j], tle[j] >> 24);
+#endif
       bin_writeout<W, ONECOL, FULL, SH, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
     }
   }
@@ -667,7 +682,19 @@ struct TupleIn {
   // segment s sits at physical index (s / seg_group) * seg_stride + s % seg_group: a group of
   // regions inside the replica-major L1 bins (seg_group == seg_stride: plain [nseg] array)
   uint32_t seg_group, seg_stride;
+  // L1 bin sets (several colours pending at once, mcx_api.hip: "L1 bin sets"): the replica index
+  // q = s / seg_group runs over the replicas of the sets a colour holds, set_rep replicas each;
+  // its physical replica is set_map[q / set_rep] * set_rep + q % set_rep.  set_rep == 0: no sets.
+  uint32_t set_rep;
+  uint8_t set_map[32];
 };
+// physical index of segment s
+__device__ __forceinline__ uint64_t tuple_seg_phys(const TupleIn &in, uint32_t seg)
+{
+  uint32_t q = seg / in.seg_group;
+  if (in.set_rep) q = (uint32_t)in.set_map[q / in.set_rep] * in.set_rep + q % in.set_rep;
+  return (uint64_t)q * in.seg_stride + seg % in.seg_group;
+}
 
 // T threads x 16 tuples per tile: 256 (4 blocks per CU), or 512 (2 blocks per CU, one-word keys; the launch
 // bound is waves per SIMD, 4 either way): runs of
@@ -728,7 +755,7 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
       seg = (uint32_t)(v % nseg_g);  // segment-interleaved
       start = (v / nseg_g) * kTile;
     }
-    const uint64_t pseg = (uint64_t)(seg / in.seg_group) * in.seg_stride + seg % in.seg_group;
+    const uint64_t pseg = tuple_seg_phys(in, seg);
     uint64_t cnt = in.counts ? (uint64_t)in.counts[pseg] : in.seg_cap;
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (start >= cnt) continue;  // uniform across the block
@@ -845,7 +872,9 @@ template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? MCX_LD
 #ifndef MCX_LDS_BATCH
 #define MCX_LDS_BATCH 4
 #endif
-constexpr int kLdsBatch = MCX_LDS_BATCH;
+#ifndef MCX_LDS_BATCH2
+#define MCX_LDS_BATCH2 MCX_LDS_BATCH  // the same for two-word keys (their tuples take twice the registers)
+#endif
 #ifndef MCX_LDS_VEC16
 #define MCX_LDS_VEC16 0  // the same for the tuple loads of the LDS insert
 #endif
@@ -867,12 +896,21 @@ template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 
 // before -- its key reads could only start at 4 positions -- and 6.6 for a single 8-byte read).
 // Slots fill in probe order, so at the load factors a graph is built with (<= 0.75) most keys sit in
 // slots 0-1 of their bucket: the second half is only read by the lanes that need it.
-// Two-word keys: slot after slot (key word 0, key word 1, value).
-__device__ __forceinline__ uint32_t lds_phys1(uint32_t slot)  // position of logical slot `slot` (one-word keys)
+// Two-word keys (MCX_LDS_IMG2, default): the same image with one more plane -- first key words of all
+// 2048 slots (16 KiB), second key words (16 KiB), values (16 KiB), slots permuted alike: a probe reads the
+// bucket's four FIRST words with two 16-byte loads, compares in registers and only then looks at the one
+// second word that matters.  (MCX_LDS_IMG2=0: slot after slot -- key word 0, key word 1, value --, the
+// image of rounds 1-2: four strided 8-byte loads per probe.)
+#ifndef MCX_LDS_IMG2
+#define MCX_LDS_IMG2 1
+#endif
+__device__ __forceinline__ uint32_t lds_phys1(uint32_t slot)  // position of logical slot `slot` in a plane
 {
   return slot ^ ((slot >> 4) & 2u);  // bit 1 (which half) ^= bit 5 of the slot (= bit 3 of the bucket)
 }
 constexpr uint32_t kLdsVal1 = 4096;  // word offset of the values in the one-word image
+constexpr uint32_t kLdsK1_2 = 2048;  // two-word image: word offset of the second key words ...
+constexpr uint32_t kLdsVal2 = 4096;  // ... and of the values
 
 // find-or-insert one occurrence in the LDS-resident sub-table.  Half a bucket (one-word keys) or a
 // whole one (two-word keys) is examined per step: the key words are loaded together and compared
@@ -922,14 +960,20 @@ __device__ __forceinline__ bool lds_apply(unsigned long long *lds, const Kmer<W>
       if (s == bucket * kBucket) return false;  // a full sub-table: every slot seen without a hit or a free one
     }
   } else {
-    constexpr int R = W + 1;
+    // slot j of bucket b: first key word at sp(j), the second kK1 words further on, the value kV
+#if MCX_LDS_IMG2
+    constexpr uint32_t kK1 = kLdsK1_2, kV = kLdsVal2;
+#define MCX_SP(b_, j_) (lds + lds_phys1((b_) * kBucket + (uint32_t)(j_)))
+#else
+    constexpr uint32_t kK1 = 1, kV = W;
+#define MCX_SP(b_, j_) (lds + (size_t)(b_) * (kBucket * (W + 1)) + (j_) * (W + 1))
+#endif
     uint32_t b = bucket;
     for (;;) {
-      unsigned long long *bp = lds + (size_t)b * (kBucket * R);
       unsigned long long k[kBucket];
 #pragma unroll
       for (int j = 0; j < kBucket; j++)
-        k[j] = __hip_atomic_load((MCX_LDS_AS unsigned long long *)(bp + j * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        k[j] = __hip_atomic_load((MCX_LDS_AS unsigned long long *)MCX_SP(b, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       int hit = -1, empty = -1;
       bool retry = false;
 #pragma unroll
@@ -937,11 +981,11 @@ __device__ __forceinline__ bool lds_apply(unsigned long long *lds, const Kmer<W>
         if (k[j] == 0) empty = j;
         if ((k[j] & ~kPending) == want) {
           if (k[j] & kPending) retry = true;  // its owner has not published word 1 yet
-          else if (__hip_atomic_load((MCX_LDS_AS unsigned long long *)(bp + j * R + 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1]) hit = j;
+          else if (__hip_atomic_load((MCX_LDS_AS unsigned long long *)(MCX_SP(b, j) + kK1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[W - 1]) hit = j;
         }
       }
       if (hit >= 0) {
-        unsigned long long *val = bp + hit * R + W;
+        unsigned long long *val = MCX_SP(b, hit) + kV;
         const unsigned long long old = atomicAdd(val, 256ULL);
         if (e & ~(uint32_t)old) atomicOr(val, (unsigned long long)e);
         return true;
@@ -951,13 +995,13 @@ __device__ __forceinline__ bool lds_apply(unsigned long long *lds, const Kmer<W>
         continue;
       }
       if (empty >= 0) {
-        unsigned long long *r = bp + empty * R;
+        unsigned long long *r = MCX_SP(b, empty);
         if (atomicCAS(r, 0ULL, want | kPending) == 0) {
-          __hip_atomic_store(r + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(r + kK1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_store(r, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
           n_novel++;
-          atomicAdd(r + W, 256ULL);
-          if (e) atomicOr(r + W, (unsigned long long)e);
+          atomicAdd(r + kV, 256ULL);
+          if (e) atomicOr(r + kV, (unsigned long long)e);
           return true;
         }
         if (++steps > (1u << 22)) { full = 1; return true; }
@@ -967,6 +1011,7 @@ __device__ __forceinline__ bool lds_apply(unsigned long long *lds, const Kmer<W>
       b = (b + 1) & (Sub<W>::kBuckets - 1);
       if (b == bucket) return false;  // a full sub-table: every bucket seen without a hit or a free slot
     }
+#undef MCX_SP
   }
 }
 
@@ -983,8 +1028,10 @@ __device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &
   const unsigned long long want = key.w[0] | kFlag;
   unsigned long long k[kBucket];
   unsigned long long *kp[kBucket];  // key word 0 of logical slot j; its value is kVal words further on
-  constexpr uint32_t kVal = W == 1 ? kLdsVal1 : (uint32_t)W;
-  if constexpr (W == 1) {
+  constexpr bool kPlanes = W == 1 || MCX_LDS_IMG2;  // key words and values in planes, buckets half-swizzled
+  constexpr uint32_t kVal = W == 1 ? kLdsVal1 : (MCX_LDS_IMG2 ? kLdsVal2 : (uint32_t)W);
+  constexpr uint32_t kK1 = MCX_LDS_IMG2 ? kLdsK1_2 : 1u;  // second key word of a two-word key
+  if constexpr (kPlanes) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef MCX_LDS_AS const u64x2 lds_c;
     const uint32_t sw = (bucket >> 3) & 1u;
@@ -1008,7 +1055,7 @@ __device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &
   for (int j = kBucket - 1; j >= 0; j--)
     if (k[j] == want) hk = kp[j];  // (a pending two-word key differs in kPending: no hit)
   if (hk) {
-    if (W == 2 && __hip_atomic_load((MCX_LDS_AS unsigned long long *)(hk + 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != key.w[W - 1])
+    if (W == 2 && __hip_atomic_load((MCX_LDS_AS unsigned long long *)(hk + kK1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != key.w[W - 1])
       return false;  // same first word, other second word: the key may still sit further down
     const unsigned long long old = atomicAdd(hk + kVal, 256ULL);
     if (e & ~(uint32_t)old) atomicOr(hk + kVal, (unsigned long long)e);
@@ -1023,7 +1070,7 @@ __device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &
   if (!ek) return false;
   if (atomicCAS(ek, 0ULL, W == 1 ? want : (want | kPending)) != 0) return false;
   if (W == 2) {
-    __hip_atomic_store(ek + 1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(ek + kK1, (unsigned long long)key.w[W - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_store(ek, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   n_novel++;
@@ -1094,7 +1141,15 @@ __device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, c
     MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5) MCX_ST(g, 6) MCX_ST(h, 7)
 #undef MCX_ST
   } else if (ONECOL) {
+#if MCX_LDS_IMG2
+    // vector i = words 2i, 2i + 1 of the record stream [k0 k1 v][k0 k1 v]...: word w is field w % 3 of
+    // slot w / 3, and field f lives in plane f (first words | second words | values)
+#define MCX_ST(m, q) { const uint32_t w0 = 2u * (uint32_t)(q * T + tid), s0 = w0 / 3u, f0 = w0 - 3u * s0; \
+                       const uint32_t s1 = f0 == 2u ? s0 + 1u : s0, f1 = f0 == 2u ? 0u : f0 + 1u;          \
+                       lds[f0 * kLdsK1_2 + lds_phys1(s0)] = v.m.x; lds[f1 * kLdsK1_2 + lds_phys1(s1)] = v.m.y; }
+#else
 #define MCX_ST(m, q) dst[q * T + tid] = make_ulonglong2(v.m.x, v.m.y);
+#endif
     MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5)
 #undef MCX_ST
   } else if (W == 1) {  // slots 2p, 2p + 1 are one half of a bucket: their keys are one vector, their values another
@@ -1102,7 +1157,12 @@ __device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, c
     MCX_PUT1(0, v.a, v.e) MCX_PUT1(1, v.b, v.f) MCX_PUT1(2, v.c, v.g) MCX_PUT1(3, v.d, v.h)
 #undef MCX_PUT1
   } else {              // slots 2p, 2p + 1 = 6 words = vectors 3p .. 3p + 2: k0a k0b | v0 k1a | k1b v1
+#if MCX_LDS_IMG2       // the pair's first words, second words and values: one 16-byte vector per plane
+#define MCX_PUT2(j, k0, k1, vv) { const uint32_t ph = lds_phys1(2u * (uint32_t)(j * T + tid)) >> 1; dst[ph] = make_ulonglong2(k0.x, k1.x); \
+                                  dst[kLdsK1_2 / 2 + ph] = make_ulonglong2(k0.y, k1.y); dst[kLdsVal2 / 2 + ph] = make_ulonglong2(vv.x, vv.y); }
+#else
 #define MCX_PUT2(j, k0, k1, vv) { const int p = j * T + tid; dst[3 * p] = make_ulonglong2(k0.x, k0.y); dst[3 * p + 1] = make_ulonglong2(vv.x, k1.x); dst[3 * p + 2] = make_ulonglong2(k1.y, vv.y); }
+#endif
     MCX_PUT2(0, v.a, v.b, v.c) MCX_PUT2(1, v.d, v.e, v.f)
 #undef MCX_PUT2
   }
@@ -1125,7 +1185,15 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
     ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(t.rec + s0 * (W + 1));
     constexpr int PER = (int)(Sub<W>::kSlots * (W + 1) * 8 / 16 / T);
 #pragma unroll
-    for (int q = 0; q < PER; q++) dst[q * T + tid] = src[q * T + tid];
+    for (int q = 0; q < PER; q++) {
+#if MCX_LDS_IMG2
+      const uint32_t w0 = 2u * (uint32_t)(q * T + tid), sl0 = w0 / 3u, f0 = w0 - 3u * sl0;
+      const uint32_t sl1 = f0 == 2u ? sl0 + 1u : sl0, f1 = f0 == 2u ? 0u : f0 + 1u;
+      dst[q * T + tid] = make_ulonglong2(lds[f0 * kLdsK1_2 + lds_phys1(sl0)], lds[f1 * kLdsK1_2 + lds_phys1(sl1)]);
+#else
+      dst[q * T + tid] = src[q * T + tid];
+#endif
+    }
   } else if (W == 1) {
     ulonglong2 *K = reinterpret_cast<ulonglong2 *>(t.rec + s0);
     ulonglong2 *V = reinterpret_cast<ulonglong2 *>(t.val + (uint64_t)col * t.VC + s0);
@@ -1141,10 +1209,18 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int p = j * T + tid;
+#if MCX_LDS_IMG2
+      const uint32_t ph = lds_phys1(2u * (uint32_t)p) >> 1;
+      const ulonglong2 a = src[ph], b = src[kLdsK1_2 / 2 + ph];  // first words, second words of the pair
+      K[2 * p] = make_ulonglong2(a.x, b.x);
+      K[2 * p + 1] = make_ulonglong2(a.y, b.y);
+      V[p] = src[kLdsVal2 / 2 + ph];
+#else
       const ulonglong2 x = src[3 * p], y = src[3 * p + 1], z = src[3 * p + 2];
       K[2 * p] = x;
       K[2 * p + 1] = make_ulonglong2(y.y, z.x);
       V[p] = make_ulonglong2(y.x, z.y);
+#endif
     }
   }
 }
@@ -1154,6 +1230,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
                                                                        uint32_t sub0, uint32_t nsub, Counters *ctr)
 {
   constexpr int kLdsThreads = LdsCfg<W>::kThreads;
+  constexpr int kLdsBatch = W == 1 ? MCX_LDS_BATCH : MCX_LDS_BATCH2;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
   const int tid = threadIdx.x;

@@ -544,3 +544,39 @@ def test_untouched_sub_tables_are_not_read_only_while_that_is_safe(mcx, orc):
         assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
         g.reset()
     g.close()
+
+
+@pytest.mark.parametrize("k,ncols,sets", [(31, 4, None), (31, 4, "1"), (31, 4, "3"), (63, 3, None), (21, 6, "4")])
+def test_interleaved_colours_keep_their_tuples_apart(mcx, orc, k, ncols, sets, monkeypatch):
+    """A population build alternates samples (ctx_build.c:384-407 loads the files of a batch side by
+    side; coverage and edges are per colour, db_node.h:240-241).  The partition path keeps a pool of
+    L1 bin sets: a colour switch takes another set instead of flushing, and a flush makes one table
+    pass per colour over all of that colour's sets (TupleIn::set_map).  Colours 0,1,..,0,1,.. in
+    small batches, pool sizes from 1 (a flush per switch, the old behaviour) to 32, several flushes
+    (the pool runs out), a device stream in between -- against the oracle, byte for byte."""
+    if sets:
+        monkeypatch.setenv("MCX_L1_SETS", sets)
+    g0 = synth.genome(40000, 17)
+    jobs = []
+    for i in range(5 * ncols):
+        b, o = synth.reads(1500, 110, seed=300 + i, g=g0, n_frac=0.04, err=0.004)
+        jobs.append((i % ncols, b, o))
+    hb, ho = orc.pack_reads(["C" * 200] * 300)   # a hot k-mer in the last colour: bin overflow -> direct insert
+    jobs.append((ncols - 1, hb, ho))
+    og, _ = _oracle(orc, k, ncols, jobs)
+    want = og.ctx_bytes(True)[og.header_size():]
+    for tcap in (1 << 21, 1 << 24):
+        g = mcx.Graph(k, ncols, 1 << 20)
+        g.configure("defer_tuples", tcap)
+        g.configure("profile", 1)
+        for col, b, o in jobs:
+            g.add_reads(col, b, o)
+        assert g.nkmers == og.nkmers, (sets, tcap)
+        assert g.export(True) == want, (sets, tcap)
+        prof = g.profile()
+        assert "k_lds_insert" in prof  # the partition path ran (not the direct fallback)
+        if sets is None and tcap == 1 << 24:
+            # everything fitted the pool: ONE flush, one table pass (= one k_lds_insert launch per region group) per colour
+            groups = prof["k_lds_insert"][0]
+            assert groups % ncols == 0 and prof["k_tuples_bin"][0] == groups
+        g.close()

@@ -17,7 +17,7 @@ import sys,json
 try:
     d=json.loads(sys.stdin.read())
     ks=d['roofline']['kernels']
-    print('%-28s %6.2f G/s  %6.3f ms/step  pipe %.3f  ' % ('$name', d['value']/1e9, d['ms_per_step'], d['roofline']['pipeline']['frac']) + '  '.join('%s %.2f' % (k.replace('k_',''), v['total_ms']) for k,v in ks.items()) + '  cs ' + d['config']['graph_checksum'])
+    print('%-28s %6.2f G/s  %6.3f ms/step  pipe %.3f  ' % ('$name', d['value']/1e9, d['ms_per_step'], d['roofline']['frac']) + '  '.join('%s %.2f' % (k.replace('k_',''), v['total_ms']) for k,v in ks.items()) + '  cs ' + d['config']['graph_checksum'])
 except Exception as e:
     print('%-28s FAILED %s' % ('$name', e))
 "
