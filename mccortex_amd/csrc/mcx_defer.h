@@ -287,14 +287,48 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
   __syncthreads();
   const uint32_t n = L.off[bs.nlocal];
   constexpr uint32_t kSt = LDS::geo::kStageG;
+  // Sorted positions [lo, hi) of the tile are staged in this round.  The loop runs over the POSITION p,
+  // not over an index into the staging area counted from "n - lo": written as
+  //     cnt = n > lo ? min(n - lo, kSt) : 0;  for (q = tid; q < cnt; ...)
+  // the compiler (ROCm 7.2 clang, gfx950) turned the guarded difference into a saturating
+  // subtraction and, in the variant whose loop index started from the opaque tid_now(), emitted it as
+  // a plain v_add_u32 -kSt followed by v_min_u32: with fewer than kSt tuples in the tile (n < lo in
+  // round 1) the difference wrapped, cnt became kSt, stale staging entries were "written out", failed
+  // the capacity test and took the direct-insert branch with a stale bin as their region -> a wild
+  // table address.  That was the unexplained fault of round 2 (profiles/r03_writeout_fault.md).  No
+  // subtraction of n is left to get wrong.
   const uint32_t lo = (uint32_t)round * kSt;
-  const uint32_t cnt = n > lo ? min(n - lo, kSt) : 0;
-  for (uint32_t q = threadIdx.x; q < cnt; q += LDS::geo::kT) {
+  const uint32_t hi = min(n, lo + kSt);
+#ifndef MCX_WRITEOUT_TIDNOW
+#define MCX_WRITEOUT_TIDNOW 0  // 1: the loop index starts from the opaque thread index (the variant that faulted in round 2)
+#endif
+#ifndef MCX_DEBUG_BOUNDS
+#define MCX_DEBUG_BOUNDS 0     // 1: every index the write-out derives is checked and reported with printf instead of being used
+#endif
+  for (uint32_t p = lo + (MCX_WRITEOUT_TIDNOW ? tid_now() : threadIdx.x); p < hi; p += LDS::geo::kT) {
+    const uint32_t q = p - lo;
     const uint32_t b = L.sbin[q];
+#if MCX_DEBUG_BOUNDS
+    if (b >= bs.nlocal || q >= kSt) {
+      printf("bin_writeout: block %u thread %u round %d: q %u, positions [%u, %u) (n %u), bin %u of %u\n", blockIdx.x, threadIdx.x, round, q, lo, hi, n, b, bs.nlocal);
+      continue;
+    }
+#endif
     const unsigned long long gb = L.gbase[b];
+#if MCX_DEBUG_BOUNDS
+    {
+      const uint64_t total = (uint64_t)bs.rep * bs.nout * (bs.mode == BIN_GLOBAL ? bs.nparts : 1u) * out.cap;
+      const uint64_t at_dbg = (gb + p) & kDstMask;
+      if (p < (uint32_t)(gb >> 48) && at_dbg >= total) {
+        printf("bin_writeout: block %u thread %u round %d: q %u bin %u gbase %llx -> tuple index %llu of %llu\n", blockIdx.x, threadIdx.x, round, q, b,
+               gb, (unsigned long long)at_dbg, (unsigned long long)total);
+        continue;
+      }
+    }
+#endif
     if (MCX_EXP_L1 && bs.mode == BIN_GROUP) { if (L.skey[q * W] == 0x123456789ULL && gb == 77) full = 1; continue; }
-    if (lo + q < (uint32_t)(gb >> 48)) {
-      const uint64_t at = (gb + (lo + q)) & kDstMask;
+    if (p < (uint32_t)(gb >> 48)) {
+      const uint64_t at = (gb + p) & kDstMask;
       uint64_t *kd = out.keys + at * W;
       kd[0] = L.skey[q * W];
       if (W == 2) kd[1] = L.skey[q * W + 1];
@@ -868,7 +902,17 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
 #ifndef MCX_LDS_THREADS1
 #define MCX_LDS_THREADS1 512
 #endif
-template <int W> struct LdsCfg { static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : 512; };
+#ifndef MCX_LDS_MINW2
+#define MCX_LDS_MINW2 4      // two-word keys: waves per SIMD the LDS insert is compiled for (its 48 KiB slices leave room for 6)
+#endif
+#ifndef MCX_LDS_PREFETCH2
+#define MCX_LDS_PREFETCH2 1  // two-word keys: the next sub-table's slice is fetched into registers while this one is applied
+#endif
+template <int W> struct LdsCfg {
+  static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : 512;
+  static constexpr int kMinWaves = W == 1 ? 4 : MCX_LDS_MINW2;
+  static constexpr bool kPrefetch = W == 1 ? true : (MCX_LDS_PREFETCH2 != 0);
+};
 #ifndef MCX_LDS_BATCH
 #define MCX_LDS_BATCH 4
 #endif
@@ -896,13 +940,15 @@ template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 
 // before -- its key reads could only start at 4 positions -- and 6.6 for a single 8-byte read).
 // Slots fill in probe order, so at the load factors a graph is built with (<= 0.75) most keys sit in
 // slots 0-1 of their bucket: the second half is only read by the lanes that need it.
-// Two-word keys (MCX_LDS_IMG2, default): the same image with one more plane -- first key words of all
-// 2048 slots (16 KiB), second key words (16 KiB), values (16 KiB), slots permuted alike: a probe reads the
-// bucket's four FIRST words with two 16-byte loads, compares in registers and only then looks at the one
-// second word that matters.  (MCX_LDS_IMG2=0: slot after slot -- key word 0, key word 1, value --, the
-// image of rounds 1-2: four strided 8-byte loads per probe.)
+// Two-word keys: slot after slot (key word 0, key word 1, value): four strided 8-byte loads per probe.
+// MCX_LDS_IMG2=1 builds the plane image for them as well -- first key words of all 2048 slots (16 KiB),
+// second key words (16 KiB), values (16 KiB), slots permuted alike, two 16-byte loads per probe and one
+// look at the second word that matters.  Measured at C4 (k = 63, 4.38 G occurrences, round 3,
+// tools/exp_c4c5.py): 39.3 ms against 38.0 for the slot-after-slot image, same graph checksum -- the
+// two-word insert is not bound by its LDS reads (8.4 K tuples per 48 KiB slice: it spends its time on
+// the per-sub-table chain of dependent global loads), so the default stays.
 #ifndef MCX_LDS_IMG2
-#define MCX_LDS_IMG2 1
+#define MCX_LDS_IMG2 0
 #endif
 __device__ __forceinline__ uint32_t lds_phys1(uint32_t slot)  // position of logical slot `slot` in a plane
 {
@@ -1226,7 +1272,7 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
 }
 
 template <int W, bool ONECOL>
-__global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
+__global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_lds_insert(TableView t, uint32_t col, BinOut bins,
                                                                        uint32_t sub0, uint32_t nsub, Counters *ctr)
 {
   constexpr int kLdsThreads = LdsCfg<W>::kThreads;
@@ -1258,7 +1304,8 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
   // sub-tables that nothing has written since the table was zeroed are not read (the first flush
   // of a build reads none of the table: 16 of its 50 bytes per slot)
   const bool zeros_known = t.touch && t.touch[0] == 0;
-  if (bi < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + bi, col, tid, v, zeros_known);
+  constexpr bool kPrefetch = LdsCfg<W>::kPrefetch;
+  if (kPrefetch && bi < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + bi, col, tid, v, zeros_known);
   while (bi < nsub) {
     const uint32_t sub = sub0 + bi;
     uint64_t n = bins.counts[bi];
@@ -1267,6 +1314,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
     const uint32_t nb = next_bin(bi + gridDim.x);
     __syncthreads();  // every thread has read the fills; the previous slice has left LDS
     if (tid == 0) bins.counts[bi] = 0;
+    if (!kPrefetch) slice_fetch<W, ONECOL, kLdsThreads>(t, sub, col, tid, v, zeros_known);
     slice_to_lds<W, ONECOL, kLdsThreads>(lds, tid, v);
     __syncthreads();
 
@@ -1353,7 +1401,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, 4) void k_lds_insert(TableView
         load_batch(j0 + 3 * kStep, tb);
       }
     };
-    if (nb < nsub) run(std::true_type{}); else run(std::false_type{});
+    if (kPrefetch && nb < nsub) run(std::true_type{}); else run(std::false_type{});
 #else
     {  // first batch of tuple loads, THEN the next slice: loads return in order, so the first
        // batch does not wait for the 64 KiB behind it

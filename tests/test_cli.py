@@ -453,3 +453,39 @@ def test_quality_cutoff_on_a_fifo_keeps_the_head_of_the_stream(built, orc, tmp_p
     th.join()
     assert rc == 0, err
     assert open(out, "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_c5_shape_four_samples_on_eight_devices(built, orc, tmp_path):
+    """Config C5 through the command line: four samples (four colours, per-colour coverage and edges)
+    on a table split over EIGHT devices (`-D 0,0,0,0,0,0,0,0`: the box has one GPU, every shard is on it;
+    the exchange, the owners' splits and the per-colour flushes are the real path), inputs of the
+    samples alternating as a population build lists them -- byte-identical to the oracle's sorted .ctx
+    and to the same build on one device."""
+    g = synth.genome(60000, 55)
+    files, jobs = [], []
+    for smp in range(4):
+        for part in range(2):
+            b, o = synth.reads(2500, 150, seed=500 + 10 * smp + part, g=g, n_frac=0.02, err=0.002)
+            files.append((smp, _write_inputs(tmp_path, b, o, "c5_%d_%d" % (smp, part), "fq", gz=bool(part))))
+            jobs.append((smp, b, o))
+    og = orc.Graph(31, 4, 1 << 22)
+    args = []
+    for smp in range(4):
+        og.set_sample(smp, "s%d" % smp)
+        args += ["--sample", "s%d" % smp]
+        for c, f in files:
+            if c == smp:
+                args += ["--seq", f]
+    for smp, b, o in jobs:
+        st = og.add_reads(smp, b, o)
+        og.update_stats(smp, st)
+    want = og.ctx_bytes(True)
+    outs = {}
+    for devs in ("0,0,0,0,0,0,0,0", "0"):
+        out = str(tmp_path / ("c5_%d.ctx" % len(devs)))
+        rc, _, err = run(31, "build", "-q", "-D", devs, "-k", "31", "-n", "8M", "-t", "4", "--sort", *args, out)
+        assert rc == 0, err
+        outs[devs] = open(out, "rb").read()
+    assert outs["0"] == want
+    assert outs["0,0,0,0,0,0,0,0"] == want

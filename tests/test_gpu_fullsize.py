@@ -189,10 +189,10 @@ def test_c4_and_c5_full_size_paths_agree(mcx, c2_batches):
 
 
 def test_c2_full_size_in_process_multi(mcx, c2_batches):
-    """mcx_graph_create_multi with two and four shards on the one GPU at C2 size: the facade's
-    checksum / node count / counters equal the single table's (csrc/mcx_multi.h)."""
+    """mcx_graph_create_multi with two, four and eight (C3's count) shards on the one GPU at C2 size: the
+    facade's checksum / node count / counters equal the single table's (csrc/mcx_multi.h)."""
     ref = _build(mcx, c2_batches, 31, 1, 1 << 30, {"defer_tuples": 8_000_000_000})
-    for devs in ([0, 0], [0, 0, 0, 0]):
+    for devs in ([0, 0], [0, 0, 0, 0], [0] * 8):
         g = mcx.Graph(31, 1, 1 << 30, devices=devs)
         g.configure("defer_tuples", 8_000_000_000 // len(devs))
         for b in c2_batches:
