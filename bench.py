@@ -280,12 +280,15 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, 5_000_000_000, pk)
     r["workload"] = "C4: k=63 (2-word BinaryKmer), 1 colour, %d reads x %d bp per step, table %d slots, 1 GPU" % (B, READ_LEN, table_slots)
     out["other_configs"] = {"C4_k63": r}
+    # (4 colours: the L1 workspace is a pool of bin sets shared by the colours, sized here to hold all 20 steps,
+    # so that the build makes one table pass per colour however the samples are ordered)
+    c5_defer = max(6_000_000_000, len(steps) * B * (READ_LEN + 1) + (1 << 28))
     cols = [min(3, 4 * i // max(1, len(steps))) for i in range(len(steps))]
-    r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000, pk)
+    r = run_config(mcx, steps, K, 4, cols, table_slots, c5_defer, pk)
     r["workload"] = "C5-like: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
     out["other_configs"]["C5_like_4_colours_1gpu"] = r
     cols = [i % 4 for i in range(len(steps))]  # a population build alternates samples: colour switches at every step
-    r = run_config(mcx, steps, K, 4, cols, table_slots, 6_000_000_000, pk)
+    r = run_config(mcx, steps, K, 4, cols, table_slots, c5_defer, pk)
     r["workload"] = "C5-like, colours interleaved: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
     out["other_configs"]["C5_like_interleaved_colours_1gpu"] = r
     # (f) the multi-GPU table of the C ABI (mcx_graph_create_multi) with BOTH shards on this one GPU:

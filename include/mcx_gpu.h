@@ -114,9 +114,12 @@ int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen);
  * shards, each k-merises its piece and sends every other shard its occurrences with peer copies
  * over xGMI), mcx_graph_add_reads_pcr, mcx_graph_add_records, sync / statistics / scans / checksum,
  * mcx_graph_export (sorted: one device sort merges the shards).  mcx_graph_add_stream_dev takes a
- * stream on any of the devices.  Not available on such a handle: intersect / must-exist mode and
- * the device-pointer exchange calls below (those take a single shard).  ndevices == 1 is
- * mcx_graph_create. */
+ * stream on any of the devices.  Intersect / must-exist mode works as on one device (records are
+ * dealt with by the shard that owns their key; reads are walked by every shard, which exchange what
+ * they found before any of them updates a node: an edge needs both of its k-mers).  Low-complexity
+ * input cannot overflow the exchange: what fits neither an (owner, region) segment nor the owner's
+ * overflow bin is spilled on the sender and routed by the host.  Not available on such a handle: the
+ * device-pointer exchange calls below (those take a single shard).  ndevices == 1 is mcx_graph_create. */
 int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers,
                            const int *devices, int ndevices);
 /* Devices the handle spans (1 for an ordinary graph). */

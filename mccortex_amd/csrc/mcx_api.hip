@@ -161,6 +161,7 @@ struct mcx_graph {
   uint32_t l2_regions = 0;      // regions the L2 (sub-table) bins cover: a flush splits and applies
                                 // the L1 bins in groups of this many regions, reusing the same bins
   uint32_t flush_regions = 0;   // configured group size (0 = automatic)
+  uint32_t idle_next = 0;       // next region group the idle-device flush takes (flush_if_device_idle)
   // ---- build --intersect (ctx_build.c:341-363,384-413) ----
   int hidden = -1;              // colour that holds the intersection graphs' edges, or -1
   int ncols_vis = 0;            // colours that are exported / scanned (ncols, or ncols - 1)
@@ -196,6 +197,9 @@ static int grp_add_reads(mcx_group *G, int colour, const uint8_t *bases, const u
 static int grp_add_reads_pcr(mcx_group *G, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
                              uint64_t nreads, uint8_t fq1, uint8_t fq2, uint8_t hp, int paired, int matedir,
                              mcx_load_stats *stats_accum);
+static int grp_add_reads_must_exist(mcx_group *G, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                                    uint64_t nreads, uint8_t fq, uint8_t hp, mcx_load_stats *stats_accum);
+static int grp_intersect_finish(mcx_group *G, uint64_t *removed);
 static int grp_add_records(mcx_group *G, const void *recs, uint64_t nrecs, int file_ncols, const int32_t *from_col,
                            const int32_t *into_col, int nmap, uint32_t flags, mcx_records_stats *stats_accum);
 static int grp_export(mcx_group *G, mcx_graph *f, int sorted, mcx_sink_fn sink, void *ctx);
@@ -604,9 +608,14 @@ static int ensure_l2(mcx_graph *g, uint32_t regions)
   return MCX_OK;
 }
 
+// Flush overlap (default on since round 3; MCX_FLUSH_OVERLAP=0 switches it off): the LDS insert of
+// region group g runs on a second stream beside the split of group g + 1 (two halves of sub-table
+// bins).  Worth 1.3-2.8 % of the C2 step (tools/sweep.sh, round 3); the per-kernel durations of the
+// two kernels then include each other's interference (a co-running insert launch takes about twice
+// as long as alone), so kernel-by-kernel profiles are taken with it off (tools/prof.sh).
 static bool flush_overlap()
 {
-  static const bool on = [] { const char *e = getenv("MCX_FLUSH_OVERLAP"); return e && atoi(e) != 0; }();
+  static const bool on = [] { const char *e = getenv("MCX_FLUSH_OVERLAP"); return !e || atoi(e) != 0; }();
   return on;
 }
 
@@ -853,7 +862,11 @@ static int ensure_stage(mcx_graph *g);
 extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value)
 {
   if (g && key && g->as_group) {
-    if (!strcmp(key, "intersect") || !strcmp(key, "must_exist")) return fail(MCX_ERR_ARG, "--intersect needs the whole table on one device");
+    if (!strcmp(key, "intersect")) {  // the facade's view of the colours follows its shards'
+      if (g->ncols < 2) return fail(MCX_ERR_ARG, "intersect mode needs one colour more than the output has");
+      g->hidden = g->ncols - 1;
+      g->ncols_vis = g->ncols - 1;
+    }
     if (!strcmp(key, "defer") && !value) return fail(MCX_ERR_ARG, "a multi-GPU table always uses the partitioned insert");
     int rc = grp_drain(g->as_group);
     for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) rc = mcx_graph_configure(grp_part(g->as_group, i), key, value);
@@ -1356,16 +1369,58 @@ extern "C" void mcx_pack_bases(const uint8_t *src, uint64_t n, uint32_t *code, u
   pack_block(src, (size_t)n, code, inv);
 }
 
-// threads that pack / copy reads into the pinned staging buffer (MCX_STAGE_THREADS, default: half the cores, at most 16)
+// threads that pack / copy reads into the pinned staging buffer (MCX_STAGE_THREADS, default: half the cores, at most 24:
+// 16 -> 24 threads was +3 % on one host and +40 % on another, 32 threads -30 % on the first; round 2 / round 3 logs)
 static int stage_threads()
 {
   static const int n = [] {
     const char *e = getenv("MCX_STAGE_THREADS");
     const int hw = (int)std::thread::hardware_concurrency();
-    const int v = e ? atoi(e) : std::max(1, std::min(16, hw / 2));
+    const int v = e ? atoi(e) : std::max(1, std::min(24, hw / 2));
     return v < 1 ? 1 : v > 64 ? 64 : v;
   }();
   return n;
+}
+
+// Host-fed builds: when the device has caught up with the host (nothing queued on the graph's stream
+// at the moment a packed chunk is about to be copied) the host is the bottleneck -- parsing, packing,
+// PCIe -- and the device would sit idle until the last batch, then flush everything while the host
+// waits.  An idle device therefore flushes ONE group of regions (split + LDS insert of 1 / 16 of the
+// table on the bench shape, about as long as the host needs for its next chunk) and moves on to the
+// next group the next time it is idle: the flush becomes a background pass that fills the idle time,
+// and what is left for the closing flush is what arrived during the last turn.  (A whole flush at
+// once was tried first: 15 ms during which the two staging buffers run dry and the HOST waits --
+// 35.6 -> 27 G k-mers/s.)  A device that is the bottleneck is never idle here and keeps its large
+// flushes.  One-colour graphs on one device only; MCX_IDLE_FLUSH=0 switches it off.
+static int flush_if_device_idle(mcx_graph *g)
+{
+  static const bool on = [] { const char *e = getenv("MCX_IDLE_FLUSH"); return !e || atoi(e) != 0; }();
+  if (!on || !g->defer || g->group || g->nsets != 1 || !g->pending || g->pending_l2 || g->set_colour.empty() || g->set_colour[0] < 0) return MCX_OK;
+  const uint32_t G = std::min(flush_group(g), g->l2_regions);
+  if (G >= g->b1) return MCX_OK;  // one group = the whole table: nothing incremental about it
+  const uint32_t ngroups = (g->b1 + G - 1) / G;
+  // worth a group's table pass: its share of 1 / 8 of the flush size, at least 16 M occurrences
+  if (g->pending / ngroups < std::max<uint64_t>(g->defer_tuples / 8 / ngroups, 1ull << 24)) return MCX_OK;
+  if (hipStreamQuery(g->stream) != hipSuccess) { (void)hipGetLastError(); return MCX_OK; }  // busy: the device is not waiting for us
+  const uint32_t r0 = g->idle_next * G < g->b1 ? g->idle_next * G : 0;
+  g->idle_next = (r0 / G + 1) % ngroups;
+  const uint32_t ng = std::min(G, g->b1 - r0);
+  const int colour = g->set_colour[0];
+  g->l2_off = 0;
+  TupleIn in{g->l1_keys + (uint64_t)r0 * g->cap1 * g->W, nullptr, g->l1_cnt + r0, g->cap1, ng * g->rep1, ng, g->b1};
+  BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, ng * g->subs_per_bin, ng, 0, r0};
+  BinOut out{g->l2_keys, nullptr, g->l2_cnt, g->cap2, nullptr, nullptr, nullptr, 0};
+  DISPATCH_WC(g, launch_split_regions, g, in, colour, bs, out);
+  HIP_TRY(hipGetLastError());
+  DISPATCH_WC(g, launch_lds_insert_t, g, colour, r0 * g->subs_per_bin, ng * g->subs_per_bin);
+  HIP_TRY(hipGetLastError());
+  for (uint32_t rep = 0; rep < g->rep1; rep++)  // the group's L1 bins are empty again
+    HIP_TRY(hipMemsetAsync(g->l1_cnt + (uint64_t)rep * g->b1 + r0, 0, (size_t)ng * 8, g->stream));
+  // (the bound on what is buffered: the group held its share of it)
+  const uint64_t share = g->pending / ngroups;
+  g->pending -= share;
+  g->set_pending[0] -= std::min(g->set_pending[0], share);
+  return MCX_OK;
 }
 
 static int ensure_stage(mcx_graph *g)
@@ -1496,6 +1551,8 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
     memcpy(carry_code, hcode + total / 16 - kCarry / 16, sizeof(carry_code));
     memcpy(carry_inv, hinv + total / 16 - kCarry / 16, sizeof(carry_inv));
     uint8_t *ds = g->d_stage[b];
+    // (the chunk is packed: if the device has meanwhile finished everything it was given, it is waiting for the host)
+    { int rc_ = flush_if_device_idle(g); if (rc_ != MCX_OK) return rc_; }
     HIP_TRY(hipMemcpyAsync(ds, hcode, total / 16 * 4, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipMemcpyAsync(ds + inv_at, hinv, total / 16 * 2, hipMemcpyHostToDevice, g->stream));
     if (nwhole)
@@ -1522,6 +1579,9 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
   if (g && g->as_group) {
     if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
     if (nreads && (!bases || !off)) return fail(MCX_ERR_ARG, "null read buffers");
+    if (nreads && colour >= g->ncols_vis) return fail(MCX_ERR_ARG, "colour %d is the intersection colour", colour);
+    if (grp_part(g->as_group, 0)->must_exist)
+      return grp_add_reads_must_exist(g->as_group, colour, bases, quals, off, nreads, fq_cutoff_abs, hp_cutoff, stats_accum);
     return grp_add_reads(g->as_group, colour, bases, quals, off, nreads, fq_cutoff_abs, hp_cutoff, stats_accum);
   }
   if (!g) return fail(MCX_ERR_ARG, "null graph");
@@ -1622,6 +1682,7 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
     memcpy(carry, hs + total - kCarry, kCarry);
     // pad the tail so the 16-byte chunk loads of the kernel stay inside the copy
     memset(hs + total, '\n', 64);
+    { int rc_ = flush_if_device_idle(g); if (rc_ != MCX_OK) return rc_; }
     HIP_TRY(hipMemcpyAsync(g->d_stage[b], hs, total + 64, hipMemcpyHostToDevice, g->stream));
     if (nwhole)
       HIP_TRY(hipMemcpyAsync(g->d_stage[b] + off_region, hoff, (nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
@@ -1668,10 +1729,10 @@ static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, 
     SpanGuard sp(g, "k_reads_must_exist");
     if (g->W == 1)
       hipLaunchKernelGGL((k_reads_must_exist<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
-                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr);
+                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u);
     else
       hipLaunchKernelGGL((k_reads_must_exist<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
-                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr);
+                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1681,7 +1742,7 @@ static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, 
 
 extern "C" int mcx_graph_intersect_finish(mcx_graph *g, uint64_t *removed)
 {
-  NO_GROUP(g, "mcx_graph_intersect_finish");
+  if (g && g->as_group) return grp_intersect_finish(g->as_group, removed);
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   if (g->hidden < 0) return fail(MCX_ERR_ARG, "the graph is not in intersect mode");
   HIP_TRY(hipSetDevice(g->device));

@@ -927,6 +927,10 @@ template <int W> struct LdsCfg {
 #endif
 // tuples of the LDS queue: what is left of a CU's 160 KiB beside two 64 KiB (three 48 KiB) slices
 template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : 288; };
+#ifndef MCX_LDS_AHEAD
+#define MCX_LDS_AHEAD 0  // 1: the fill of the next sub-table's bin and its first two tuple batches are requested one sub-table ahead
+                         // (round 3: 16.5 vs 16.65 ms at C2, 38.1 vs 37.8 at C4 -- the insert is not waiting for those loads; off)
+#endif
 #ifndef MCX_LDS_PIPE
 #define MCX_LDS_PIPE 1   // 1: the tuple loads of batch i + 1 are in flight while batch i is applied
 #endif
@@ -1306,50 +1310,72 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
   const bool zeros_known = t.touch && t.touch[0] == 0;
   constexpr bool kPrefetch = LdsCfg<W>::kPrefetch;
   if (kPrefetch && bi < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + bi, col, tid, v, zeros_known);
+  // tuple j0 + idx(q) is the q-th of this thread's batch; with 16-byte loads (aligned bins) a
+  // one-word thread takes pairs of neighbours
+  const bool vec16 = MCX_LDS_VEC16 && (((uintptr_t)bins.keys & 15u) == 0) && (W == 2 || (bins.cap & 1u) == 0);
+  auto idx = [&](int q) -> uint32_t {
+    return (W == 1 && vec16) ? 2u * ((uint32_t)(q >> 1) * kLdsThreads + tid) + (uint32_t)(q & 1)
+                             : (uint32_t)q * kLdsThreads + tid;
+  };
+  // Loads are unconditional (an index past the fill reads tuple 0 of the bin, which is then not
+  // applied): without branches between them the compiler can count the loads in flight and wait
+  // for exactly the batch it is about to apply (s_waitcnt vmcnt(n)) instead of for all of them.
+  auto load_batch_of = [&](uint32_t bin, uint64_t nfill, uint64_t j0, Kmer<W> (&tk)[kLdsBatch]) {
+    const uint64_t *kin = bins.keys + (uint64_t)bin * bins.cap * W;
+    if (vec16) {
+      const ulonglong2 *kin2 = reinterpret_cast<const ulonglong2 *>(kin);
+#pragma unroll
+      for (int q = 0; q < kLdsBatch; q += (W == 1 ? 2 : 1)) {
+        uint64_t i = j0 + idx(q);
+        i = i < nfill ? i : 0;  // (the pair's second word may lie past n: inside the bin, never applied)
+        const ulonglong2 x = kin2[W == 1 ? i / 2 : i];
+        tk[q].w[0] = x.x;
+        if (W == 1) tk[q + (W == 1 ? 1 : 0)].w[0] = x.y; else tk[q].w[W - 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kLdsBatch; q++) {
+        uint64_t i = j0 + idx(q);
+        i = i < nfill ? i : 0;
+        tk[q].w[0] = kin[i * W];
+        if (W == 2) tk[q].w[W - 1] = kin[i * W + 1];
+      }
+    }
+  };
+  constexpr uint64_t kStep = (uint64_t)kLdsThreads * kLdsBatch;
+#if MCX_LDS_AHEAD && MCX_LDS_PIPE
+  // One sub-table ahead.  Under load a global load takes several microseconds (what is in flight
+  // divided by the bandwidth), and an iteration used to pay that twice in a row before its first tuple
+  // was applied: the fill of the next bin (the loop in next_bin waits for it), then the first two
+  // batches.  Now the fill of the candidate bi + gridDim.x is requested at the top of an iteration and
+  // looked at only at its end, and the first two batches of the next sub-table are requested before
+  // this one's queue is drained and its slice stored.  (A candidate that turns out empty -- rare in a
+  // build, the rule in a sparse --graph load -- costs the old sequence.)
+  Kmer<W> ta[kLdsBatch], tb[kLdsBatch];
+  uint64_t n_cur = bi < nsub ? (uint64_t)bins.counts[bi] : 0;
+  if (n_cur > bins.cap) n_cur = bins.cap;
+  if (bi < nsub) { load_batch_of(bi, n_cur, 0, ta); load_batch_of(bi, n_cur, kStep, tb); }
+#endif
   while (bi < nsub) {
     const uint32_t sub = sub0 + bi;
+    const uint32_t region = sub / t.spb;  // uniform
+#if MCX_LDS_AHEAD && MCX_LDS_PIPE
+    const uint64_t n = n_cur;
+    const uint32_t nb_c = bi + gridDim.x;  // the candidate; its fill is not waited for here
+    uint64_t n_next = nb_c < nsub ? (uint64_t)bins.counts[nb_c] : 0;
+    uint32_t nb = nb_c;
+#else
     uint64_t n = bins.counts[bi];
     if (n > bins.cap) n = bins.cap;
-    const uint32_t region = sub / t.spb;  // uniform
     const uint32_t nb = next_bin(bi + gridDim.x);
+#endif
     __syncthreads();  // every thread has read the fills; the previous slice has left LDS
     if (tid == 0) bins.counts[bi] = 0;
     if (!kPrefetch) slice_fetch<W, ONECOL, kLdsThreads>(t, sub, col, tid, v, zeros_known);
     slice_to_lds<W, ONECOL, kLdsThreads>(lds, tid, v);
     __syncthreads();
 
-    const uint64_t *kin = bins.keys + (uint64_t)bi * bins.cap * W;
-    // tuple j0 + idx(q) is the q-th of this thread's batch; with 16-byte loads (aligned bins) a
-    // one-word thread takes pairs of neighbours
-    const bool vec16 = MCX_LDS_VEC16 && (((uintptr_t)bins.keys & 15u) == 0) && (W == 2 || (bins.cap & 1u) == 0);
-    auto idx = [&](int q) -> uint32_t {
-      return (W == 1 && vec16) ? 2u * ((uint32_t)(q >> 1) * kLdsThreads + tid) + (uint32_t)(q & 1)
-                               : (uint32_t)q * kLdsThreads + tid;
-    };
-    // Loads are unconditional (an index past the fill reads tuple 0 of the bin, which is then not
-    // applied): without branches between them the compiler can count the loads in flight and wait
-    // for exactly the batch it is about to apply (s_waitcnt vmcnt(n)) instead of for all of them.
-    auto load_batch = [&](uint64_t j0, Kmer<W> (&tk)[kLdsBatch]) {
-      if (vec16) {
-        const ulonglong2 *kin2 = reinterpret_cast<const ulonglong2 *>(kin);
-#pragma unroll
-        for (int q = 0; q < kLdsBatch; q += (W == 1 ? 2 : 1)) {
-          uint64_t i = j0 + idx(q);
-          i = i < n ? i : 0;  // (the pair's second word may lie past n: inside the bin, never applied)
-          const ulonglong2 x = kin2[W == 1 ? i / 2 : i];
-          tk[q].w[0] = x.x;
-          if (W == 1) tk[q + (W == 1 ? 1 : 0)].w[0] = x.y; else tk[q].w[W - 1] = x.y;
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < kLdsBatch; q++) {
-          uint64_t i = j0 + idx(q);
-          i = i < n ? i : 0;
-          tk[q].w[0] = kin[i * W];
-          if (W == 2) tk[q].w[W - 1] = kin[i * W + 1];
-        }
-      }
-    };
+    auto load_batch = [&](uint64_t j0, Kmer<W> (&tk)[kLdsBatch]) { load_batch_of(bi, n, j0, tk); };
     // packed tuple + region -> full key, start bucket, edge byte
     auto unpack = [&](const Kmer<W> &tp, Kmer<W> &key, uint32_t &bucket, uint32_t &e) {
       e = (uint32_t)(tp.w[0] >> 56);
@@ -1384,8 +1410,29 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
 #endif
         }
     };
-    constexpr uint64_t kStep = (uint64_t)kLdsThreads * kLdsBatch;
-#if MCX_LDS_PIPE
+#if MCX_LDS_AHEAD && MCX_LDS_PIPE
+    {
+      // (this sub-table's first two batches are on their way since the end of the previous iteration)
+      const bool cand = nb_c < nsub;  // uniform
+      if (kPrefetch && cand) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb_c, col, tid, v, zeros_known);
+      for (uint64_t j0 = 0; j0 < n; j0 += 2 * kStep) {
+        apply_batch(j0, ta);
+        load_batch(j0 + 2 * kStep, ta);
+        apply_batch(j0 + kStep, tb);
+        load_batch(j0 + 3 * kStep, tb);
+      }
+      // the next sub-table: the candidate unless its bin is empty
+      if (n_next > bins.cap) n_next = bins.cap;
+      if (cand && n_next == 0) {
+        nb = next_bin(nb_c + gridDim.x);
+        n_next = nb < nsub ? (uint64_t)bins.counts[nb] : 0;
+        if (n_next > bins.cap) n_next = bins.cap;
+        if (kPrefetch && nb < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v, zeros_known);
+      }
+      if (nb < nsub) { load_batch_of(nb, n_next, 0, ta); load_batch_of(nb, n_next, kStep, tb); }
+      n_cur = n_next;
+    }
+#elif MCX_LDS_PIPE
     // Two batches in flight: while one is applied (LDS only) the loads of the next are on their way.
     // The next slice is requested after the first two batches (loads return in order, so those do
     // not queue behind its 64 KiB).  Both variants of "is there a next slice" are straight-line code.

@@ -1161,11 +1161,18 @@ __global__ __launch_bounds__(256) void k_checksum(TableView t, uint32_t W, uint3
 // must_exist_in_graph (src/tools/build_graph.c:99-150,154-189): every k-mer of every contig is
 // looked up; a found k-mer gets coverage +1; an edge is added between consecutive k-mers only
 // when BOTH were found.  Not a fast path (intersection builds are small and rare): clarity first.
+// Table split over several GPUs (mcx_multi.h: grp_add_reads_must_exist): consecutive k-mers of a read
+// live on different shards, and the edge rule needs to know whether BOTH were found.  Every shard
+// walks all reads twice.  phase 1: for the k-mers it owns, present[index of the k-mer's last base] =
+// "found in my table" (no updates); the shards' arrays are OR-ed together (each byte is written by
+// exactly one shard).  phase 2, with the merged array: the reference's rule, each shard updating
+// only the nodes it owns; shard 0 keeps the read / contig / k-mer statistics.  phase 0: one table.
 template <int W>
 __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
-                                   uint64_t nreads, int k, uint32_t qcut, uint32_t hcut, uint32_t col, Counters *ctr)
+                                   uint64_t nreads, int k, uint32_t qcut, uint32_t hcut, uint32_t col, Counters *ctr,
+                                   uint8_t *present, uint32_t phase)
 {
-  if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
+  if (phase != 1 && blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nreads) return;
   const uint8_t *seq = bases + off[r];
@@ -1190,25 +1197,55 @@ __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint
       const Kmer<W> rc = revcomp<W>(fw, k);
       uint32_t o;
       const Kmer<W> key = canonical<W>(fw, rc, o);
-      const uint64_t slot = find_or_insert_rec<W>(t, key, true, dummy_novel, full);
       const uint32_t first = (uint32_t)(fw.w[0] >> first_shift) & 3u;  // first base of this k-mer, read strand
-      if (slot != kNoSlot) {
-        __hip_atomic_fetch_add(val_ptr(t, slot, col), 256ULL, MCX_RLX, MCX_AGENT);
-        if (prev_slot != kNoSlot) {  // db_graph_add_edge_mt(prev, curr): db_graph.c:152-166
-          __hip_atomic_fetch_or(val_ptr(t, prev_slot, col), (uint64_t)(1u << (nuc + 4u * prev_o)), MCX_RLX, MCX_AGENT);
-          __hip_atomic_fetch_or(val_ptr(t, slot, col), (uint64_t)(1u << ((3u - prev_first) + 4u * (1u - o))), MCX_RLX, MCX_AGENT);
+      if (phase == 0) {
+        const uint64_t slot = find_or_insert_rec<W>(t, key, true, dummy_novel, full);
+        if (slot != kNoSlot) {
+          __hip_atomic_fetch_add(val_ptr(t, slot, col), 256ULL, MCX_RLX, MCX_AGENT);
+          if (prev_slot != kNoSlot) {  // db_graph_add_edge_mt(prev, curr): db_graph.c:152-166
+            __hip_atomic_fetch_or(val_ptr(t, prev_slot, col), (uint64_t)(1u << (nuc + 4u * prev_o)), MCX_RLX, MCX_AGENT);
+            __hip_atomic_fetch_or(val_ptr(t, slot, col), (uint64_t)(1u << ((3u - prev_first) + 4u * (1u - o))), MCX_RLX, MCX_AGENT);
+          }
+        }
+        prev_slot = slot; prev_o = o; prev_first = first;
+        n_kmers++;
+        n_absent += slot == kNoSlot;
+      } else {
+        const uint64_t gi = off[r] + i;  // the k-mer's last base: one byte of `present` per k-mer occurrence
+        const bool mine = key_owner<W>(t, key) == t.part;
+        if (phase == 1) {
+          if (mine) present[gi] = find_or_insert_rec<W>(t, key, true, dummy_novel, full) != kNoSlot;
+        } else {
+          const bool found = present[gi] != 0;
+          // prev_slot: kNoSlot = the previous k-mer was not found; kNoSlot - 1 = found, on another shard
+          uint64_t slot = kNoSlot;
+          if (found) slot = mine ? find_or_insert_rec<W>(t, key, true, dummy_novel, full) : kNoSlot - 1;
+          if (found && prev_slot != kNoSlot) {
+            if (prev_slot != kNoSlot - 1)
+              __hip_atomic_fetch_or(val_ptr(t, prev_slot, col), (uint64_t)(1u << (nuc + 4u * prev_o)), MCX_RLX, MCX_AGENT);
+            if (mine && slot != kNoSlot)
+              __hip_atomic_fetch_or(val_ptr(t, slot, col), (uint64_t)(1u << ((3u - prev_first) + 4u * (1u - o))), MCX_RLX, MCX_AGENT);
+          }
+          if (found && mine && slot != kNoSlot) __hip_atomic_fetch_add(val_ptr(t, slot, col), 256ULL, MCX_RLX, MCX_AGENT);
+          prev_slot = slot; prev_o = o; prev_first = first;
+          n_kmers++;
+          n_absent += !found;
         }
       }
-      prev_slot = slot; prev_o = o; prev_first = first;
-      n_kmers++;
-      n_absent += slot == kNoSlot;
     }
     n_contigs++;
   }
+  if (phase == 1 || (phase == 2 && t.part != 0)) return;  // (statistics: once)
   if (n_kmers) atomicAdd(&ctr->kmers, n_kmers);
   if (n_absent) atomicAdd(&ctr->absent, n_absent);
   if (n_contigs) atomicAdd(&ctr->contigs, n_contigs);
   atomicAdd(n_contigs ? &ctr->good_reads : &ctr->bad_reads, 1ULL);
+}
+
+// dst |= src, byte arrays (the shards' `present` arrays of k_reads_must_exist)
+__global__ void k_or_bytes(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] |= src[i];
 }
 
 // db_graph_remove_no_covg_kmers + db_graph_intersect_edges (src/graph/db_graph.c:630-673): drop

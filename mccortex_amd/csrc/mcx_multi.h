@@ -391,6 +391,99 @@ static int grp_add_reads(mcx_group *G, int colour, const uint8_t *bases, const u
   return MCX_OK;
 }
 
+// build --intersect on a sharded table: reads only update k-mers that are already in the graph, and an
+// edge needs both of its k-mers found (ctx_build.c:341-363,409-413; build_graph.c:99-150) -- but
+// consecutive k-mers of a read live on different shards.  Every shard gets the whole batch and walks
+// it twice (k_reads_must_exist phases 1 and 2): first it records, per k-mer occurrence, whether a
+// k-mer it owns was found; the arrays are OR-ed on device 0 and handed back to every shard; then
+// each shard applies the reference's rule to the nodes it owns.  Not a fast path (as on one device).
+static int grp_add_reads_must_exist(mcx_group *G, int colour, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
+                                    uint64_t nreads, uint8_t fq, uint8_t hp, mcx_load_stats *stats_accum)
+{
+  if (stats_accum) {
+    stats_accum->num_se_reads += nreads;
+    stats_accum->total_bases_read += nreads ? off[nreads] - off[0] : 0;
+  }
+  if (!nreads) return MCX_OK;
+  int rc = grp_drain(G);
+  if (rc != MCX_OK) return rc;
+  const int N = G->n;
+  const uint64_t base0 = off[0], nb = off[nreads] - off[0];
+  std::vector<uint64_t> rel(nreads + 1);
+  for (uint64_t i = 0; i <= nreads; i++) rel[i] = off[i] - base0;
+  std::vector<uint8_t *> d_bases(N, nullptr), d_quals(N, nullptr), d_present(N, nullptr);
+  std::vector<uint64_t *> d_off(N, nullptr);
+  uint8_t *d_tmp = nullptr;  // on device 0
+  auto cleanup = [&]() {
+    for (int i = 0; i < N; i++) {
+      (void)hipSetDevice(G->part[i]->device);
+      (void)hipStreamSynchronize(G->part[i]->stream);
+      (void)hipFree(d_bases[i]); (void)hipFree(d_quals[i]); (void)hipFree(d_present[i]); (void)hipFree(d_off[i]);
+    }
+    (void)hipSetDevice(G->part[0]->device);
+    (void)hipFree(d_tmp);
+  };
+#define ISEC_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc_ = fail(_e == hipErrorOutOfMemory ? MCX_ERR_NOMEM : MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); cleanup(); return rc_; } } while (0)
+  const unsigned blocks = (unsigned)((nreads + 127) / 128);
+  auto launch = [&](int i, uint32_t phase) {
+    mcx_graph *g = G->part[i];
+    if (g->W == 1)
+      hipLaunchKernelGGL((k_reads_must_exist<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases[i], (const uint8_t *)d_quals[i],
+                         (const uint64_t *)d_off[i], nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, d_present[i], phase);
+    else
+      hipLaunchKernelGGL((k_reads_must_exist<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases[i], (const uint8_t *)d_quals[i],
+                         (const uint64_t *)d_off[i], nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, d_present[i], phase);
+  };
+  for (int i = 0; i < N; i++) {  // upload, phase 1
+    mcx_graph *g = G->part[i];
+    ISEC_TRY(hipSetDevice(g->device));
+    ISEC_TRY(hipMalloc((void **)&d_bases[i], nb + 16));
+    ISEC_TRY(hipMalloc((void **)&d_off[i], (nreads + 1) * 8));
+    ISEC_TRY(hipMalloc((void **)&d_present[i], nb + 16));
+    if (quals && fq > 0) ISEC_TRY(hipMalloc((void **)&d_quals[i], nb + 16));
+    ISEC_TRY(hipMemcpyAsync(d_bases[i], bases + base0, nb, hipMemcpyHostToDevice, g->stream));
+    if (d_quals[i]) ISEC_TRY(hipMemcpyAsync(d_quals[i], quals + base0, nb, hipMemcpyHostToDevice, g->stream));
+    ISEC_TRY(hipMemcpyAsync(d_off[i], rel.data(), (nreads + 1) * 8, hipMemcpyHostToDevice, g->stream));
+    ISEC_TRY(hipMemsetAsync(d_present[i], 0, nb + 16, g->stream));
+    launch(i, 1u);
+    ISEC_TRY(hipGetLastError());
+  }
+  for (int i = 0; i < N; i++) { ISEC_TRY(hipSetDevice(G->part[i]->device)); ISEC_TRY(hipStreamSynchronize(G->part[i]->stream)); }
+  {  // OR the shards' answers on device 0, hand the result back
+    mcx_graph *g0 = G->part[0];
+    ISEC_TRY(hipSetDevice(g0->device));
+    ISEC_TRY(hipMalloc((void **)&d_tmp, nb + 16));
+    for (int i = 1; i < N; i++) {
+      ISEC_TRY(hipMemcpyPeerAsync(d_tmp, g0->device, d_present[i], G->part[i]->device, nb, g0->stream));
+      hipLaunchKernelGGL(k_or_bytes, dim3((unsigned)std::min<uint64_t>((nb + 255) / 256, 4096)), dim3(256), 0, g0->stream, d_present[0], (const uint8_t *)d_tmp, nb);
+      ISEC_TRY(hipGetLastError());
+    }
+    ISEC_TRY(hipStreamSynchronize(g0->stream));
+    for (int i = 1; i < N; i++) ISEC_TRY(hipMemcpyPeer(d_present[i], G->part[i]->device, d_present[0], g0->device, nb));
+  }
+  for (int i = 0; i < N; i++) {  // phase 2
+    ISEC_TRY(hipSetDevice(G->part[i]->device));
+    launch(i, 2u);
+    ISEC_TRY(hipGetLastError());
+  }
+  cleanup();
+#undef ISEC_TRY
+  return MCX_OK;
+}
+
+static int grp_intersect_finish(mcx_group *G, uint64_t *removed)
+{
+  int rc = grp_drain(G);
+  uint64_t total = 0;
+  for (int i = 0; rc == MCX_OK && i < G->n; i++) {
+    uint64_t r = 0;
+    rc = mcx_graph_intersect_finish(G->part[i], &r);
+    total += r;
+  }
+  if (removed) *removed = total;
+  return rc;
+}
+
 // --remove-pcr on a sharded table: every shard sees the whole batch and answers for the start
 // nodes it owns (k_pcr_claim); the answers are copied to every shard, each reaches the same
 // verdict (k_pcr_decide_claims) and loads its share of the kept reads.
@@ -469,7 +562,8 @@ static int grp_add_reads_pcr(mcx_group *G, int colour, const uint8_t *bases, con
 static int grp_add_records(mcx_group *G, const void *recs, uint64_t nrecs, int file_ncols, const int32_t *from_col,
                            const int32_t *into_col, int nmap, uint32_t flags, mcx_records_stats *stats_accum)
 {
-  if (flags) return fail(MCX_ERR_ARG, "must-exist / intersect loads are not available on a multi-GPU table");
+  // (must-exist / masked-edge loads of build --intersect: every record is dealt with by the shard that
+  // owns its key, where the intersection colour of that key lives as well -- k_load_records)
   int rc = grp_drain(G);
   if (rc != MCX_OK) return rc;
   mcx_records_stats tot;
@@ -501,9 +595,12 @@ static int grp_add_records(mcx_group *G, const void *recs, uint64_t nrecs, int f
   return MCX_OK;
 }
 
-// The shards hold disjoint key sets.  Unsorted: one shard after the other.  Sorted: the shards'
-// records are gathered on the host and ordered by one device sort (mcx_sort_records), then streamed
-// to the sink in 64 MiB pieces.
+// The shards hold disjoint key sets.  Unsorted: one shard after the other.  Sorted: every shard
+// exports its own records sorted (its own device sort, which walks the key space in ranges when its
+// scratch would not fit beside the table) into host memory, and the host merges the N sorted runs
+// straight into the sink's 64 MiB pieces -- nothing is gathered on one device, so a graph that needs
+// several GPUs to build does not need one GPU to hold it for `--sort`.  Small graphs (MCX_MULTI_SORT_DEV
+// records at most, default 32 M) keep the faster way: one device sort of the gathered records.
 static int grp_export(mcx_group *G, mcx_graph *f, int sorted, mcx_sink_fn sink, void *ctx)
 {
   int rc = grp_sync(G);
@@ -515,7 +612,6 @@ static int grp_export(mcx_group *G, mcx_graph *f, int sorted, mcx_sink_fn sink, 
     }
     return MCX_OK;
   }
-  std::vector<uint8_t> all;
   uint64_t total = 0;
   for (int i = 0; i < G->n; i++) {
     uint64_t n = 0;
@@ -523,25 +619,61 @@ static int grp_export(mcx_group *G, mcx_graph *f, int sorted, mcx_sink_fn sink, 
     if (rc != MCX_OK) return rc;
     total += n;
   }
-  const uint64_t recsz = 8ull * f->W + 5ull * (uint64_t)f->ncols;
-  try { all.reserve(total * recsz); } catch (...) { return fail(MCX_ERR_NOMEM, "out of host memory for %llu records", (unsigned long long)total); }
+  const int W = f->W;
+  const uint64_t recsz = 8ull * W + 5ull * (uint64_t)f->ncols_vis;  // (an intersect build does not export its hidden colour)
+  const char *dsm = getenv("MCX_MULTI_SORT_DEV");
+  const uint64_t dev_sort_max = dsm ? strtoull(dsm, nullptr, 10) : (32ull << 20);
+  const bool on_device = total <= dev_sort_max;
+  std::vector<std::vector<uint8_t>> run(on_device ? 1 : G->n);
   struct Collect { std::vector<uint8_t> *v; };
-  Collect c{&all};
   auto collect = [](void *p, const void *r, size_t nb) -> int {
     Collect *cc = (Collect *)p;
     const uint8_t *b = (const uint8_t *)r;
-    cc->v->insert(cc->v->end(), b, b + nb);
+    try { cc->v->insert(cc->v->end(), b, b + nb); } catch (...) { return 1; }
     return 0;
   };
   for (int i = 0; i < G->n; i++) {
-    rc = mcx_graph_export(G->part[i], 0, collect, &c);
-    if (rc != MCX_OK) return rc;
+    Collect c{&run[on_device ? 0 : i]};
+    rc = mcx_graph_export(G->part[i], on_device ? 0 : 1, collect, &c);
+    if (rc != MCX_OK) return rc == MCX_ERR_SINK ? fail(MCX_ERR_NOMEM, "out of host memory for %llu records", (unsigned long long)total) : rc;
   }
-  const uint64_t n = all.size() / recsz;
-  rc = mcx_sort_records(all.data(), n, f->k, f->ncols, G->part[0]->device);
-  if (rc != MCX_OK) return rc;
   const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz) * recsz;
-  for (uint64_t o = 0; o < all.size(); o += chunk)
-    if (sink(ctx, all.data() + o, (size_t)std::min<uint64_t>(chunk, all.size() - o)) != 0) return fail(MCX_ERR_SINK, "export sink failed");
+  if (on_device) {
+    std::vector<uint8_t> &all = run[0];
+    rc = mcx_sort_records(all.data(), all.size() / recsz, f->k, f->ncols_vis, G->part[0]->device);
+    if (rc != MCX_OK) return rc;
+    for (uint64_t o = 0; o < all.size(); o += chunk)
+      if (sink(ctx, all.data() + o, (size_t)std::min<uint64_t>(chunk, all.size() - o)) != 0) return fail(MCX_ERR_SINK, "export sink failed");
+    return MCX_OK;
+  }
+  // N-way merge: records compare by their key words, word 0 (the top word) first (hash_table.c:371)
+  auto key_word = [&](const uint8_t *r, int w) { uint64_t x; memcpy(&x, r + 8 * w, 8); return x; };
+  auto less = [&](const uint8_t *a, const uint8_t *b) {
+    for (int w = 0; w < W; w++) { const uint64_t x = key_word(a, w), y = key_word(b, w); if (x != y) return x < y; }
+    return false;
+  };
+  struct Head { const uint8_t *p, *end; };
+  std::vector<Head> heap;
+  for (auto &v : run) if (!v.empty()) heap.push_back(Head{v.data(), v.data() + v.size()});
+  auto cmp = [&](const Head &a, const Head &b) { return less(b.p, a.p); };  // min-heap on the head records
+  std::make_heap(heap.begin(), heap.end(), cmp);
+  std::vector<uint8_t> out;
+  out.reserve(chunk);
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), cmp);
+    Head &h = heap.back();
+    // everything of this run below the next run's head goes out in one piece
+    const uint8_t *limit = heap.size() > 1 ? heap.front().p : nullptr;
+    do {
+      out.insert(out.end(), h.p, h.p + recsz);
+      h.p += recsz;
+      if (out.size() >= chunk) {
+        if (sink(ctx, out.data(), out.size()) != 0) return fail(MCX_ERR_SINK, "export sink failed");
+        out.clear();
+      }
+    } while (h.p < h.end && (!limit || less(h.p, limit)));
+    if (h.p < h.end) std::push_heap(heap.begin(), heap.end(), cmp); else heap.pop_back();
+  }
+  if (!out.empty() && sink(ctx, out.data(), out.size()) != 0) return fail(MCX_ERR_SINK, "export sink failed");
   return MCX_OK;
 }

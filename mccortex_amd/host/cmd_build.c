@@ -649,7 +649,6 @@ int ctx_build(int argc, char **argv)
   stage_time("arguments parsed");
   if (mcx_device_count() < 1) die("No MI355X / HIP device found: %s has no CPU build path", CMD_NAME);
   stage_time("HIP runtime up");
-  if (ndevices > 1 && ngisec > 0) die("--intersect needs the whole table on one device (-D takes a single device with it)");
   const size_t dev_cols = ncols + (ngisec > 0 ? 1 : 0); /* + the hidden colour of the intersection edges */
   /* per device: its share of the table (+ the read-start table of --remove-pcr, + the overflow area) */
   const uint64_t dev_bytes = (kmers_in_hash / (uint64_t)ndevices + kmers_in_hash / (uint64_t)ndevices / 32) * 8 * (W + dev_cols + (remove_pcr_used ? 1 : 0));

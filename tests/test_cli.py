@@ -400,7 +400,7 @@ def test_build_on_several_devices_matches_oracle_ctx(built, orc, tmp_path):
         assert rc == 0, err
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and len(outs[0]) > 1000
-    # an odd number of devices is refused; --intersect needs one device
+    # an odd number of devices is refused
     rc, _, err = run(31, "build", "-D", "0,0,0", "-k", "31", "-s", "a", "--seq", f0, str(tmp_path / "x.ctx"))
     assert rc == 1 and "power of two" in err
 

@@ -513,6 +513,14 @@ def test_reference_build1_intersect_and_graph(mcx, orc, tmp_path):
     want, _ = _oracle_intersect(orc, K, 3, [open(ctx["isec1"], "rb").read(), open(ctx["isec0"], "rb").read()],
                                 [(open(ctx["small"], "rb").read(), "1:" + ctx["small"], 0)], {2: "Spiderman"}, [(2, b, o)])
     assert got == want
+    # ... and the same command with the table split over two and four devices (mcx_multi.h:
+    # grp_add_reads_must_exist; consecutive k-mers of a read live on different shards)
+    for devs in ("0,0", "0,0,0,0"):
+        out = str(tmp_path / ("merge_%d.ctx" % len(devs)))
+        rc, _, err = run(31, "build", "-q", "-D", devs, "-n", "1M", "-k", str(K), "--sort", "--intersect", ctx["isec1"], "--intersect", ctx["isec0"],
+                         "--graph", "1:" + ctx["small"], "--sample", "Spiderman", "--seq", seq, out)
+        assert rc == 0, err
+        assert open(out, "rb").read() == want, devs
     rc, _, err = run(31, "build", "-q", "-k", str(K), "-I", ctx["isec0"], "-s", "a", "-p", "--seq", seq, str(tmp_path / "x.ctx"))
     assert rc == 1 and "--remove-pcr" in err
 
@@ -540,6 +548,11 @@ def test_intersect_matches_oracle_on_random_graphs(mcx, orc, tmp_path, maxk, k):
     want, og = _oracle_intersect(orc, k, 2, [open(I, "rb").read()], [(open(G, "rb").read(), G, 0)], {1: "q"}, [(1, *rq), (1, *ra)])
     got = open(out, "rb").read()
     assert 0 < og.nkmers and got == want
+    for devs in ("0,0", "0,0,0,0,0,0,0,0"):  # the table split over several devices: same file
+        out2 = str(tmp_path / ("o_%d.ctx" % len(devs)))
+        rc, _, err = run(maxk, "build", "-q", "-D", devs, "-k", str(k), "-n", "1M", "--sort", "-I", I, "-g", G, "-s", "q", "--seq", f[2], "--seq", f[0], out2)
+        assert rc == 0, err
+        assert open(out2, "rb").read() == want, devs
 
 
 @pytest.mark.gpu

@@ -169,3 +169,29 @@ def test_multi_hot_kmers_spill_instead_of_failing(mcx, orc, k):
         ca = a[:, rs - 5:rs - 1].copy().view("<u4")[:, 0].astype(np.int64)
         cb = b[:, rs - 5:rs - 1].copy().view("<u4")[:, 0].astype(np.int64)
         assert (ca == np.minimum(2 * cb, 0xFFFFFFFF)).all()                               # every read twice
+
+
+@pytest.mark.parametrize("k,ncols,ndev", [(31, 1, 4), (63, 2, 2), (21, 3, 8)])
+def test_multi_sorted_export_merges_per_shard_runs(mcx, orc, k, ncols, ndev, monkeypatch):
+    """`--sort` on a multi-GPU table: above MCX_MULTI_SORT_DEV records nothing is gathered on one device;
+    every shard sorts its own records and the host merges the N sorted runs (hash_table.c:371 order:
+    key words compared top word first).  Forced here for a small graph; same bytes as the oracle and
+    as the one-device-sort path."""
+    g0 = synth.genome(50000, 3)
+    jobs = []
+    for c in range(ncols):
+        b, o = synth.reads(5000, 100, seed=40 + c, g=g0, n_frac=0.03, err=0.003)
+        jobs.append((c, b, o))
+    og = orc.Graph(k, ncols, 1 << 20)
+    for c, b, o in jobs:
+        og.add_reads(c, b, o)
+    want = og.ctx_bytes(True)[og.header_size():]
+    got = {}
+    for lim in ("0", "1000000000"):
+        monkeypatch.setenv("MCX_MULTI_SORT_DEV", lim)
+        g = _multi(mcx, k, ncols, [0] * ndev)
+        for c, b, o in jobs:
+            g.add_reads(c, b, o)
+        got[lim] = g.export(True)
+        g.close()
+    assert got["0"] == want and got["1000000000"] == want

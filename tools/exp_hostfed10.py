@@ -28,8 +28,7 @@ for rep in range(2):
     g.reset(); g.sync()
 print("; ".join(res))
 ''' % ROOT
-variants = [dict(), dict(MCX_STAGE_THREADS="24"),
-            dict(MCX_STAGE_THREADS="32")]
+variants = [dict(), dict(MCX_IDLE_FLUSH="0"), dict(MCX_STAGE_THREADS="24")]
 for env in variants:
     p = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     print(env, p.stdout.decode().strip().splitlines()[-1:], flush=True)
