@@ -366,7 +366,8 @@ def extras(mcx, batches, packed, nsteps, table_slots):
                     a[:500_000].tofile(fq_small)
                 del rec, a
         nthreads = min(32, os.cpu_count() or 1)
-        cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-t", str(nthreads), "--sort", "--sample", "bench", "--seq", fq, ctx]
+        cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-m", "%dG" % (table_slots * 21 // (1 << 30) + 2), "-t", str(nthreads),
+               "--sort", "--sample", "bench", "--seq", fq, ctx]
         best = None
         runs, recs = [], []
         for _ in range(3):  # later runs: file in the page cache, HIP kernels' code objects loaded before
@@ -393,7 +394,7 @@ def extras(mcx, batches, packed, nsteps, table_slots):
                        "exit_to_reaped_s": round(best[3] - ep["epoch_main_exit"], 3)}
         out["e2e"] = {"value": kmers / best[0], "unit": "k-mers/s (upper bound on k-mers: %d per read)" % (READ_LEN - K + 1),
                       "seconds": best[0], "fastq_bytes": os.path.getsize(fq), "ctx_bytes": os.path.getsize(ctx),
-                      "command": "mccortex31 build -k %d -n %d -t %d --sort --seq <%d-read FASTQ> out.ctx" % (K, table_slots, nthreads, ne * B),
+                      "command": "mccortex31 build -k %d -n %d -m %dG -t %d --sort --seq <%d-read FASTQ> out.ctx" % (K, table_slots, table_slots * 21 // (1 << 30) + 2, nthreads, ne * B),
                       "what": "wall clock of the whole process (start, HIP init, parse, build, device sort, .ctx write), MEDIAN of 3 runs (all in runs_s; stages are the median run's)",
                       "runs_s": runs,
                       "process": outside, "stages": [x for x in stages if "epoch_" not in x][-14:]}
@@ -460,7 +461,7 @@ def main():
     B = args.batch_reads
     nsteps, nwarm = args.steps, args.warmup
     sharded = world > 1 or force_shard
-    strong = world > 1 and args.scaling == "strong" and not args.iid
+    strong = sharded and args.scaling == "strong" and not args.iid  # (also under MCX_BENCH_FORCE_SHARD=1 at N = 1: the same code path)
     if args.iid:
         batches = [make_batch_iid(B, seed=1000 * (rank + 1) + i, device=device) for i in range(nsteps + nwarm)]
     elif strong:
@@ -520,6 +521,9 @@ def main():
         xmax = max(x.numel() for x in x_timed + x_warm)
         inserter = shard.ShardedInserter(graph, world, device, xmax, use_v3,
                                          max_tuples=xmax // (READ_LEN + 1) * (READ_LEN - K + 1))
+        if strong:
+            batches = batches[:1]  # (the exchange steps hold copies of the slices)
+            torch.cuda.empty_cache()
 
     def run_steps(idx, xs=None):
         idx = list(idx)
@@ -581,7 +585,7 @@ def main():
     if rank == 0:
         value = kmers_total / dt
         scaling = "strong" if strong else "weak"
-        if world == 1:
+        if world == 1 and not strong:
             shape = "%d reads x %d bp per step from a %d Mbp random genome, table %d slots" % (B, READ_LEN, args.genome // 1_000_000, args.table_slots)
         elif strong:
             shape = ("C3: the N=1 reads (%d reads x %d bp per step from a %d Mbp random genome) dealt out to %d GPUs, %d reads per step per GPU, "

@@ -31,7 +31,7 @@ static const char build_usage[] =
 "  -h, --help               This help message\n"
 "  -q, --quiet              Silence status output normally printed to STDERR\n"
 "  -f, --force              Overwrite output files\n"
-"  -m, --memory <mem>       Memory to use (sizes the table when -n is absent; only an explicit -m is enforced)\n"
+"  -m, --memory <mem>       Memory to use\n"
 "  -n, --nkmers <kmers>     Number of hash table entries (e.g. 1G ~ 1 billion)\n"
 "  -t, --threads <T>        Number of threads to use [default: " MCX_STR(DEFAULT_NTHREADS) "]\n"
 "  -k, --kmer <kmer>        Kmer size must be odd (" MCX_STR(MAX_KMER_SIZE) " >= k >= " MCX_STR(MIN_KMER_SIZE) ")\n"

@@ -209,10 +209,12 @@ const char *table_plan_for_build(size_t mem_to_use, bool mem_set, size_t num_kme
              bytes_to_str(p.bytes, 1, s1), bytes_to_str(mem_to_use, 1, s2));
     return errbuf;
   }
-  /* The reference checks graph_mem against -m even when -m was not given (its 512 MB default), so
-   * `-n 1G` alone dies there.  Here the table lives in HBM and -m bounds nothing on the host: the
-   * check is made only for an explicit -m (documented in the usage text); HBM is checked apart. */
-  if (mem_set && p.bytes > mem_to_use) {
+  /* As the reference (cmd_mem.c:120-123): graph_mem is checked against -m whether or not -m was
+   * given (its default is 512 MB), so `-n 1G` alone dies here as it dies there, with the same
+   * message -- a command line behaves alike in both.  (Until round 3 the check was only made for an
+   * explicit -m.)  The HBM the table really takes is checked apart. */
+  (void)mem_set;
+  if (p.bytes > mem_to_use) {
     snprintf(errbuf, errlen, "Not enough memory for requested graph: require at least %s [>%s]",
              bytes_to_str(p.bytes, 1, s1), bytes_to_str(mem_to_use, 1, s2));
     return errbuf;

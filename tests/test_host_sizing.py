@@ -69,8 +69,11 @@ def test_memory_limit_fills_but_never_exceeds(host):
 def test_build_decision_rules(host):
     bits = 104
     # -n wins over -m; the table holds at least n
-    p, err = _build_plan(host, 512 << 20, False, 10 ** 9, True, bits)
+    p, err = _build_plan(host, 16 << 30, True, 10 ** 9, True, bits)
     assert err is None and p.capacity == 33554432 * 30
+    # ... but must fit -m, given or not (cmd_mem.c:120-123: `-n 1G` alone dies against the 512 MB default)
+    p, err = _build_plan(host, 512 << 20, False, 10 ** 9, True, bits)
+    assert err and "Not enough memory for requested graph" in err
     # -n that does not fit an explicit -m: the reference's message
     p, err = _build_plan(host, 1 << 30, True, 10 ** 9, True, bits)
     assert err and "Not enough memory for requested graph" in err

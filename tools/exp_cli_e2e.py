@@ -37,7 +37,7 @@ if os.environ.get("GZ"):   # GZ=1: the same reads as four .gz files: do the read
     print("wrote 4 x %.2f GB .gz" % (os.path.getsize(parts[0]) / 1e9), flush=True)
     for t in ("1", "2", "4", "8"):
         t0 = time.perf_counter()
-        a = [exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp", "--sort", "-t", t]
+        a = [exe, "build", "-f", "-k", "31", "-n", "512M", "-m", "12G", "-s", "smp", "--sort", "-t", t]
         for pth in parts:
             a += ["--seq", pth]
         p = subprocess.run(a + [os.path.join(out, "o.ctx")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -50,7 +50,7 @@ if os.environ.get("PREFS"):   # e.g. PREFS=1: the read preferences that take the
                 ["--sort", "-t", "8", "--remove-pcr"], ["--sort", "-t", "8", "-Q", "10", "--remove-pcr"])
 for args in VARIANTS:
     t0 = time.perf_counter()
-    p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp"] + args + ["--seq", fq, os.environ.get("OUT", os.path.join(out, "o.ctx"))],
+    p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-m", "12G", "-s", "smp"] + args + ["--seq", fq, os.environ.get("OUT", os.path.join(out, "o.ctx"))],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     dt = time.perf_counter() - t0
     err = p.stderr.decode()
@@ -60,7 +60,7 @@ for args in VARIANTS:
         print("   ", l[-150:])
 print("ctx size %.2f GB" % (os.path.getsize(os.path.join(out, "o.ctx")) / 1e9))
 # stages of one run, from the status lines
-p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-s", "smp", "--sort", "-t", "32", "--seq", fq, os.path.join(out, "o.ctx")],
+p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "512M", "-m", "12G", "-s", "smp", "--sort", "-t", "32", "--seq", fq, os.path.join(out, "o.ctx")],
                    stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 for l in p.stderr.decode().splitlines():
     print("   ", l[:160])

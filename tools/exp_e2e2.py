@@ -20,7 +20,7 @@ del genome; torch.cuda.empty_cache()
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mccortex_amd", "bin", "mccortex31")
 for env, t in [({}, "32"), ({}, "32"), ({}, "32"), ({}, "16"), ({}, "48"), ({"MCX_STAGE_THREADS": "8"}, "32")]:
     t0 = time.perf_counter()
-    p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "1G", "-t", t, "--sort", "-s", "x", "--seq", fq, os.path.join(out, "o.ctx")],
+    p = subprocess.run([exe, "build", "-f", "-k", "31", "-n", "1G", "-m", "24G", "-t", t, "--sort", "-s", "x", "--seq", fq, os.path.join(out, "o.ctx")],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MCX_TIMING="1", **env))
     dt = time.perf_counter() - t0
     st = [l.split("ms", 1) for l in p.stderr.decode().splitlines() if l.startswith("[timing]") and "epoch" not in l and "export" not in l]

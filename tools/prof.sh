@@ -15,6 +15,8 @@ run() { # name, rocprof flags...
   echo "== $name rc=$?"; tail -2 $OUT/$name.log | cut -c1-400
 }
 run trace --kernel-trace --stats
+# the same without the flush overlap (MCX_FLUSH_OVERLAP=0): kernel by kernel, nothing co-running
+MCX_FLUSH_OVERLAP=0 run trace_noovl --kernel-trace --stats
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE
 run pmc_write --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run pmc_ea --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
@@ -24,6 +26,7 @@ run pmc_lds --kernel-trace --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFL
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 # condense on the box (gpurun copies back at most 64 MiB): summary + small CSVs only
 cd $REPO && python tools/summarize_prof.py $TAG $ARGS > $OUT/summary.txt 2>&1
+cp $OUT/trace_noovl/trace_noovl_kernel_stats.csv profiles/${TAG}_kernel_stats_no_overlap.csv 2>/dev/null
 cp profiles/${TAG}_* $OUT/ 2>/dev/null
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
