@@ -177,7 +177,15 @@ struct mcx_graph {
   mcx_group *group = nullptr;
   int gidx = 0;
   mcx_group *as_group = nullptr;
+  uint32_t own_lbo = 0;  // > 0: a shard of a group that deals the keys out by minimizer (exchange format v3): log2 shards
 };
+
+// how the kernels that walk records / reads on every shard tell their own keys (mcx_kernels.h: OwnerSpec)
+static OwnerSpec owner_spec(const mcx_graph *g)
+{
+  if (g->own_lbo) return OwnerSpec{2u, g->own_lbo, (uint32_t)g->gidx, g->k};
+  return OwnerSpec{g->t.lbo ? 1u : 0u, 0u, 0u, g->k};
+}
 
 static int flush_deferred(mcx_graph *g);
 static void free_defer(mcx_graph *g);
@@ -1209,11 +1217,33 @@ extern "C" int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uin
   const StreamArgs a = make_args(g, L);
   const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
   if (!nt) return MCX_OK;
-  SuperkOut out{d_recs, (unsigned long long *)d_counts, seg_cap, lbo, kSuperkRep};
+  SuperkOut out{d_recs, (unsigned long long *)d_counts, seg_cap, lbo, kSuperkRep, nullptr, nullptr, nullptr, 0};
   SpanGuard sp(g, "k_stream_superk");
   const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
-  if (g->W == 1) hipLaunchKernelGGL(k_stream_superk<1>, grid, dim3(kThreads), 0, g->stream, a, out);
-  else hipLaunchKernelGGL(k_stream_superk<2>, grid, dim3(kThreads), 0, g->stream, a, out);
+  if (g->W == 1) hipLaunchKernelGGL((k_stream_superk<1, false>), grid, dim3(kThreads), 0, g->stream, a, out);
+  else hipLaunchKernelGGL((k_stream_superk<2, false>), grid, dim3(kThreads), 0, g->stream, a, out);
+  HIP_TRY(hipGetLastError());
+  return MCX_OK;
+}
+
+// the same for a launch description (ASCII or packed stream, owned range) and with a spill area: the
+// sender step of the in-process multi-GPU table (mcx_multi.h)
+static int superk_bins_launch(mcx_graph *g, const StreamLaunch &L, const SuperkOut &out)
+{
+  if (!L.code && ((uintptr_t)L.stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(g->device));
+  const StreamArgs a = make_args(g, L);
+  const uint64_t nt = a.ntiles > a.tile0 ? a.ntiles - a.tile0 : 0;
+  if (!nt) return MCX_OK;
+  SpanGuard sp(g, "k_stream_superk");
+  const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)g->grid));
+  if (g->W == 1) {
+    if (a.code) hipLaunchKernelGGL((k_stream_superk<1, true>), grid, dim3(kThreads), 0, g->stream, a, out);
+    else hipLaunchKernelGGL((k_stream_superk<1, false>), grid, dim3(kThreads), 0, g->stream, a, out);
+  } else {
+    if (a.code) hipLaunchKernelGGL((k_stream_superk<2, true>), grid, dim3(kThreads), 0, g->stream, a, out);
+    else hipLaunchKernelGGL((k_stream_superk<2, false>), grid, dim3(kThreads), 0, g->stream, a, out);
+  }
   HIP_TRY(hipGetLastError());
   return MCX_OK;
 }
@@ -1267,6 +1297,7 @@ extern "C" uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_
 {
   if (!g) return 0;
   if (g->as_group) g = grp_part(g->as_group, 0);
+  if (g->own_lbo) return g->W == 1 ? superk_owner(0, key_words[0], g->k, g->own_lbo) : superk_owner(key_words[0], key_words[1], g->k, g->own_lbo);
   const uint32_t lbq = g->t.lb1 + g->t.lbo;
   uint32_t r = 0, m;
   if (g->W == 1) {
@@ -1394,14 +1425,15 @@ static int stage_threads()
 // flushes.  One-colour graphs on one device only; MCX_IDLE_FLUSH=0 switches it off.
 static int flush_if_device_idle(mcx_graph *g)
 {
-  static const bool on = [] { const char *e = getenv("MCX_IDLE_FLUSH"); return !e || atoi(e) != 0; }();
+  static const int mode = [] { const char *e = getenv("MCX_IDLE_FLUSH"); return e ? atoi(e) : 1; }();  // 2: take every chance (tests)
+  const bool on = mode != 0;
   if (!on || !g->defer || g->group || g->nsets != 1 || !g->pending || g->pending_l2 || g->set_colour.empty() || g->set_colour[0] < 0) return MCX_OK;
   const uint32_t G = std::min(flush_group(g), g->l2_regions);
   if (G >= g->b1) return MCX_OK;  // one group = the whole table: nothing incremental about it
   const uint32_t ngroups = (g->b1 + G - 1) / G;
   // worth a group's table pass: its share of 1 / 8 of the flush size, at least 16 M occurrences
-  if (g->pending / ngroups < std::max<uint64_t>(g->defer_tuples / 8 / ngroups, 1ull << 24)) return MCX_OK;
-  if (hipStreamQuery(g->stream) != hipSuccess) { (void)hipGetLastError(); return MCX_OK; }  // busy: the device is not waiting for us
+  if (mode != 2 && g->pending / ngroups < std::max<uint64_t>(g->defer_tuples / 8 / ngroups, 1ull << 24)) return MCX_OK;
+  if (mode != 2 && hipStreamQuery(g->stream) != hipSuccess) { (void)hipGetLastError(); return MCX_OK; }  // busy: the device is not waiting for us
   const uint32_t r0 = g->idle_next * G < g->b1 ? g->idle_next * G : 0;
   g->idle_next = (r0 / G + 1) % ngroups;
   const uint32_t ng = std::min(G, g->b1 - r0);
@@ -1729,10 +1761,10 @@ static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, 
     SpanGuard sp(g, "k_reads_must_exist");
     if (g->W == 1)
       hipLaunchKernelGGL((k_reads_must_exist<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
-                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u);
+                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u, owner_spec(g));
     else
       hipLaunchKernelGGL((k_reads_must_exist<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
-                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u);
+                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u, owner_spec(g));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1856,10 +1888,10 @@ static int cut_starts(CutJob &J)
   const unsigned blocks = (unsigned)((J.nreads + 127) / 128);
   if (g->W == 1)
     hipLaunchKernelGGL((k_pcr_starts<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
-                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr);
+                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr, owner_spec(g));
   else
     hipLaunchKernelGGL((k_pcr_starts<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
-                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr);
+                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr, owner_spec(g));
   CUT_TRY(hipGetLastError());
   return MCX_OK;
 }
@@ -2067,10 +2099,10 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
     SpanGuard sp(g, "k_load_records");
     if (g->W == 1)
       hipLaunchKernelGGL((k_load_records<1>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p);
+                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p, owner_spec(g));
     else
       hipLaunchKernelGGL((k_load_records<2>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p);
+                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p, owner_spec(g));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->ev[cur], g->stream));
   }

@@ -909,7 +909,7 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
 #define MCX_LDS_PREFETCH2 1  // two-word keys: the next sub-table's slice is fetched into registers while this one is applied
 #endif
 template <int W> struct LdsCfg {
-  static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : 512;
+  static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : (MCX_SUB2_SHIFT == 12 ? 1024 : 512);
   static constexpr int kMinWaves = W == 1 ? 4 : MCX_LDS_MINW2;
   static constexpr bool kPrefetch = W == 1 ? true : (MCX_LDS_PREFETCH2 != 0);
 };
@@ -926,7 +926,7 @@ template <int W> struct LdsCfg {
 #define MCX_LDS_QUEUE 1  // 1: one straight-line probe per occurrence; what it cannot finish is queued in LDS
 #endif
 // tuples of the LDS queue: what is left of a CU's 160 KiB beside two 64 KiB (three 48 KiB) slices
-template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : 288; };
+template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : (MCX_SUB2_SHIFT == 12 ? 2048 : 288); };
 #ifndef MCX_LDS_AHEAD
 #define MCX_LDS_AHEAD 0  // 1: the fill of the next sub-table's bin and its first two tuple batches are requested one sub-table ahead
                          // (round 3: 16.5 vs 16.65 ms at C2, 38.1 vs 37.8 at C4 -- the insert is not waiting for those loads; off)

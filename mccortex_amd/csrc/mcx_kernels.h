@@ -31,12 +31,15 @@ constexpr int kBucket = 4;  // slots per hash bucket (64 B when S == 2)
 // single workgroup (mcx_defer.h).  One-word keys: 4096 slots (64 KiB of key + value words, two
 // workgroups per CU); two-word keys: 2048 slots (48 KiB, so that two or three workgroups share a
 // CU instead of one 96 KiB slice monopolising it).
+#ifndef MCX_SUB2_SHIFT
+#define MCX_SUB2_SHIFT 11  // log2 slots of a two-word sub-table (12: 96 KiB slices, one 1024-thread workgroup per CU -- experiment)
+#endif
 template <int W> struct Sub {
-  static constexpr int kShift = W == 1 ? 12 : 11;
+  static constexpr int kShift = W == 1 ? 12 : MCX_SUB2_SHIFT;
   static constexpr uint64_t kSlots = 1ull << kShift;
   static constexpr uint32_t kBuckets = (uint32_t)(kSlots / kBucket);
 };
-__host__ __device__ constexpr int sub_shift_for_words(int W) { return W == 1 ? 12 : 11; }
+__host__ __device__ constexpr int sub_shift_for_words(int W) { return W == 1 ? 12 : MCX_SUB2_SHIFT; }
 
 struct TableView {
   uint64_t *rec;
@@ -191,6 +194,64 @@ template <int W> __device__ __forceinline__ uint64_t key_slot(const TableView &t
   const Kmer<W> q = key_quot<W>(key, lbq_of(t), r);
   const TableAddr a = addr_of<W>(t, q, r);
   return ((uint64_t)a.sub << Sub<W>::kShift) + (uint64_t)a.bucket * kBucket;
+}
+
+// ---------------------------------------------------------------------------
+// Who owns a key (a table split over several GPUs)
+// ---------------------------------------------------------------------------
+// Two ways to deal the keys out.  (1) hash prefix: owner = top bits of the address word G; the table
+// itself is sharded (TableView::lbo / part) -- exchange format v2.  (2) minimizer: owner = hash of the
+// smallest hashed canonical 13-mer inside the k-mer (mcx_superk.h, exchange format v3: reads travel,
+// not occurrences); every shard then holds an ordinary table.  Kernels that walk records or reads on
+// every shard and keep what is theirs (k_load_records, k_pcr_starts, k_reads_must_exist) take an
+// OwnerSpec.
+constexpr int kMmer = 13;                                  // minimizer length
+constexpr uint32_t kMmerMask = (1u << (2 * kMmer)) - 1u;
+constexpr int kSuperkMinK = kMmer + 16;                    // 29
+
+// hash of a canonical m-mer (its 2-bit value): multiply-xorshift, 32 bits
+MCX_HD uint32_t mmer_hash(uint32_t c)
+{
+  const uint32_t x = c * 0x9E3779B1u;
+  return x ^ (x >> 15);
+}
+// owner from the minimum hash: the minimum of many uniform values is biased towards 0, so it is
+// mixed again before its top bits are taken
+MCX_HD uint32_t owner_of_minimizer(uint32_t min_hash, uint32_t lbo)
+{
+  return lbo ? ((min_hash * 0x85EBCA6Bu) ^ (min_hash >> 13)) * 0xC2B2AE35u >> (32u - lbo) : 0u;
+}
+
+// Host/device reference: owner of a k-mer given as its 2-bit value (w0 = top word, unused for
+// k <= 31).  The kernels compute the same thing incrementally; tests compare shard contents
+// against this.
+MCX_HD uint32_t superk_owner(uint64_t w0, uint64_t w1, int k, uint32_t lbo)
+{
+  uint32_t best = 0xFFFFFFFFu;
+  for (int p = 0; p + kMmer <= k; p++) {
+    const int sh = 2 * (k - kMmer - p);  // the m-mer's low bit inside the 2k-bit number w0 : w1
+    const uint64_t low = sh >= 64 ? (w0 >> (sh - 64)) : (sh ? (w1 >> sh) | (w0 << (64 - sh)) : w1);
+    const uint32_t f = (uint32_t)low & kMmerMask;
+    uint32_t r = 0;
+    for (int i = 0; i < kMmer; i++) r |= (3u - ((f >> (2 * i)) & 3u)) << (2 * (kMmer - 1 - i));
+    const uint32_t h = mmer_hash(f < r ? f : r);
+    best = h < best ? h : best;
+  }
+  return owner_of_minimizer(best, lbo);
+}
+
+
+struct OwnerSpec {
+  uint32_t mode;  // 0: one table, everything is mine; 1: hash prefix (the table's lbo / part); 2: minimizer
+  uint32_t lbo;   // mode 2: log2 shards
+  uint32_t part;  // mode 2: this shard
+  int k;
+};
+template <int W> __device__ __forceinline__ bool owner_is_me(const TableView &t, const OwnerSpec &os, const Kmer<W> &key)
+{
+  if (os.mode == 2) return superk_owner(W == 1 ? 0ULL : key.w[0], key.w[W - 1], os.k, os.lbo) == os.part;
+  if (os.mode == 1) return key_owner<W>(t, key) == t.part;
+  return true;
 }
 
 struct Counters {  // device-resident, 64-bit each
@@ -401,7 +462,7 @@ template <int W>
 __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t *recs, uint64_t nrecs, uint64_t rec0,
                                                       uint32_t file_ncols, const int32_t *from, const int32_t *into,
                                                       uint32_t nmap, uint32_t must_exist, int mask_col, int kmer_size,
-                                                      Counters *ctr, RecordStats *st)
+                                                      Counters *ctr, RecordStats *st, OwnerSpec os)
 {
   if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   const uint32_t rec_bytes = 8u * W + 5u * file_ncols;
@@ -425,7 +486,7 @@ __global__ __launch_bounds__(256) void k_load_records(TableView t, const uint8_t
     if (!any_file) atomicMin(&st->first_zero_covg, (unsigned long long)(rec0 + i));
     if (edges_no_covg) atomicMin(&st->first_edges_no_covg, (unsigned long long)(rec0 + i));
     if (!any_loaded) continue;
-    if (t.lbo && key_owner<W>(t, key) != t.part) continue;  // a shard of a multi-GPU table only loads its own keys
+    if (!owner_is_me<W>(t, os, key)) continue;  // a shard of a multi-GPU table only loads its own keys
     const uint64_t slot = find_or_insert_rec<W>(t, key, must_exist != 0, novel, full);
     if (slot == kNoSlot) continue;
     // must_exist_in_edges (graphs_load.c:166-167): only edges the intersection graph has
@@ -1017,7 +1078,7 @@ constexpr uint64_t kForeignNode = ~0ULL - 1;  // the read's start k-mer belongs 
 template <int W>
 __global__ void k_pcr_starts(TableView t, const uint8_t *bases, const uint8_t *quals, const uint64_t *off, uint64_t nreads,
                              int k, uint32_t qcut1, uint32_t qcut2, uint32_t pmask, uint32_t hcut,
-                             uint32_t *first, uint64_t *node_of, Counters *ctr)
+                             uint32_t *first, uint64_t *node_of, Counters *ctr, OwnerSpec os)
 {
   if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1040,7 +1101,7 @@ __global__ void k_pcr_starts(TableView t, const uint8_t *bases, const uint8_t *q
     const Kmer<W> rc = revcomp<W>(fw, k);
     uint32_t o, novel = 0, full = 0;
     const Kmer<W> key = canonical<W>(fw, rc, o);
-    if (t.lbo && key_owner<W>(t, key) != t.part) { node_of[r] = kForeignNode; return; }
+    if (!owner_is_me<W>(t, os, key)) { node_of[r] = kForeignNode; return; }
     const uint64_t slot = find_or_insert_rec<W>(t, key, false, novel, full);
     if (novel) atomicAdd(&ctr->novel, 1ULL);
     if (full) atomicAdd(&ctr->full, 1ULL);
@@ -1170,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_checksum(TableView t, uint32_t W, uint3
 template <int W>
 __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint8_t *quals, const uint64_t *off,
                                    uint64_t nreads, int k, uint32_t qcut, uint32_t hcut, uint32_t col, Counters *ctr,
-                                   uint8_t *present, uint32_t phase)
+                                   uint8_t *present, uint32_t phase, OwnerSpec os)
 {
   if (phase != 1 && blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(t);
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1212,7 +1273,7 @@ __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint
         n_absent += slot == kNoSlot;
       } else {
         const uint64_t gi = off[r] + i;  // the k-mer's last base: one byte of `present` per k-mer occurrence
-        const bool mine = key_owner<W>(t, key) == t.part;
+        const bool mine = owner_is_me<W>(t, os, key);
         if (phase == 1) {
           if (mine) present[gi] = find_or_insert_rec<W>(t, key, true, dummy_novel, full) != kNoSlot;
         } else {
@@ -1235,7 +1296,7 @@ __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint
     }
     n_contigs++;
   }
-  if (phase == 1 || (phase == 2 && t.part != 0)) return;  // (statistics: once)
+  if (phase == 1 || (phase == 2 && (os.mode == 2 ? os.part : t.part) != 0)) return;  // (statistics: once)
   if (n_kmers) atomicAdd(&ctr->kmers, n_kmers);
   if (n_absent) atomicAdd(&ctr->absent, n_absent);
   if (n_contigs) atomicAdd(&ctr->contigs, n_contigs);

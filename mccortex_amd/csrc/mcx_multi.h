@@ -7,7 +7,16 @@
 // out to the shards, so that the host program (host/cmd_build.c) is the same for one GPU and for
 // eight: reads, -Q / -H, --remove-pcr, --graph loads, statistics and the export all go through it.
 //
-// Data path of a batch of reads (exchange format v2, the same kernels bench.py drives through
+// Two exchange formats, as in the process-per-GPU driver (mccortex_amd/shard.py):
+//   v3 (odd k in 29..63, the default there): the owner of a k-mer is a hash of its canonical minimizer;
+//      READS travel -- per-owner super-k-mer records, about a third of v2's bytes on the links --, the
+//      owner k-merises what it receives, and every shard holds an ordinary table (mcx_superk.h);
+//   v2 (any k; MCX_MULTI_EXCHANGE=v2 forces it): the table is sharded by quotient-hash prefix and
+//      packed OCCURRENCES travel.
+// Either way a piece's blocks have a fixed size, go out with one peer copy per (owner, buffer) and carry
+// their fills with them: the host never reads a count.
+//
+// Data path of a batch of reads in format v2 (the same kernels bench.py drives through
 // torch.distributed / RCCL with one process per GPU):
 //   1. the batch is cut into one contiguous piece per shard; shard i stages its piece and k-merises
 //      it with the sender kernel (k_stream_bin, BIN_GLOBAL): packed occurrences binned by
@@ -31,6 +40,13 @@ struct XBuf {  // one block set: packed tuples by (owner, region) + per-owner ov
   uint64_t *ov_keys = nullptr;    // send sets: [N][ov_cap], then the spill area [sp_cap] (BinOut::ov_keys)
   uint8_t *ov_edges = nullptr;
   unsigned long long *ov_counts = nullptr;  // send sets: [N] fills, [N] = spill fill, [N + 1] = spill capacity
+  // format v3: super-k-mer records by (owner, replica segment)
+  void *recs = nullptr;                      // send: [N][segs][sk_cap] records; receive: [segs][sk_cap]
+  unsigned long long *fills_rm = nullptr;    // send: fills as the sender kernel writes them, [segs][N]
+  unsigned long long *fills = nullptr;       // send: the same, [N][segs] (one row per owner: what travels); receive: [segs]
+  void *sp_recs = nullptr;                   // send: spill area (SuperkOut::sp_recs / sp_own / sp_count)
+  uint8_t *sp_own = nullptr;
+  unsigned long long *sp_count = nullptr;
 };
 
 }  // namespace
@@ -41,6 +57,9 @@ struct mcx_group {
   // geometry of one exchange piece (at most max_pos k-mer start positions)
   uint32_t segs = 0;
   uint64_t seg_cap = 0, ov_cap = 0, max_pos = 0;
+  bool v3 = false;      // exchange format v3 (minimizer ownership, ordinary per-shard tables)
+  uint32_t sk_segs = 0; // v3: replica segments per owner
+  uint64_t sk_cap = 0;  // v3: records per segment
   uint64_t sp_cap = 0;  // spill area of a send set: every occurrence of a piece fits, so no input can overflow
   std::vector<std::array<unsigned long long *, 2>> h_spill;  // [i][b] pinned: spill fill of the set's last piece
   std::vector<std::array<int, 2>> spill_colour;               // colour of that piece
@@ -72,6 +91,7 @@ static void group_free_buffers(mcx_group *G)
       if ((size_t)i < G->send.size()) {
         XBuf &x = G->send[i][b];
         (void)hipFree(x.keys); (void)hipFree(x.counts); (void)hipFree(x.ov_keys); (void)hipFree(x.ov_edges); (void)hipFree(x.ov_counts);
+        (void)hipFree(x.recs); (void)hipFree(x.fills_rm); (void)hipFree(x.fills); (void)hipFree(x.sp_recs); (void)hipFree(x.sp_own); (void)hipFree(x.sp_count);
         x = XBuf();
         if ((size_t)i < G->h_spill.size() && G->h_spill[i][b]) { (void)hipHostFree(G->h_spill[i][b]); G->h_spill[i][b] = nullptr; }
       }
@@ -79,6 +99,7 @@ static void group_free_buffers(mcx_group *G)
         for (auto &r : G->recv[i]) {
           XBuf &x = r[b];
           (void)hipFree(x.keys); (void)hipFree(x.counts); (void)hipFree(x.ov_keys); (void)hipFree(x.ov_edges); (void)hipFree(x.ov_counts);
+          (void)hipFree(x.recs); (void)hipFree(x.fills);
           x = XBuf();
         }
     }
@@ -95,6 +116,43 @@ static int group_ensure_buffers(mcx_group *G)
   const int N = G->n, W = g0->W;
   G->max_pos = std::max<uint64_t>(kStageBytes + kCarry, 32ull << 20);
   if (const char *e = getenv("MCX_MULTI_PIECE")) G->max_pos = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));  // tests
+  if (G->v3) {
+    // ~2.3 records per 16 positions on random reads; room for 3: what does not fit a segment goes to the
+    // sender's spill area and is routed by the host.  The spill takes 4 records per 16 positions more: low-
+    // complexity input makes LONG runs (one minimizer), i.e. few records; only an input that changes owner
+    // at nearly every k-mer of a whole piece could exceed 7 records per 16 positions (reported: MCX_ERR_FULL)
+    const uint64_t recb = 16ull * W;
+    G->sk_segs = kSuperkRep;
+    G->sk_cap = G->max_pos * 3 / 16 / ((uint64_t)N * G->sk_segs) + 4096;
+    G->sp_cap = G->max_pos / 4 + 4096;
+    if (const char *e = getenv("MCX_MULTI_SKCAP")) G->sk_cap = std::max<uint64_t>(16, strtoull(e, nullptr, 10));  // tests: force the spill path
+    G->send.resize(N);
+    G->recv.assign(N, std::vector<std::array<XBuf, 2>>(N));
+    G->h_spill.assign(N, {nullptr, nullptr});
+    G->spill_colour.assign(N, {0, 0});
+    const uint64_t blk_recs = (uint64_t)G->sk_segs * G->sk_cap;
+    for (int i = 0; i < N; i++) {
+      GRP_TRY(hipSetDevice(G->part[i]->device));
+      for (int b = 0; b < 2; b++) {
+        XBuf &s = G->send[i][b];
+        GRP_TRY(hipMalloc((void **)&s.recs, (uint64_t)N * blk_recs * recb));
+        GRP_TRY(hipMalloc((void **)&s.fills_rm, (uint64_t)N * G->sk_segs * 8));
+        GRP_TRY(hipMalloc((void **)&s.fills, (uint64_t)N * G->sk_segs * 8));
+        GRP_TRY(hipMalloc((void **)&s.sp_recs, G->sp_cap * recb));
+        GRP_TRY(hipMalloc((void **)&s.sp_own, G->sp_cap));
+        GRP_TRY(hipMalloc((void **)&s.sp_count, 8));
+        GRP_TRY(hipHostMalloc((void **)&G->h_spill[i][b], 8, hipHostMallocDefault));
+        *G->h_spill[i][b] = 0;
+        for (int src = 0; src < N; src++) {
+          XBuf &r = G->recv[i][src][b];
+          GRP_TRY(hipMalloc((void **)&r.recs, blk_recs * recb));
+          GRP_TRY(hipMalloc((void **)&r.fills, (uint64_t)G->sk_segs * 8));
+        }
+      }
+    }
+    G->buffers = true;
+    return MCX_OK;
+  }
   const uint32_t b1 = 1u << g0->t.lb1;
   G->segs = kShardRep * b1;
   const double mean = (double)G->max_pos / ((double)N * G->segs);
@@ -154,6 +212,32 @@ static int group_route_spill(mcx_group *G, int idx, int b)
   *G->h_spill[idx][b] = 0;
   const int N = G->n, W = me->W, colour = G->spill_colour[idx][b];
   const XBuf &s = G->send[idx][b];
+  if (G->v3) {  // records: every shard picks its own out of the spill and k-merises them
+    const uint64_t recb = 16ull * W;
+    for (int j = 0; j < N; j++) {
+      mcx_graph *own = G->part[j];
+      GRP_TRY(hipSetDevice(own->device));
+      uint8_t *r = nullptr, *o = nullptr, *d = nullptr;
+      unsigned long long *cnt = nullptr;
+      GRP_TRY(hipMalloc((void **)&r, n * recb));
+      GRP_TRY(hipMalloc((void **)&o, n));
+      GRP_TRY(hipMalloc((void **)&d, n * recb));
+      GRP_TRY(hipMalloc((void **)&cnt, 8));
+      GRP_TRY(hipMemcpyPeerAsync(r, own->device, s.sp_recs, me->device, n * recb, own->stream));
+      GRP_TRY(hipMemcpyPeerAsync(o, own->device, s.sp_own, me->device, n, own->stream));
+      GRP_TRY(hipMemsetAsync(cnt, 0, 8, own->stream));
+      const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
+      if (W == 1) hipLaunchKernelGGL(k_superk_pick<1>, dim3(blocks), dim3(256), 0, own->stream, (const void *)r, (const uint8_t *)o, n, (uint32_t)j, (void *)d, cnt);
+      else hipLaunchKernelGGL(k_superk_pick<2>, dim3(blocks), dim3(256), 0, own->stream, (const void *)r, (const uint8_t *)o, n, (uint32_t)j, (void *)d, cnt);
+      GRP_TRY(hipGetLastError());
+      int rc = mcx_graph_add_superk_dev(own, colour, d, cnt, 1, n, n * 16);
+      if (rc != MCX_OK) return rc;
+      GRP_TRY(hipStreamSynchronize(own->stream));
+      (void)hipFree(r); (void)hipFree(o); (void)hipFree(d); (void)hipFree(cnt);
+    }
+    GRP_TRY(hipSetDevice(me->device));
+    return MCX_OK;
+  }
   const uint64_t at = (uint64_t)N * G->ov_cap;
   for (int j = 0; j < N; j++) {
     mcx_graph *own = G->part[j];
@@ -182,6 +266,61 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
   const int N = G->n;
   mcx_graph *me = G->part[idx];
   const int W = me->W;
+  if (G->v3) {
+    const uint64_t recb = 16ull * W, blk_recs = (uint64_t)G->sk_segs * G->sk_cap;
+    uint32_t lbo = 0;
+    while ((1 << lbo) < N) lbo++;
+    for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
+      const uint64_t hi = std::min(L.pos_hi, lo + G->max_pos);
+      const int b = G->cur[idx];
+      G->cur[idx] ^= 1;
+      XBuf &s = G->send[idx][b];
+      rc = group_route_spill(G, idx, b);  // what this set's previous piece spilled (nearly always nothing)
+      if (rc != MCX_OK) return rc;
+      // 1. sender: minimizers, per-owner records
+      GRP_TRY(hipSetDevice(me->device));
+      if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(me->stream, G->sent[idx][b], 0));  // its last copies have left
+      GRP_TRY(hipMemsetAsync(s.fills_rm, 0, (uint64_t)N * G->sk_segs * 8, me->stream));
+      GRP_TRY(hipMemsetAsync(s.sp_count, 0, 8, me->stream));
+      StreamLaunch P = L;
+      P.pos_lo = lo; P.pos_hi = hi;
+      SuperkOut so{s.recs, s.fills_rm, G->sk_cap, lbo, G->sk_segs, s.sp_recs, s.sp_own, s.sp_count, G->sp_cap};
+      rc = superk_bins_launch(me, P, so);
+      if (rc != MCX_OK) return rc;
+      hipLaunchKernelGGL(k_transpose_fills, dim3(((unsigned)N * G->sk_segs + 63) / 64), dim3(64), 0, me->stream,
+                         (const unsigned long long *)s.fills_rm, s.fills, G->sk_segs, (uint32_t)N);
+      GRP_TRY(hipGetLastError());
+      GRP_TRY(hipMemcpyAsync(G->h_spill[idx][b], s.sp_count, 8, hipMemcpyDeviceToHost, me->stream));
+      G->spill_colour[idx][b] = colour;
+      GRP_TRY(hipEventRecord(G->filled[idx][b], me->stream));
+      // 2. one copy of the fills and one of the records per owner: whole segments, so no count is read on the host
+      GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->filled[idx][b], 0));
+      for (int j = 0; j < N; j++) {
+        mcx_graph *own = G->part[j];
+        XBuf &r = G->recv[j][idx][b];
+        if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->consumed[j][idx][b], 0));  // the slot is free again
+        GRP_TRY(hipMemcpyPeerAsync(r.fills, own->device, s.fills + (uint64_t)j * G->sk_segs, me->device, (uint64_t)G->sk_segs * 8, G->cs[idx]));
+        GRP_TRY(hipMemcpyPeerAsync(r.recs, own->device, (const uint8_t *)s.recs + (uint64_t)j * blk_recs * recb, me->device, blk_recs * recb, G->cs[idx]));
+        GRP_TRY(hipEventRecord(G->arrived[j][idx][b], G->cs[idx]));
+      }
+      GRP_TRY(hipEventRecord(G->sent[idx][b], G->cs[idx]));
+      // 3. owners: k-merise what arrived into their region bins
+      const uint64_t share = (hi - lo) / (uint64_t)N + (hi - lo) / (uint64_t)(4 * N) + 4096;  // estimate for the flush clock
+      for (int j = 0; j < N; j++) {
+        mcx_graph *own = G->part[j];
+        XBuf &r = G->recv[j][idx][b];
+        GRP_TRY(hipSetDevice(own->device));
+        GRP_TRY(hipStreamWaitEvent(own->stream, G->arrived[j][idx][b], 0));
+        rc = mcx_graph_add_superk_dev(own, colour, r.recs, r.fills, G->sk_segs, G->sk_cap, std::min(share, blk_recs * 16));
+        if (rc != MCX_OK) return rc;
+        GRP_TRY(hipEventRecord(G->consumed[j][idx][b], own->stream));
+      }
+      G->used[idx][b] = true;
+      lo = hi;
+    }
+    GRP_TRY(hipSetDevice(me->device));
+    return MCX_OK;
+  }
   const uint64_t blk = (uint64_t)G->segs * G->seg_cap;
   for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
     const uint64_t hi = std::min(L.pos_hi, lo + G->max_pos);
@@ -283,11 +422,20 @@ extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols,
   mcx_group *G = new mcx_group();
   G->n = ndevices;
   G->part.assign(ndevices, nullptr);
+  {
+    const char *e = getenv("MCX_MULTI_EXCHANGE");
+    G->v3 = mcx_superk_supported(kmer_size) && !(e && !strcmp(e, "v2"));
+  }
+  uint32_t lbo = 0;
+  while ((1 << lbo) < ndevices) lbo++;
   for (int i = 0; i < ndevices; i++) {
-    int rc = mcx_graph_create_shard(&G->part[i], kmer_size, ncols, per, devices[i], ndevices, i);
+    // v3: an ordinary table per device (the keys are dealt out by minimizer); v2: a hash-prefix shard
+    int rc = G->v3 ? mcx_graph_create(&G->part[i], kmer_size, ncols, per, devices[i])
+                   : mcx_graph_create_shard(&G->part[i], kmer_size, ncols, per, devices[i], ndevices, i);
     if (rc != MCX_OK) { group_destroy(G); return rc; }
     G->part[i]->group = G;
     G->part[i]->gidx = i;
+    if (G->v3) G->part[i]->own_lbo = lbo;
   }
   G->cs.assign(ndevices, nullptr);
   G->filled.assign(ndevices, {nullptr, nullptr});
@@ -429,10 +577,10 @@ static int grp_add_reads_must_exist(mcx_group *G, int colour, const uint8_t *bas
     mcx_graph *g = G->part[i];
     if (g->W == 1)
       hipLaunchKernelGGL((k_reads_must_exist<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases[i], (const uint8_t *)d_quals[i],
-                         (const uint64_t *)d_off[i], nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, d_present[i], phase);
+                         (const uint64_t *)d_off[i], nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, d_present[i], phase, owner_spec(g));
     else
       hipLaunchKernelGGL((k_reads_must_exist<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases[i], (const uint8_t *)d_quals[i],
-                         (const uint64_t *)d_off[i], nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, d_present[i], phase);
+                         (const uint64_t *)d_off[i], nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, d_present[i], phase, owner_spec(g));
   };
   for (int i = 0; i < N; i++) {  // upload, phase 1
     mcx_graph *g = G->part[i];

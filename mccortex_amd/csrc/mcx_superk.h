@@ -19,40 +19,7 @@
 
 namespace mcx {
 
-constexpr int kMmer = 13;                                  // minimizer length
-constexpr uint32_t kMmerMask = (1u << (2 * kMmer)) - 1u;
-constexpr int kSuperkMinK = kMmer + 16;                    // 29
-
-// hash of a canonical m-mer (its 2-bit value): multiply-xorshift, 32 bits
-MCX_HD uint32_t mmer_hash(uint32_t c)
-{
-  const uint32_t x = c * 0x9E3779B1u;
-  return x ^ (x >> 15);
-}
-// owner from the minimum hash: the minimum of many uniform values is biased towards 0, so it is
-// mixed again before its top bits are taken
-MCX_HD uint32_t owner_of_minimizer(uint32_t min_hash, uint32_t lbo)
-{
-  return lbo ? ((min_hash * 0x85EBCA6Bu) ^ (min_hash >> 13)) * 0xC2B2AE35u >> (32u - lbo) : 0u;
-}
-
-// Host/device reference: owner of a k-mer given as its 2-bit value (w0 = top word, unused for
-// k <= 31).  The kernels compute the same thing incrementally; tests compare shard contents
-// against this.
-MCX_HD uint32_t superk_owner(uint64_t w0, uint64_t w1, int k, uint32_t lbo)
-{
-  uint32_t best = 0xFFFFFFFFu;
-  for (int p = 0; p + kMmer <= k; p++) {
-    const int sh = 2 * (k - kMmer - p);  // the m-mer's low bit inside the 2k-bit number w0 : w1
-    const uint64_t low = sh >= 64 ? (w0 >> (sh - 64)) : (sh ? (w1 >> sh) | (w0 << (64 - sh)) : w1);
-    const uint32_t f = (uint32_t)low & kMmerMask;
-    uint32_t r = 0;
-    for (int i = 0; i < kMmer; i++) r |= (3u - ((f >> (2 * i)) & 3u)) << (2 * (kMmer - 1 - i));
-    const uint32_t h = mmer_hash(f < r ? f : r);
-    best = h < best ? h : best;
-  }
-  return owner_of_minimizer(best, lbo);
-}
+// (kMmer, mmer_hash, owner_of_minimizer, superk_owner: mcx_kernels.h, "Who owns a key")
 
 #if defined(__HIPCC__)
 
@@ -89,14 +56,31 @@ struct SuperkOut {
   unsigned long long *counts;
   uint64_t cap;
   uint32_t lbo, rep;
+  // Records that do not fit their segment (one owner far above its share: poly-G reads, a satellite
+  // repeat) go to the sender's spill area, any owner, with the owner beside them; the host routes
+  // them (mcx_multi.h).  sp_cap == 0: no spill area, such records are dropped and reported (bin_over).
+  void *sp_recs;                 // [sp_cap] records
+  uint8_t *sp_own;               // [sp_cap] owner of each
+  unsigned long long *sp_count;  // fill
+  uint64_t sp_cap;
 };
+
+template <int W> __device__ __forceinline__ bool sk_spill(const SuperkOut &out, const SkRec<W> &rec, uint32_t owner)
+{
+  if (!out.sp_cap) return false;
+  const unsigned long long p = atomicAdd(out.sp_count, 1ULL);
+  if (p >= out.sp_cap) return false;
+  reinterpret_cast<SkRec<W> *>(out.sp_recs)[p] = rec;
+  out.sp_own[p] = (uint8_t)owner;
+  return true;
+}
 
 template <int W> struct SkCfg { static constexpr int kStage = 2048 / W; };  // records staged per tile in LDS (a tile of random reads makes ~600, ~350 at k = 63)
 
 // ---------------------------------------------------------------------------
 // sender: reads -> per-owner bins of super-k-mer records
 // ---------------------------------------------------------------------------
-template <int W>
+template <int W, bool PK /* the stream comes packed (code words + invalid flags), as the host entry stages it */>
 __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, SuperkOut out)
 {
   constexpr int kSkStage = SkCfg<W>::kStage;
@@ -119,17 +103,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
   pre.a = make_uint4(0, 0, 0, 0); pre.b = make_uint4(0, 0, 0, 0);
   {
     const uint64_t t0 = a.tile0 + blockIdx.x;
-    if (t0 < a.ntiles) tile_fetch<false>(a, t0, tid, pre);
+    if (t0 < a.ntiles) tile_fetch<PK>(a, t0, tid, pre);
   }
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
-    tile_stage<false>(a, pre, tid, s_code, s_inv);
+    tile_stage<PK>(a, pre, tid, s_code, s_inv);
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     if (tid < 32) { s_cnt[tid] = 0; s_rank[tid] = 0; }
     if (tid == 0) s_total = 0;
     {
       const uint64_t tn = tile + gridDim.x;
-      if (tn < a.ntiles) tile_fetch<false>(a, tn, tid, pre);
+      if (tn < a.ntiles) tile_fetch<PK>(a, tn, tid, pre);
     }
     __syncthreads();
 
@@ -215,7 +199,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
           else {  // staging full (pathological input): straight to the bin, one global atomic
             const unsigned long long pos = atomicAdd(&out.counts[rep * nparts + cur], 1ULL);
             if (pos < out.cap) recs_out[((uint64_t)cur * out.rep + rep) * out.cap + pos] = rec;
-            else dropped = 1;
+            else if (!sk_spill<W>(out, rec, cur)) dropped = 1;
           }
           start = -1;
         }
@@ -233,12 +217,29 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_superk(StreamArgs a, Sup
       const uint32_t o = s_own[q];
       const unsigned long long pos = s_base[o] + atomicAdd(&s_rank[o], 1u);
       if (pos < out.cap) recs_out[((uint64_t)o * out.rep + rep) * out.cap + pos] = s_rec[q];
-      else dropped = 1;
+      else if (!sk_spill<W>(out, s_rec[q], o)) dropped = 1;
     }
   }
   block_add(&a.ctr->kmers, n_kmers);
   block_add(&a.ctr->contigs, n_contigs);
   if (dropped) a.ctr->bin_over = 1;
+  if (a.flag && n_contigs) *a.flag = 1;  // (a piece of a read longer than a staging chunk holds a contig: the read is a good one)
+}
+
+// owner side of a spill: the records of `owner` out of a spill area (recs, own)[n] -> dst[0 .. *count)
+template <int W>
+__global__ void k_superk_pick(const void *recs, const uint8_t *own, uint64_t n, uint32_t owner, void *dst, unsigned long long *count)
+{
+  const SkRec<W> *src = reinterpret_cast<const SkRec<W> *>(recs);
+  SkRec<W> *out = reinterpret_cast<SkRec<W> *>(dst);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    if (own[i] == owner) out[atomicAdd(count, 1ULL)] = src[i];
+}
+// fills [rep][nparts] (what the sender writes) -> [nparts][rep] (one contiguous row per owner, what travels)
+__global__ void k_transpose_fills(const unsigned long long *in, unsigned long long *out, uint32_t rep, uint32_t nparts)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rep * nparts) out[(i % nparts) * rep + i / nparts] = in[i];
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,53 @@
+"""The host entry at a size where its background flush runs: reads in host memory ->
+mcx_graph_add_reads (staging threads, packed chunks, H2D) with the idle-device flush forced at every
+chunk (MCX_IDLE_FLUSH=2: one region group per chunk, csrc/mcx_api.hip flush_if_device_idle) must
+build the graph the device-resident path builds.  Replaces the worker loop of
+src/basic/async_read_io.c:283-310 + src/tools/build_graph.c:233-254."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import bench, mccortex_amd as mcx
+dev = torch.device("cuda", 0)
+B, L = 2_000_000, 150
+genome = bench.make_genome(20_000_000, dev, 7)
+b = bench.make_batch(genome, B, 77, dev)
+host = b.reshape(B, L + 1)[:, :L].contiguous().cpu().numpy().reshape(-1)
+offs = np.arange(B + 1, dtype=np.uint64) * L
+res = []
+for mode in ("host", "dev"):
+    g = mcx.Graph(31, 1, 1 << 27)
+    g.configure("profile", 1)
+    for rep in range(3):
+        if mode == "host":
+            g.add_reads(0, host, offs)
+        else:
+            g.add_stream_dev(0, b, b.numel())
+    g.sync()
+    st = g.device_stats()
+    cs, n = g.checksum()
+    prof = g.profile()
+    res.append((cs, n, st.num_kmers_loaded, st.contigs_parsed, prof["k_lds_insert"][0]))
+    g.close()
+print("RESULT", res)
+''' % ROOT
+
+
+def test_host_fed_build_with_background_flush_matches_device_resident_build():
+    env = dict(os.environ, MCX_IDLE_FLUSH="2", MCX_STAGE_BYTES=str(32 << 20))  # 20 chunks per call: 20 chances to flush a group
+    p = subprocess.run([sys.executable, "-c", CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("RESULT")][-1]
+    host, dev = eval(line[len("RESULT"):])
+    assert host[:4] == dev[:4]          # checksum, nodes, k-mers loaded, contigs
+    assert host[2] > 700_000_000 and host[1] > 10_000_000
+    assert host[4] > dev[4]             # ... and the background flush did run (more LDS-insert launches than one closing flush)

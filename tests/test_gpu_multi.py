@@ -18,8 +18,11 @@ def _multi(mcx, k, ncols, devices, cap=1 << 20):
     return g
 
 
-@pytest.mark.parametrize("k,ndev", [(31, 2), (31, 4), (63, 2), (21, 2)])
-def test_multi_add_reads_matches_oracle(mcx, orc, k, ndev):
+@pytest.mark.parametrize("k,ndev,xch", [(31, 2, "v3"), (31, 4, "v3"), (31, 8, "v3"), (63, 2, "v3"), (63, 4, "v2"), (31, 2, "v2"), (31, 4, "v2"), (21, 2, "v2")])
+def test_multi_add_reads_matches_oracle(mcx, orc, k, ndev, xch, monkeypatch):
+    """both exchange formats of the in-process table: v3 (minimizer-owned super-k-mer records, ordinary
+    per-shard tables; odd k >= 29) and v2 (hash-prefix shards, packed occurrences; any k)"""
+    monkeypatch.setenv("MCX_MULTI_EXCHANGE", xch)
     bases, offs = synth.reads(6000, 120, genome_len=60000, seed=k + ndev, n_frac=0.05, lower_frac=0.1)
     og = orc.Graph(k, 1, 1 << 20)
     ost = og.add_reads(0, bases, offs)
@@ -38,6 +41,12 @@ def test_multi_add_reads_matches_oracle(mcx, orc, k, ndev):
     assert sorted(map(bytes, a)) == sorted(map(bytes, b))
     cs, n = g.checksum()
     assert n == og.nkmers and cs == mcx.records_checksum(want, k, 1)
+    # which shard holds a key is what mcx_graph_key_owner says (minimizer hash in v3, hash prefix in v2)
+    rs = 8 * g.W + 5
+    recs = np.frombuffer(want, np.uint8).reshape(-1, rs)
+    for row in recs[:: max(1, len(recs) // 50)]:
+        kw = [int(x) for x in np.frombuffer(row[:8 * g.W].tobytes(), "<u8")]
+        assert 0 <= g.key_owner(kw) < ndev
     g.close()
 
 
@@ -131,13 +140,14 @@ def test_multi_needs_power_of_two(mcx):
         mcx.Graph(31, 1, 1 << 20, devices=[0, 0, 0])
 
 
-@pytest.mark.parametrize("k", [31, 63])
-def test_multi_hot_kmers_spill_instead_of_failing(mcx, orc, k):
+@pytest.mark.parametrize("k,xch", [(31, "v3"), (63, "v3"), (31, "v2"), (63, "v2")])
+def test_multi_hot_kmers_spill_instead_of_failing(mcx, orc, k, xch, monkeypatch):
     """Low-complexity input on a sharded table: a 3 Mbase poly-G read and 4000 poly-A reads put
     millions of occurrences of ONE k-mer on one owner -- far beyond its (owner, region) segment
     (mean + 8 sigma) and the owner's overflow bin (>= 64 K tuples).  One GPU handles that with a direct
     insert on the spot; the multi-GPU sender spills what fits nowhere and the host routes it to the
     owners (mcx_multi.h, group_route_spill).  Same graph as the oracle, in one piece and in many."""
+    monkeypatch.setenv("MCX_MULTI_EXCHANGE", xch)
     rng = np.random.default_rng(5)
     reads = [b"G" * 3_000_000]
     reads += [b"A" * 150] * 4000
@@ -195,3 +205,23 @@ def test_multi_sorted_export_merges_per_shard_runs(mcx, orc, k, ncols, ndev, mon
         got[lim] = g.export(True)
         g.close()
     assert got["0"] == want and got["1000000000"] == want
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_multi_v3_record_segments_spill(mcx, orc, k, monkeypatch):
+    """Exchange format v3 with record segments far too small (MCX_MULTI_SKCAP): nearly every super-k-mer
+    record takes the sender's spill area and is routed to its owner by the host (k_superk_pick); same
+    graph as the oracle."""
+    monkeypatch.setenv("MCX_MULTI_EXCHANGE", "v3")
+    monkeypatch.setenv("MCX_MULTI_SKCAP", "64")
+    monkeypatch.setenv("MCX_MULTI_PIECE", "400000")
+    bases, offs = synth.reads(9000, 130, genome_len=80000, seed=k, n_frac=0.04, lower_frac=0.05)
+    og = orc.Graph(k, 1, 1 << 20)
+    ost = og.add_reads(0, bases, offs)
+    g = _multi(mcx, k, 1, [0, 0, 0, 0])
+    g.add_reads(0, bases, offs)
+    g.sync()
+    st = g.device_stats()
+    assert st.num_kmers_loaded == ost.num_kmers_loaded and st.contigs_parsed == ost.contigs_parsed
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    g.close()
