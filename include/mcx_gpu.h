@@ -107,8 +107,11 @@ int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value);
 int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen);
 
 /* One table over several GPUs of a node, driven by one host process: what the reference's batch
- * loop (src/commands/ctx_build.c:384-407) becomes when the hash table it feeds is split by hash
- * prefix across `ndevices` devices (a power of two <= 32; a device may be named more than once).
+ * loop (src/commands/ctx_build.c:384-407) becomes when the hash table it feeds is split across
+ * `ndevices` devices (a power of two <= 32; a device may be named more than once): by the hash of a
+ * k-mer's canonical minimizer for odd k in 29..63 (exchange format v3: reads travel as super-k-mer
+ * records, every device holds an ordinary table), by hash prefix otherwise (format v2: occurrences
+ * travel; MCX_MULTI_EXCHANGE=v2 forces it).  mcx_graph_key_owner tells which device holds a key.
  * SURVEY.md 8(b) sketched this as the devices / ndevices arguments of mcx_graph_create.  The handle
  * that comes back is used like any other: mcx_graph_add_reads (the batch is dealt out to the
  * shards, each k-merises its piece and sends every other shard its occurrences with peer copies

@@ -192,8 +192,11 @@ def test_c2_full_size_in_process_multi(mcx, c2_batches):
     """mcx_graph_create_multi with two, four and eight (C3's count) shards on the one GPU at C2 size: the
     facade's checksum / node count / counters equal the single table's (csrc/mcx_multi.h)."""
     ref = _build(mcx, c2_batches, 31, 1, 1 << 30, {"defer_tuples": 8_000_000_000})
-    for devs in ([0, 0], [0, 0, 0, 0], [0] * 8):
+    # exchange format v3 (minimizer-owned super-k-mer records: the default at k = 31) and v2 (hash-prefix shards)
+    for xch, devs in (("v3", [0, 0]), ("v3", [0, 0, 0, 0]), ("v3", [0] * 8), ("v2", [0, 0]), ("v2", [0] * 8)):
+        os.environ["MCX_MULTI_EXCHANGE"] = xch
         g = mcx.Graph(31, 1, 1 << 30, devices=devs)
+        os.environ.pop("MCX_MULTI_EXCHANGE")
         g.configure("defer_tuples", 8_000_000_000 // len(devs))
         for b in c2_batches:
             g.add_stream_dev(0, b, b.numel())
@@ -202,5 +205,5 @@ def test_c2_full_size_in_process_multi(mcx, c2_batches):
         cs, n = g.checksum()
         nk, sc = g.kmer_covg()
         g.close()
-        assert (cs, n, st.num_kmers_loaded, st.contigs_parsed) == (ref["checksum"], ref["nodes"], ref["loaded"], ref["contigs"]), devs
+        assert (cs, n, st.num_kmers_loaded, st.contigs_parsed) == (ref["checksum"], ref["nodes"], ref["loaded"], ref["contigs"]), (xch, devs)
         assert int(nk[0]) == ref["nodes"] and int(sc[0]) == ref["loaded"]
