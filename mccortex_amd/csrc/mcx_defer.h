@@ -305,40 +305,21 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
 #ifndef MCX_DEBUG_BOUNDS
 #define MCX_DEBUG_BOUNDS 0     // 1: every index the write-out derives is checked and reported with printf instead of being used
 #endif
-  for (uint32_t p = lo + (MCX_WRITEOUT_TIDNOW ? tid_now() : threadIdx.x); p < hi; p += LDS::geo::kT) {
-    const uint32_t q = p - lo;
-    const uint32_t b = L.sbin[q];
-#if MCX_DEBUG_BOUNDS
-    if (b >= bs.nlocal || q >= kSt) {
-      printf("bin_writeout: block %u thread %u round %d: q %u, positions [%u, %u) (n %u), bin %u of %u\n", blockIdx.x, threadIdx.x, round, q, lo, hi, n, b, bs.nlocal);
-      continue;
-    }
-#endif
-    const unsigned long long gb = L.gbase[b];
-#if MCX_DEBUG_BOUNDS
-    {
-      const uint64_t total = (uint64_t)bs.rep * bs.nout * (bs.mode == BIN_GLOBAL ? bs.nparts : 1u) * out.cap;
-      const uint64_t at_dbg = (gb + p) & kDstMask;
-      if (p < (uint32_t)(gb >> 48) && at_dbg >= total) {
-        printf("bin_writeout: block %u thread %u round %d: q %u bin %u gbase %llx -> tuple index %llu of %llu\n", blockIdx.x, threadIdx.x, round, q, b,
-               gb, (unsigned long long)at_dbg, (unsigned long long)total);
-        continue;
-      }
-    }
-#endif
-    if (MCX_EXP_L1 && bs.mode == BIN_GROUP) { if (L.skey[q * W] == 0x123456789ULL && gb == 77) full = 1; continue; }
+  // one staged tuple (sorted position p, bin b, that bin's base word gb, tuple words t0 [t1]) -> its place
+  auto emit = [&](uint32_t p, uint32_t b, unsigned long long gb, uint64_t t0, uint64_t t1) {
+    if (MCX_EXP_L1 && bs.mode == BIN_GROUP) { if (t0 == 0x123456789ULL && gb == 77) full = 1; return; }
     if (p < (uint32_t)(gb >> 48)) {
       const uint64_t at = (gb + p) & kDstMask;
       uint64_t *kd = out.keys + at * W;
-      kd[0] = L.skey[q * W];
-      if (W == 2) kd[1] = L.skey[q * W + 1];
-      if (FULL) out.edges[at] = L.se[q];
+      kd[0] = t0;
+      if (W == 2) kd[1] = t1;
+      if (FULL) out.edges[at] = L.se[p - lo];
     } else if (FULL || bs.mode == BIN_OWNER) {
       full = 2;
     } else {  // packed tuple -> full key
       Kmer<W> tq;
-      tq.w[0] = L.skey[q * W];
-      if (W == 2) tq.w[W - 1] = L.skey[q * W + 1];
+      tq.w[0] = t0;
+      if (W == 2) tq.w[W - 1] = t1;
       const uint32_t e = (uint32_t)(tq.w[0] >> 56);
       const Kmer<W> qq = tuple_q<W>(tq);
       const uint32_t lbq = lbq_of(isink.t);
@@ -379,6 +360,20 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
         probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
       }
     }
+  };
+  // (A lane taking two neighbouring sorted positions -- one 16-byte store where both go to the same bin at an
+  // even index, else two 8-byte stores -- was tried in round 3: k_stream_bin 22.5 -> 30 ms, the unmerged pairs
+  // write half lines per instruction.  One position per lane it is.)
+  for (uint32_t p = lo + (MCX_WRITEOUT_TIDNOW ? tid_now() : threadIdx.x); p < hi; p += LDS::geo::kT) {
+    const uint32_t q = p - lo;
+    const uint32_t b = L.sbin[q];
+#if MCX_DEBUG_BOUNDS
+    if (b >= bs.nlocal || q >= kSt) {
+      printf("bin_writeout: block %u thread %u round %d: q %u, positions [%u, %u) (n %u), bin %u of %u\n", blockIdx.x, threadIdx.x, round, q, lo, hi, n, b, bs.nlocal);
+      continue;
+    }
+#endif
+    emit(p, b, L.gbase[b], L.skey[q * W], W == 2 ? L.skey[q * W + W - 1] : 0);
   }
   if (round + 1 < kRounds) __syncthreads();  // staging is reused by the next round
 }
