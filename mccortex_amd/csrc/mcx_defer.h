@@ -922,6 +922,9 @@ template <int W> struct LdsCfg {
 #endif
 // tuples of the LDS queue: what is left of a CU's 160 KiB beside two 64 KiB (three 48 KiB) slices
 template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : (MCX_SUB2_SHIFT == 12 ? 2048 : 288); };
+#ifndef MCX_EXP_INS
+#define MCX_EXP_INS 0  // timing experiments on the LDS insert (results are wrong by construction): 1 no apply, 2 no slice store, 3 neither, 4 probe reads only
+#endif
 #ifndef MCX_LDS_AHEAD
 #define MCX_LDS_AHEAD 0  // 1: the fill of the next sub-table's bin and its first two tuple batches are requested one sub-table ahead
                          // (round 3: 16.5 vs 16.65 ms at C2, 38.1 vs 37.8 at C4 -- the insert is not waiting for those loads; off)
@@ -1390,6 +1393,15 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
           Kmer<W> key;
           uint32_t bucket, e;
           unpack(tk[q], key, bucket, e);
+#if MCX_EXP_INS == 1 || MCX_EXP_INS == 3   // timing experiment: tuples are loaded and unpacked, not applied
+          if (key.w[0] == 0x123456789ULL && bucket == 77u && e == 5u) full = 1;
+          continue;
+#elif MCX_EXP_INS == 4                     // ... applied, but only the probe's reads (no atomics)
+          { typedef unsigned long long u64x2_ __attribute__((ext_vector_type(2)));
+            const u64x2_ a_ = *(MCX_LDS_AS const u64x2_ *)(lds + bucket * kBucket), b_ = *(MCX_LDS_AS const u64x2_ *)(lds + bucket * kBucket + 2);
+            if ((a_.x ^ a_.y ^ b_.x ^ b_.y) == (key.w[0] | kFlag) + 12345u) full = 1; }
+          continue;
+#endif
 #if MCX_LDS_QUEUE
           if (!lds_try<W>(lds, key, bucket, e, n_novel)) {
             const uint32_t qi = atomicAdd(&s_nq, 1u);
@@ -1474,7 +1486,11 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
       if (tid == 0) s_nq = 0;
     }
 #endif
+#if MCX_EXP_INS == 2 || MCX_EXP_INS == 3     // timing experiment: the slice is not written back
+    if (lds[tid] == 0x123456789ULL) full = 1;
+#else
     slice_store<W, ONECOL, kLdsThreads>(t, sub, col, tid, lds);
+#endif
     if (tid == 0 && t.touch) atomicOr(&t.touch[1 + (sub >> 5)], 1u << (sub & 31u));
     bi = nb;
   }

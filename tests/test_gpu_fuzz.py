@@ -1,6 +1,10 @@
 """Randomised parity: arbitrary byte streams, every odd k, ragged stream lengths."""
+import os
+
 import numpy as np
 import pytest
+
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -102,3 +106,42 @@ def test_superkmer_records_on_arbitrary_bytes(mcx, orc, seed):
                 bodies.append(g.export(True))
                 g.close()
             assert shard.merge_sorted_bodies(bodies, 8 * W + 5, 8 * W) == want, (n, k, nparts)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MCX_FUZZ_SEEDS", "6"))))
+def test_random_colours_devices_and_batches(mcx, orc, seed, monkeypatch):
+    """Random k, colours, device count, exchange format, pool of L1 bin sets, flush size and batch cuts;
+    samples in random order (colour switches at every batch); arbitrary bytes in some reads.  The graph
+    must be the oracle's whatever the shape (MCX_FUZZ_SEEDS widens the run for a soak)."""
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.choice([5, 11, 21, 27, 29, 31, 33, 41, 55, 63]))
+    ncols = int(rng.integers(1, 5))
+    ndev = int(rng.choice([1, 1, 2, 4, 8]))
+    monkeypatch.setenv("MCX_MULTI_EXCHANGE", str(rng.choice(["v2", "v3"])))
+    monkeypatch.setenv("MCX_L1_SETS", str(int(rng.choice([1, 2, 5, 32]))))
+    monkeypatch.setenv("MCX_MULTI_PIECE", str(int(rng.choice([40000, 250000, 1 << 27]))))
+    g0 = synth.genome(int(rng.integers(3000, 60000)), seed)
+    alphabet = np.frombuffer(b"ACGT" * 30 + b"acgtNn-*", np.uint8)
+    jobs = []
+    for _ in range(int(rng.integers(3, 14))):
+        n = int(rng.integers(1, 2500))
+        ln = int(rng.integers(1, 260))
+        b, o = synth.reads(n, ln, seed=int(rng.integers(1 << 30)), g=g0, n_frac=float(rng.choice([0, 0.05, 0.5])), lower_frac=0.1, err=0.003)
+        if rng.random() < 0.3:  # a few reads of arbitrary bytes, ragged lengths (among them empty ones)
+            extra = [bytes(rng.choice(alphabet, int(rng.integers(0, 400)))) for _ in range(int(rng.integers(1, 40)))]
+            b2, o2 = orc.pack_reads(extra)
+            b = np.concatenate([b, b2]); o = np.concatenate([o, o[-1] + o2[1:]])
+        jobs.append((int(rng.integers(0, ncols)), b, o))
+    og = orc.Graph(k, ncols, 1 << 20)
+    tot = 0
+    for c, b, o in jobs:
+        tot += og.add_reads(c, b, o).num_kmers_loaded
+    want = og.ctx_bytes(True)[og.header_size():]
+    g = mcx.Graph(k, ncols, 1 << 20, devices=[0] * ndev) if ndev > 1 else mcx.Graph(k, ncols, 1 << 20)
+    g.configure("defer_tuples", int(rng.choice([1 << 20, 1 << 22, 1 << 26])))
+    for c, b, o in jobs:
+        g.add_reads(c, b, o)
+    assert g.device_stats().num_kmers_loaded == tot, (seed, k, ncols, ndev)
+    assert g.nkmers == og.nkmers, (seed, k, ncols, ndev)
+    assert g.export(True) == want, (seed, k, ncols, ndev)
+    g.close()
