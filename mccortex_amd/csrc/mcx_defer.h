@@ -922,6 +922,9 @@ template <int W> struct LdsCfg {
 #endif
 // tuples of the LDS queue: what is left of a CU's 160 KiB beside two 64 KiB (three 48 KiB) slices
 template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : (MCX_SUB2_SHIFT == 12 ? 2048 : 288); };
+#ifndef MCX_LDS_DEPTH
+#define MCX_LDS_DEPTH 2  // tuple batches in flight per thread in the LDS insert
+#endif
 #ifndef MCX_EXP_INS
 #define MCX_EXP_INS 0  // timing experiments on the LDS insert (results are wrong by construction): 1 no apply, 2 no slice store, 3 neither, 4 probe reads only
 #endif
@@ -1444,6 +1447,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
     // The next slice is requested after the first two batches (loads return in order, so those do
     // not queue behind its 64 KiB).  Both variants of "is there a next slice" are straight-line code.
     auto run = [&](auto has_next) {
+#if MCX_LDS_DEPTH == 2
       Kmer<W> ta[kLdsBatch], tb[kLdsBatch];
       load_batch(0, ta);
       load_batch(kStep, tb);
@@ -1454,6 +1458,20 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
         apply_batch(j0 + kStep, tb);
         load_batch(j0 + 3 * kStep, tb);
       }
+#else   // MCX_LDS_DEPTH batches in flight (experiment: more bytes on their way while a batch is applied)
+      constexpr int D = MCX_LDS_DEPTH;
+      Kmer<W> tq[D][kLdsBatch];
+#pragma unroll
+      for (int d = 0; d < D; d++) load_batch((uint64_t)d * kStep, tq[d]);
+      if (decltype(has_next)::value) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v, zeros_known);
+      for (uint64_t j0 = 0; j0 < n; j0 += D * kStep) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+          apply_batch(j0 + (uint64_t)d * kStep, tq[d]);
+          load_batch(j0 + (uint64_t)(D + d) * kStep, tq[d]);
+        }
+      }
+#endif
     };
     if (kPrefetch && nb < nsub) run(std::true_type{}); else run(std::false_type{});
 #else
