@@ -88,7 +88,12 @@ int mcx_graph_reset(mcx_graph *g);
  *                  occurrence is inserted straight into the HBM table with device atomics.
  *                  Both give the same graph.
  *   "defer_tuples" occurrences buffered per flush (sizes the bin workspace in HBM); default: 64 per
- *                  table slot within 30 % of the HBM free after the table was allocated
+ *                  table slot within 30 % of the HBM free after the table was allocated.  A graph with
+ *                  several colours shares this workspace between its colours (a pool of bin sets, each
+ *                  bound to the colour that first writes to it): colours may alternate from call to
+ *                  call without a flush, and a flush makes one pass over the table per colour.
+ *                  Reads handed over in host memory while the device is idle are flushed in the
+ *                  background, one group of table regions at a time (MCX_IDLE_FLUSH=0: off).
  *   "flush_regions" table regions split + applied per step of a flush (0 = automatic: 16 K sub-tables
  *                  per step); bounds the sub-table bin workspace to that share of the table
  *   "intersect"    1: `build --intersect` (ctx_build.c:341-363,384-413).  The graph must have been
