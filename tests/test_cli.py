@@ -393,13 +393,14 @@ def test_build_on_several_devices_matches_oracle_ctx(built, orc, tmp_path):
     p1 = _write_inputs(tmp_path, b0, o0, "p1", "fq")
     b2, o2 = synth.reads(4000, 100, seed=9, g=g)
     p2 = _write_inputs(tmp_path, b2, o2, "p2", "fq")
-    outs = []
-    for devs in ("0", "0,0"):
-        out = str(tmp_path / ("pcr_%d.ctx" % len(devs)))
-        rc, _, err = run(31, "build", "-q", "-D", devs, "-k", "27", "-n", "4M", "--sort", "-s", "x", "--remove-pcr", "--seq2", p1 + ":" + p2, out)
-        assert rc == 0, err
-        outs.append(open(out, "rb").read())
-    assert outs[0] == outs[1] and len(outs[0]) > 1000
+    for kk in ("27", "31"):  # k = 27: exchange format v2 (hash-prefix owners); k = 31: v3 (minimizer owners)
+        outs = []
+        for devs in ("0", "0,0", "0,0,0,0"):
+            out = str(tmp_path / ("pcr_%s_%d.ctx" % (kk, len(devs))))
+            rc, _, err = run(31, "build", "-q", "-D", devs, "-k", kk, "-n", "4M", "--sort", "-s", "x", "--remove-pcr", "--seq2", p1 + ":" + p2, out)
+            assert rc == 0, err
+            outs.append(open(out, "rb").read())
+        assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000, kk
     # an odd number of devices is refused
     rc, _, err = run(31, "build", "-D", "0,0,0", "-k", "31", "-s", "a", "--seq", f0, str(tmp_path / "x.ctx"))
     assert rc == 1 and "power of two" in err
