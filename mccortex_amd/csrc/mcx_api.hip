@@ -562,7 +562,7 @@ template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, Tupl
 
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour, uint32_t sub0, uint32_t nsub)
 {
-  const size_t lds = Sub<W>::kSlots * (W + 1) * 8 + (MCX_LDS_QUEUE ? LdsQueue<W>::kTuples * 8 * W : 0);
+  const size_t lds = Sub<W>::kSlots * (W + 1) * 8 + LdsQueue<W>::kTuples * 8 * W;
   static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
   bool &once = once_dev[g->device & 63];
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }

@@ -71,26 +71,6 @@ struct BinOut {
   uint64_t ov_cap;
 };
 
-#ifndef MCX_RANK_FROM_COUNT
-#define MCX_RANK_FROM_COUNT 1  // k_stream_bin: sorted position = bin offset + what the counting atomic returned
-#endif
-#ifndef MCX_TOP_BARRIER
-#define MCX_TOP_BARRIER 0
-#endif
-#ifndef MCX_RANK_GROUP
-#define MCX_RANK_GROUP 4  // returning LDS atomics of the ranking in flight per lane (4, 8; other = the compiler's choice)
-#endif
-#ifndef MCX_PSCAN
-#define MCX_PSCAN 1   // 1: the histogram scan of a tile is shared by the block's four waves (0: wave 0 scans alone)
-#endif
-#ifndef MCX_VEC16
-#define MCX_VEC16 1    // 1: tuple segments are read with 16-byte loads where their alignment allows
-#endif
-// Timing experiments only (tools/variants.sh): switch parts of the L1 binning kernel off to see what they
-// cost.  The graph that comes out is wrong by construction (the bins stay empty).
-#ifndef MCX_EXP_L1
-#define MCX_EXP_L1 0  // 1: no global write-out; 2: also no LDS placement; 3: also no histogram / rank atomics
-#endif
 #define MCX_LDS_AS __attribute__((address_space(3)))
 constexpr int kMaxBins = 2048;
 constexpr uint64_t kQMask = (1ull << 56) - 1;  // quotient bits of the top tuple word
@@ -111,10 +91,7 @@ template <int W> __device__ __forceinline__ Kmer<W> tuple_q(const Kmer<W> &t)
 
 // The sorted tile is staged and written out in kRounds rounds of kStage tuples: the staging
 // area is what limits blocks per CU (W=2: 84 KB for a whole tile = 1 block, 46 KB = 3 blocks).
-#ifndef MCX_ROUNDS
-#define MCX_ROUNDS 2
-#endif
-constexpr int kRounds = MCX_ROUNDS;
+constexpr int kRounds = 2;  // (1 round: k_stream_bin 22.8 -> 31.2 ms at C2, round 3)
 constexpr int kStage = kTile / kRounds;
 
 // Geometry of a binning block: T threads, TILE tuples per tile (staged in kRounds rounds).  The
@@ -145,9 +122,8 @@ template <int W, int NB, bool FULL, class G = Geo256> struct BinLds {
 // addresses, masks) is then recomputed per tile in an instruction or two -- hoisted out of the
 // loop these values were spilled to scratch, and a scratch reload waits for the next tile's
 // prefetch (vmcnt counts in order).
-// Used by k_stream_bin's tile loop only.  (In the write-out loop of bin_writeout the same trick
-// produced a kernel that faults -- `tools/`-built variant, round 2; the cause was not found, so the
-// shared helpers keep reading threadIdx.x.)
+// Used by k_stream_bin's tile loop only (the write-out loop of bin_writeout keeps threadIdx.x: see the
+// note there and profiles/r03_writeout_fault.md).
 __device__ __forceinline__ uint32_t tid_now()
 {
   uint32_t t = threadIdx.x;
@@ -168,7 +144,6 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
   constexpr int kT = LDS::geo::kT;
   const int tid = threadIdx.x;
   __syncthreads();
-#if MCX_PSCAN
   {  // every thread scans NB / kT consecutive bins; the waves' totals meet in LDS.  (One wave
      // scanning all bins while the other three wait at the barrier cost 8 % of the k-merising kernel.)
     constexpr int PERB = NB / kT;
@@ -206,24 +181,6 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     // (trash_beyond) past the tile, where the placement never looks
     if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)LDS::geo::kTileG : total;
   }
-#else
-  if (tid < 64) {
-    uint32_t carry = 0;
-    for (uint32_t b0 = 0; b0 < bs.nlocal; b0 += 64) {
-      const uint32_t b = b0 + tid;
-      const uint32_t c = b < bs.nlocal ? L.cnt[b] : 0;
-      uint32_t x = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (tid >= d) x += y;
-      }
-      if (b < bs.nlocal) L.off[b] = carry + x - c;
-      carry += __shfl(x, 63, 64);
-    }
-    if (tid < 64) L.off[bs.nlocal + tid] = tid && trash_beyond ? (uint32_t)LDS::geo::kTileG : carry;
-  }
-#endif
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < (NB + kT - 1) / kT; q++) {
@@ -231,7 +188,7 @@ __device__ __forceinline__ void bin_reserve(LDS &L, const BinSpec &bs, const Bin
     res.g0[q] = 0;
     if (b < bs.nlocal) {
       const uint32_t c = L.cnt[b];
-      if (c) res.g0[q] = atomicAdd(&out.counts[out_seg(bs, ob0, b)], (unsigned long long)(MCX_EXP_L1 ? 0 : c));
+      if (c) res.g0[q] = atomicAdd(&out.counts[out_seg(bs, ob0, b)], (unsigned long long)c);
     }
   }
   // (no barrier: the ranking that follows counts in rnk[], which was zeroed at the top of the tile)
@@ -299,15 +256,8 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
   // subtraction of n is left to get wrong.
   const uint32_t lo = (uint32_t)round * kSt;
   const uint32_t hi = min(n, lo + kSt);
-#ifndef MCX_WRITEOUT_TIDNOW
-#define MCX_WRITEOUT_TIDNOW 0  // 1: the loop index starts from the opaque thread index (the variant that faulted in round 2)
-#endif
-#ifndef MCX_DEBUG_BOUNDS
-#define MCX_DEBUG_BOUNDS 0     // 1: every index the write-out derives is checked and reported with printf instead of being used
-#endif
   // one staged tuple (sorted position p, bin b, that bin's base word gb, tuple words t0 [t1]) -> its place
   auto emit = [&](uint32_t p, uint32_t b, unsigned long long gb, uint64_t t0, uint64_t t1) {
-    if (MCX_EXP_L1 && bs.mode == BIN_GROUP) { if (t0 == 0x123456789ULL && gb == 77) full = 1; return; }
     if (p < (uint32_t)(gb >> 48)) {
       const uint64_t at = (gb + p) & kDstMask;
       uint64_t *kd = out.keys + at * W;
@@ -364,15 +314,9 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
   // (A lane taking two neighbouring sorted positions -- one 16-byte store where both go to the same bin at an
   // even index, else two 8-byte stores -- was tried in round 3: k_stream_bin 22.5 -> 30 ms, the unmerged pairs
   // write half lines per instruction.  One position per lane it is.)
-  for (uint32_t p = lo + (MCX_WRITEOUT_TIDNOW ? tid_now() : threadIdx.x); p < hi; p += LDS::geo::kT) {
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += LDS::geo::kT) {
     const uint32_t q = p - lo;
     const uint32_t b = L.sbin[q];
-#if MCX_DEBUG_BOUNDS
-    if (b >= bs.nlocal || q >= kSt) {
-      printf("bin_writeout: block %u thread %u round %d: q %u, positions [%u, %u) (n %u), bin %u of %u\n", blockIdx.x, threadIdx.x, round, q, lo, hi, n, b, bs.nlocal);
-      continue;
-    }
-#endif
     emit(p, b, L.gbase[b], L.skey[q * W], W == 2 ? L.skey[q * W + W - 1] : 0);
   }
   if (round + 1 < kRounds) __syncthreads();  // staging is reused by the next round
@@ -433,11 +377,8 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
 //    other shards take the direct insert), SH 2 of every shard (BIN_GLOBAL, exchange blocks).
 //    The variants are compiled apart: code of the rare paths costs the common one registers.
 // ---------------------------------------------------------------------------
-#ifndef MCX_SB_BLOCKS
-#define MCX_SB_BLOCKS 4
-#endif
 template <int W, bool ONECOL, int NB, bool FULL, int SH, bool PK>
-__global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stream_bin(StreamArgs a_arg, BinSpec bs, BinOut out_arg,
+__global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a_arg, BinSpec bs, BinOut out_arg,
                                                                          InsertSink<W, ONECOL> isink_arg)
 {
   __shared__ uint32_t s_code[kChunks + 4];
@@ -480,9 +421,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
     // (opaque: what is derived from the thread index -- LDS addresses, masks -- is recomputed per
     // tile in an instruction or two; hoisted out of the loop it was spilled to scratch)
     const int tid = (int)tid_now();
-#if MCX_TOP_BARRIER
-    __syncthreads();
-#endif
     // (No barrier here: what is written before the next one -- the tile's codes and flags, the
     // zeroed counters -- was last read before the write-out's entry barrier of the previous tile;
     // what a slower wave may still be reading, the staging area and the bin bases, is next
@@ -629,12 +567,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
           local = (local & valid) | (trash & ~valid);
           tle[j] = local;
         }
-#if MCX_EXP_L1 >= 3
-        const uint32_t arr_now = local & 7u;
-        if (j > 0) { tle[j - 1] |= arr_prev << 12; }
-        arr_prev = arr_now;
-        if (j == kPosPerLane - 1) tle[j] |= arr_now << 12;
-#elif MCX_RANK_FROM_COUNT
         // The counting atomic returns the tuple's arrival index in its bin: with the bin's offset that
         // IS its sorted position, so the ranking needs no second atomic per tuple.  The result is
         // folded into tle one position later: its LDS round trip overlaps the next position's work.
@@ -642,9 +574,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
         if (j > 0) { tle[j - 1] |= arr_prev << 12; asm volatile("" : "+v"(tle[j - 1])); }
         arr_prev = arr_now;
         if (j == kPosPerLane - 1) tle[j] |= arr_now << 12;
-#else
-        atomicAdd(&L.cnt[local], 1u);
-#endif
         // one position at a time: VALU work gains nothing from interleaving positions, and their
         // temporaries together pushed tuples out to scratch
         if (W == 1) asm volatile("" : "+v"(tle[j]), "+v"(tk[j].w[0]));
@@ -661,29 +590,17 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? MCX_SB_BLOCKS : 3)) void k_stre
     bin_reserve<LDS, NB>(L, bs, out, ob0, res, !FULL);
 #pragma unroll
     for (int j = 0; j < kPosPerLane; j++) {  // sorted position goes into bits 12..24 of tle (FULL: 12..23)
-#if MCX_RANK_FROM_COUNT
       tle[j] += L.off[tle[j] & 0xfffu] << 12;  // arrival index -> sorted position
-#else
-      tle[j] |= bin_rank<LDS>(L, tle[j] & 0xfffu) << 12;
-#endif
       // four returning atomics in flight, then their results are folded into tle (the opaque
       // statement also keeps the compiler from holding on to the bin index for the placement:
       // it spilled sixteen of them)
-#if MCX_RANK_GROUP == 4
       if ((j & 3) == 3) asm volatile("" : "+v"(tle[j - 3]), "+v"(tle[j - 2]), "+v"(tle[j - 1]), "+v"(tle[j]));
-#elif MCX_RANK_GROUP == 8
-      if ((j & 7) == 7) asm volatile("" : "+v"(tle[j - 7]), "+v"(tle[j - 6]), "+v"(tle[j - 5]), "+v"(tle[j - 4]), "+v"(tle[j - 3]), "+v"(tle[j - 2]), "+v"(tle[j - 1]), "+v"(tle[j]));
-#endif
     }
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
     for (int round = 0; round < kRounds; round++) {
-#if MCX_EXP_L1 >= 2
-      if (round == 0) { uint64_t acc = 0; for (int j = 0; j < kPosPerLane; j++) acc ^= tk[j].w[0] + tle[j]; if (acc == 0x123456789ULL) full = 1; }
-#else
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
         bin_place<W, FULL, LDS>(L, round, FULL ? (tle[j] >> 12) & 0xfffu : tle[j] >> 12, tle[j] & 0xfffu, tk[j], tle[j] >> 24);
-#endif
       bin_writeout<W, ONECOL, FULL, SH, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
     }
   }
@@ -757,10 +674,7 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
   // each (64 B) stay resident in that XCD's L2 until the runs have filled whole lines.  Measured
   // (C2, ms per 12 G occurrences, two runs each): 16 regions 51.7; 8: 44.7 / 43.8; 4: 45.6 / 45.4;
   // 2: 42.5 / 41.3; 1: 43.7 / 41.7.
-#ifndef MCX_SPLIT_WIN
-#define MCX_SPLIT_WIN 2
-#endif
-  constexpr uint32_t kWin = MCX_SPLIT_WIN;
+  constexpr uint32_t kWin = 2;
   const uint32_t bins_g = xcd ? bs.seg_mod / 8 : 1;      // regions of this group
   const uint32_t reps = xcd ? in.nseg / bs.seg_mod : 1;  // replicas per region
   const uint32_t win_segs = kWin * reps;
@@ -806,7 +720,7 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
     uint32_t okm = 0;  // tuples of this lane that are binned
     // 16-byte loads when the segments are 16-byte aligned (one-word tuples: a lane takes two
     // neighbours; which lane holds which tuple of the tile is irrelevant to the partition)
-    const bool vec16 = MCX_VEC16 && !IN_FULL && (((uintptr_t)in.keys & 15u) == 0) && (W == 2 || (in.seg_cap & 1u) == 0);
+    const bool vec16 = !IN_FULL && (((uintptr_t)in.keys & 15u) == 0) && (W == 2 || (in.seg_cap & 1u) == 0);
     if (vec16) {
       const ulonglong2 *kin2 = reinterpret_cast<const ulonglong2 *>(kin);
 #pragma unroll
@@ -893,48 +807,19 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
 // The slice is held in LDS as Sub<W>::kSlots x (W key words + this colour's value word); other
 // colours' value words stay untouched in HBM.  find-or-insert / coverage / edges are the same
 // protocol as probe_insert, with LDS atomics.
-// threads of the LDS-insert workgroup: W=2 slices are 96 KiB (one workgroup per CU), so that one is larger
-#ifndef MCX_LDS_THREADS1
-#define MCX_LDS_THREADS1 512
-#endif
-#ifndef MCX_LDS_MINW2
-#define MCX_LDS_MINW2 4      // two-word keys: waves per SIMD the LDS insert is compiled for (its 48 KiB slices leave room for 6)
-#endif
-#ifndef MCX_LDS_PREFETCH2
-#define MCX_LDS_PREFETCH2 1  // two-word keys: the next sub-table's slice is fetched into registers while this one is applied
-#endif
+// Geometry of the LDS-insert workgroup: 512 threads, two workgroups per CU (4 waves per SIMD); the next
+// sub-table's slice is fetched into registers while the current one is applied; every thread keeps two
+// batches of kBatch tuple loads in flight.  (Rejected with measurements, profiles/r03_experiments.md:
+// 1 or 3 workgroups per CU, 3-6 batches in flight, 2 or 8 tuples per batch, 16-byte tuple loads, 4096-slot
+// two-word sub-tables with 1024-thread workgroups, requesting the next sub-table's tuples one sub-table ahead.)
 template <int W> struct LdsCfg {
-  static constexpr int kThreads = W == 1 ? MCX_LDS_THREADS1 : (MCX_SUB2_SHIFT == 12 ? 1024 : 512);
-  static constexpr int kMinWaves = W == 1 ? 4 : MCX_LDS_MINW2;
-  static constexpr bool kPrefetch = W == 1 ? true : (MCX_LDS_PREFETCH2 != 0);
+  static constexpr int kThreads = 512;
+  static constexpr int kMinWaves = 4;
+  static constexpr bool kPrefetch = true;
+  static constexpr int kBatch = 4;
 };
-#ifndef MCX_LDS_BATCH
-#define MCX_LDS_BATCH 4
-#endif
-#ifndef MCX_LDS_BATCH2
-#define MCX_LDS_BATCH2 MCX_LDS_BATCH  // the same for two-word keys (their tuples take twice the registers)
-#endif
-#ifndef MCX_LDS_VEC16
-#define MCX_LDS_VEC16 0  // the same for the tuple loads of the LDS insert
-#endif
-#ifndef MCX_LDS_QUEUE
-#define MCX_LDS_QUEUE 1  // 1: one straight-line probe per occurrence; what it cannot finish is queued in LDS
-#endif
 // tuples of the LDS queue: what is left of a CU's 160 KiB beside two 64 KiB (three 48 KiB) slices
-template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : (MCX_SUB2_SHIFT == 12 ? 2048 : 288); };
-#ifndef MCX_LDS_DEPTH
-#define MCX_LDS_DEPTH 2  // tuple batches in flight per thread in the LDS insert
-#endif
-#ifndef MCX_EXP_INS
-#define MCX_EXP_INS 0  // timing experiments on the LDS insert (results are wrong by construction): 1 no apply, 2 no slice store, 3 neither, 4 probe reads only
-#endif
-#ifndef MCX_LDS_AHEAD
-#define MCX_LDS_AHEAD 0  // 1: the fill of the next sub-table's bin and its first two tuple batches are requested one sub-table ahead
-                         // (round 3: 16.5 vs 16.65 ms at C2, 38.1 vs 37.8 at C4 -- the insert is not waiting for those loads; off)
-#endif
-#ifndef MCX_LDS_PIPE
-#define MCX_LDS_PIPE 1   // 1: the tuple loads of batch i + 1 are in flight while batch i is applied
-#endif
+template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 1856 : 288; };
 
 // LDS image of a sub-table.
 // One-word keys: the keys of all slots first (32 KiB), then the values (32 KiB).  A bucket's four
@@ -946,22 +831,14 @@ template <int W> struct LdsQueue { static constexpr uint32_t kTuples = W == 1 ? 
 // Slots fill in probe order, so at the load factors a graph is built with (<= 0.75) most keys sit in
 // slots 0-1 of their bucket: the second half is only read by the lanes that need it.
 // Two-word keys: slot after slot (key word 0, key word 1, value): four strided 8-byte loads per probe.
-// MCX_LDS_IMG2=1 builds the plane image for them as well -- first key words of all 2048 slots (16 KiB),
-// second key words (16 KiB), values (16 KiB), slots permuted alike, two 16-byte loads per probe and one
-// look at the second word that matters.  Measured at C4 (k = 63, 4.38 G occurrences, round 3,
-// tools/exp_c4c5.py): 39.3 ms against 38.0 for the slot-after-slot image, same graph checksum -- the
-// two-word insert is not bound by its LDS reads (8.4 K tuples per 48 KiB slice: it spends its time on
-// the per-sub-table chain of dependent global loads), so the default stays.
-#ifndef MCX_LDS_IMG2
-#define MCX_LDS_IMG2 0
-#endif
+// (A plane image for two-word keys as well -- first words | second words | values, two 16-byte loads per
+// probe -- measured 39.3 ms against 38.0 at C4 in round 3, profiles/r03_experiments.md: the two-word insert
+// is not bound by its LDS reads.)
 __device__ __forceinline__ uint32_t lds_phys1(uint32_t slot)  // position of logical slot `slot` in a plane
 {
   return slot ^ ((slot >> 4) & 2u);  // bit 1 (which half) ^= bit 5 of the slot (= bit 3 of the bucket)
 }
 constexpr uint32_t kLdsVal1 = 4096;  // word offset of the values in the one-word image
-constexpr uint32_t kLdsK1_2 = 2048;  // two-word image: word offset of the second key words ...
-constexpr uint32_t kLdsVal2 = 4096;  // ... and of the values
 
 // find-or-insert one occurrence in the LDS-resident sub-table.  Half a bucket (one-word keys) or a
 // whole one (two-word keys) is examined per step: the key words are loaded together and compared
@@ -1012,13 +889,8 @@ __device__ __forceinline__ bool lds_apply(unsigned long long *lds, const Kmer<W>
     }
   } else {
     // slot j of bucket b: first key word at sp(j), the second kK1 words further on, the value kV
-#if MCX_LDS_IMG2
-    constexpr uint32_t kK1 = kLdsK1_2, kV = kLdsVal2;
-#define MCX_SP(b_, j_) (lds + lds_phys1((b_) * kBucket + (uint32_t)(j_)))
-#else
     constexpr uint32_t kK1 = 1, kV = W;
 #define MCX_SP(b_, j_) (lds + (size_t)(b_) * (kBucket * (W + 1)) + (j_) * (W + 1))
-#endif
     uint32_t b = bucket;
     for (;;) {
       unsigned long long k[kBucket];
@@ -1079,9 +951,9 @@ __device__ __forceinline__ bool lds_try(unsigned long long *lds, const Kmer<W> &
   const unsigned long long want = key.w[0] | kFlag;
   unsigned long long k[kBucket];
   unsigned long long *kp[kBucket];  // key word 0 of logical slot j; its value is kVal words further on
-  constexpr bool kPlanes = W == 1 || MCX_LDS_IMG2;  // key words and values in planes, buckets half-swizzled
-  constexpr uint32_t kVal = W == 1 ? kLdsVal1 : (MCX_LDS_IMG2 ? kLdsVal2 : (uint32_t)W);
-  constexpr uint32_t kK1 = MCX_LDS_IMG2 ? kLdsK1_2 : 1u;  // second key word of a two-word key
+  constexpr bool kPlanes = W == 1;  // one-word keys: key words and values in planes, buckets half-swizzled
+  constexpr uint32_t kVal = W == 1 ? kLdsVal1 : (uint32_t)W;
+  constexpr uint32_t kK1 = 1u;  // second key word of a two-word key
   if constexpr (kPlanes) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef MCX_LDS_AS const u64x2 lds_c;
@@ -1192,15 +1064,7 @@ __device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, c
     MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5) MCX_ST(g, 6) MCX_ST(h, 7)
 #undef MCX_ST
   } else if (ONECOL) {
-#if MCX_LDS_IMG2
-    // vector i = words 2i, 2i + 1 of the record stream [k0 k1 v][k0 k1 v]...: word w is field w % 3 of
-    // slot w / 3, and field f lives in plane f (first words | second words | values)
-#define MCX_ST(m, q) { const uint32_t w0 = 2u * (uint32_t)(q * T + tid), s0 = w0 / 3u, f0 = w0 - 3u * s0; \
-                       const uint32_t s1 = f0 == 2u ? s0 + 1u : s0, f1 = f0 == 2u ? 0u : f0 + 1u;          \
-                       lds[f0 * kLdsK1_2 + lds_phys1(s0)] = v.m.x; lds[f1 * kLdsK1_2 + lds_phys1(s1)] = v.m.y; }
-#else
 #define MCX_ST(m, q) dst[q * T + tid] = make_ulonglong2(v.m.x, v.m.y);
-#endif
     MCX_ST(a, 0) MCX_ST(b, 1) MCX_ST(c, 2) MCX_ST(d, 3) MCX_ST(e, 4) MCX_ST(f, 5)
 #undef MCX_ST
   } else if (W == 1) {  // slots 2p, 2p + 1 are one half of a bucket: their keys are one vector, their values another
@@ -1208,12 +1072,7 @@ __device__ __forceinline__ void slice_to_lds(unsigned long long *lds, int tid, c
     MCX_PUT1(0, v.a, v.e) MCX_PUT1(1, v.b, v.f) MCX_PUT1(2, v.c, v.g) MCX_PUT1(3, v.d, v.h)
 #undef MCX_PUT1
   } else {              // slots 2p, 2p + 1 = 6 words = vectors 3p .. 3p + 2: k0a k0b | v0 k1a | k1b v1
-#if MCX_LDS_IMG2       // the pair's first words, second words and values: one 16-byte vector per plane
-#define MCX_PUT2(j, k0, k1, vv) { const uint32_t ph = lds_phys1(2u * (uint32_t)(j * T + tid)) >> 1; dst[ph] = make_ulonglong2(k0.x, k1.x); \
-                                  dst[kLdsK1_2 / 2 + ph] = make_ulonglong2(k0.y, k1.y); dst[kLdsVal2 / 2 + ph] = make_ulonglong2(vv.x, vv.y); }
-#else
 #define MCX_PUT2(j, k0, k1, vv) { const int p = j * T + tid; dst[3 * p] = make_ulonglong2(k0.x, k0.y); dst[3 * p + 1] = make_ulonglong2(vv.x, k1.x); dst[3 * p + 2] = make_ulonglong2(k1.y, vv.y); }
-#endif
     MCX_PUT2(0, v.a, v.b, v.c) MCX_PUT2(1, v.d, v.e, v.f)
 #undef MCX_PUT2
   }
@@ -1237,13 +1096,7 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
     constexpr int PER = (int)(Sub<W>::kSlots * (W + 1) * 8 / 16 / T);
 #pragma unroll
     for (int q = 0; q < PER; q++) {
-#if MCX_LDS_IMG2
-      const uint32_t w0 = 2u * (uint32_t)(q * T + tid), sl0 = w0 / 3u, f0 = w0 - 3u * sl0;
-      const uint32_t sl1 = f0 == 2u ? sl0 + 1u : sl0, f1 = f0 == 2u ? 0u : f0 + 1u;
-      dst[q * T + tid] = make_ulonglong2(lds[f0 * kLdsK1_2 + lds_phys1(sl0)], lds[f1 * kLdsK1_2 + lds_phys1(sl1)]);
-#else
       dst[q * T + tid] = src[q * T + tid];
-#endif
     }
   } else if (W == 1) {
     ulonglong2 *K = reinterpret_cast<ulonglong2 *>(t.rec + s0);
@@ -1260,18 +1113,10 @@ __device__ __forceinline__ void slice_store(const TableView &t, uint32_t sub, ui
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int p = j * T + tid;
-#if MCX_LDS_IMG2
-      const uint32_t ph = lds_phys1(2u * (uint32_t)p) >> 1;
-      const ulonglong2 a = src[ph], b = src[kLdsK1_2 / 2 + ph];  // first words, second words of the pair
-      K[2 * p] = make_ulonglong2(a.x, b.x);
-      K[2 * p + 1] = make_ulonglong2(a.y, b.y);
-      V[p] = src[kLdsVal2 / 2 + ph];
-#else
       const ulonglong2 x = src[3 * p], y = src[3 * p + 1], z = src[3 * p + 2];
       K[2 * p] = x;
       K[2 * p + 1] = make_ulonglong2(y.y, z.x);
       V[p] = make_ulonglong2(y.x, z.y);
-#endif
     }
   }
 }
@@ -1281,18 +1126,16 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
                                                                        uint32_t sub0, uint32_t nsub, Counters *ctr)
 {
   constexpr int kLdsThreads = LdsCfg<W>::kThreads;
-  constexpr int kLdsBatch = W == 1 ? MCX_LDS_BATCH : MCX_LDS_BATCH2;
+  constexpr int kLdsBatch = LdsCfg<W>::kBatch;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   unsigned long long *lds = reinterpret_cast<unsigned long long *>(dyn_lds);
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
-#if MCX_LDS_QUEUE
   // occurrences that lds_try could not finish (packed tuples, as they came): behind the slice
   unsigned long long *queue = lds + Sub<W>::kSlots * (W + 1);
   constexpr uint32_t kQueueCap = LdsQueue<W>::kTuples;
   __shared__ uint32_t s_nq;
   if (tid == 0) s_nq = 0;
-#endif
 
   // sub-tables sub0 .. sub0 + nsub - 1; bin i of `bins` belongs to sub-table sub0 + i and is handed
   // back empty (fill reset) for the next group of regions.
@@ -1311,65 +1154,28 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
   const bool zeros_known = t.touch && t.touch[0] == 0;
   constexpr bool kPrefetch = LdsCfg<W>::kPrefetch;
   if (kPrefetch && bi < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + bi, col, tid, v, zeros_known);
-  // tuple j0 + idx(q) is the q-th of this thread's batch; with 16-byte loads (aligned bins) a
-  // one-word thread takes pairs of neighbours
-  const bool vec16 = MCX_LDS_VEC16 && (((uintptr_t)bins.keys & 15u) == 0) && (W == 2 || (bins.cap & 1u) == 0);
-  auto idx = [&](int q) -> uint32_t {
-    return (W == 1 && vec16) ? 2u * ((uint32_t)(q >> 1) * kLdsThreads + tid) + (uint32_t)(q & 1)
-                             : (uint32_t)q * kLdsThreads + tid;
-  };
+  // tuple j0 + idx(q) is the q-th of this thread's batch
+  auto idx = [&](int q) -> uint32_t { return (uint32_t)q * kLdsThreads + tid; };
   // Loads are unconditional (an index past the fill reads tuple 0 of the bin, which is then not
   // applied): without branches between them the compiler can count the loads in flight and wait
   // for exactly the batch it is about to apply (s_waitcnt vmcnt(n)) instead of for all of them.
   auto load_batch_of = [&](uint32_t bin, uint64_t nfill, uint64_t j0, Kmer<W> (&tk)[kLdsBatch]) {
     const uint64_t *kin = bins.keys + (uint64_t)bin * bins.cap * W;
-    if (vec16) {
-      const ulonglong2 *kin2 = reinterpret_cast<const ulonglong2 *>(kin);
 #pragma unroll
-      for (int q = 0; q < kLdsBatch; q += (W == 1 ? 2 : 1)) {
-        uint64_t i = j0 + idx(q);
-        i = i < nfill ? i : 0;  // (the pair's second word may lie past n: inside the bin, never applied)
-        const ulonglong2 x = kin2[W == 1 ? i / 2 : i];
-        tk[q].w[0] = x.x;
-        if (W == 1) tk[q + (W == 1 ? 1 : 0)].w[0] = x.y; else tk[q].w[W - 1] = x.y;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < kLdsBatch; q++) {
-        uint64_t i = j0 + idx(q);
-        i = i < nfill ? i : 0;
-        tk[q].w[0] = kin[i * W];
-        if (W == 2) tk[q].w[W - 1] = kin[i * W + 1];
-      }
+    for (int q = 0; q < kLdsBatch; q++) {
+      uint64_t i = j0 + idx(q);
+      i = i < nfill ? i : 0;
+      tk[q].w[0] = kin[i * W];
+      if (W == 2) tk[q].w[W - 1] = kin[i * W + 1];
     }
   };
   constexpr uint64_t kStep = (uint64_t)kLdsThreads * kLdsBatch;
-#if MCX_LDS_AHEAD && MCX_LDS_PIPE
-  // One sub-table ahead.  Under load a global load takes several microseconds (what is in flight
-  // divided by the bandwidth), and an iteration used to pay that twice in a row before its first tuple
-  // was applied: the fill of the next bin (the loop in next_bin waits for it), then the first two
-  // batches.  Now the fill of the candidate bi + gridDim.x is requested at the top of an iteration and
-  // looked at only at its end, and the first two batches of the next sub-table are requested before
-  // this one's queue is drained and its slice stored.  (A candidate that turns out empty -- rare in a
-  // build, the rule in a sparse --graph load -- costs the old sequence.)
-  Kmer<W> ta[kLdsBatch], tb[kLdsBatch];
-  uint64_t n_cur = bi < nsub ? (uint64_t)bins.counts[bi] : 0;
-  if (n_cur > bins.cap) n_cur = bins.cap;
-  if (bi < nsub) { load_batch_of(bi, n_cur, 0, ta); load_batch_of(bi, n_cur, kStep, tb); }
-#endif
   while (bi < nsub) {
     const uint32_t sub = sub0 + bi;
     const uint32_t region = sub / t.spb;  // uniform
-#if MCX_LDS_AHEAD && MCX_LDS_PIPE
-    const uint64_t n = n_cur;
-    const uint32_t nb_c = bi + gridDim.x;  // the candidate; its fill is not waited for here
-    uint64_t n_next = nb_c < nsub ? (uint64_t)bins.counts[nb_c] : 0;
-    uint32_t nb = nb_c;
-#else
     uint64_t n = bins.counts[bi];
     if (n > bins.cap) n = bins.cap;
     const uint32_t nb = next_bin(bi + gridDim.x);
-#endif
     __syncthreads();  // every thread has read the fills; the previous slice has left LDS
     if (tid == 0) bins.counts[bi] = 0;
     if (!kPrefetch) slice_fetch<W, ONECOL, kLdsThreads>(t, sub, col, tid, v, zeros_known);
@@ -1396,16 +1202,6 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
           Kmer<W> key;
           uint32_t bucket, e;
           unpack(tk[q], key, bucket, e);
-#if MCX_EXP_INS == 1 || MCX_EXP_INS == 3   // timing experiment: tuples are loaded and unpacked, not applied
-          if (key.w[0] == 0x123456789ULL && bucket == 77u && e == 5u) full = 1;
-          continue;
-#elif MCX_EXP_INS == 4                     // ... applied, but only the probe's reads (no atomics)
-          { typedef unsigned long long u64x2_ __attribute__((ext_vector_type(2)));
-            const u64x2_ a_ = *(MCX_LDS_AS const u64x2_ *)(lds + bucket * kBucket), b_ = *(MCX_LDS_AS const u64x2_ *)(lds + bucket * kBucket + 2);
-            if ((a_.x ^ a_.y ^ b_.x ^ b_.y) == (key.w[0] | kFlag) + 12345u) full = 1; }
-          continue;
-#endif
-#if MCX_LDS_QUEUE
           if (!lds_try<W>(lds, key, bucket, e, n_novel)) {
             const uint32_t qi = atomicAdd(&s_nq, 1u);
             if (qi < kQueueCap) {
@@ -1415,39 +1211,12 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
               apply_slow(key, bucket, e);
             }
           }
-#else
-          apply_slow(key, bucket, e);
-#endif
         }
     };
-#if MCX_LDS_AHEAD && MCX_LDS_PIPE
-    {
-      // (this sub-table's first two batches are on their way since the end of the previous iteration)
-      const bool cand = nb_c < nsub;  // uniform
-      if (kPrefetch && cand) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb_c, col, tid, v, zeros_known);
-      for (uint64_t j0 = 0; j0 < n; j0 += 2 * kStep) {
-        apply_batch(j0, ta);
-        load_batch(j0 + 2 * kStep, ta);
-        apply_batch(j0 + kStep, tb);
-        load_batch(j0 + 3 * kStep, tb);
-      }
-      // the next sub-table: the candidate unless its bin is empty
-      if (n_next > bins.cap) n_next = bins.cap;
-      if (cand && n_next == 0) {
-        nb = next_bin(nb_c + gridDim.x);
-        n_next = nb < nsub ? (uint64_t)bins.counts[nb] : 0;
-        if (n_next > bins.cap) n_next = bins.cap;
-        if (kPrefetch && nb < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v, zeros_known);
-      }
-      if (nb < nsub) { load_batch_of(nb, n_next, 0, ta); load_batch_of(nb, n_next, kStep, tb); }
-      n_cur = n_next;
-    }
-#elif MCX_LDS_PIPE
     // Two batches in flight: while one is applied (LDS only) the loads of the next are on their way.
     // The next slice is requested after the first two batches (loads return in order, so those do
     // not queue behind its 64 KiB).  Both variants of "is there a next slice" are straight-line code.
     auto run = [&](auto has_next) {
-#if MCX_LDS_DEPTH == 2
       Kmer<W> ta[kLdsBatch], tb[kLdsBatch];
       load_batch(0, ta);
       load_batch(kStep, tb);
@@ -1458,38 +1227,9 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
         apply_batch(j0 + kStep, tb);
         load_batch(j0 + 3 * kStep, tb);
       }
-#else   // MCX_LDS_DEPTH batches in flight (experiment: more bytes on their way while a batch is applied)
-      constexpr int D = MCX_LDS_DEPTH;
-      Kmer<W> tq[D][kLdsBatch];
-#pragma unroll
-      for (int d = 0; d < D; d++) load_batch((uint64_t)d * kStep, tq[d]);
-      if (decltype(has_next)::value) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v, zeros_known);
-      for (uint64_t j0 = 0; j0 < n; j0 += D * kStep) {
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-          apply_batch(j0 + (uint64_t)d * kStep, tq[d]);
-          load_batch(j0 + (uint64_t)(D + d) * kStep, tq[d]);
-        }
-      }
-#endif
     };
     if (kPrefetch && nb < nsub) run(std::true_type{}); else run(std::false_type{});
-#else
-    {  // first batch of tuple loads, THEN the next slice: loads return in order, so the first
-       // batch does not wait for the 64 KiB behind it
-      Kmer<W> tk[kLdsBatch];
-      load_batch(0, tk);
-      if (nb < nsub) slice_fetch<W, ONECOL, kLdsThreads>(t, sub0 + nb, col, tid, v, zeros_known);
-      apply_batch(0, tk);
-    }
-    for (uint64_t j0 = kStep; j0 < n; j0 += kStep) {
-      Kmer<W> tk[kLdsBatch];
-      load_batch(j0, tk);
-      apply_batch(j0, tk);
-    }
-#endif
     __syncthreads();
-#if MCX_LDS_QUEUE
     {  // the occurrences set aside: every lane takes one, all of them run the general probe loop
       const uint32_t nq = min(s_nq, kQueueCap);
       for (uint32_t i = tid; i < nq; i += kLdsThreads) {
@@ -1503,12 +1243,7 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
       __syncthreads();
       if (tid == 0) s_nq = 0;
     }
-#endif
-#if MCX_EXP_INS == 2 || MCX_EXP_INS == 3     // timing experiment: the slice is not written back
-    if (lds[tid] == 0x123456789ULL) full = 1;
-#else
     slice_store<W, ONECOL, kLdsThreads>(t, sub, col, tid, lds);
-#endif
     if (tid == 0 && t.touch) atomicOr(&t.touch[1 + (sub >> 5)], 1u << (sub & 31u));
     bi = nb;
   }

@@ -31,15 +31,12 @@ constexpr int kBucket = 4;  // slots per hash bucket (64 B when S == 2)
 // single workgroup (mcx_defer.h).  One-word keys: 4096 slots (64 KiB of key + value words, two
 // workgroups per CU); two-word keys: 2048 slots (48 KiB, so that two or three workgroups share a
 // CU instead of one 96 KiB slice monopolising it).
-#ifndef MCX_SUB2_SHIFT
-#define MCX_SUB2_SHIFT 11  // log2 slots of a two-word sub-table (12: 96 KiB slices, one 1024-thread workgroup per CU -- experiment)
-#endif
 template <int W> struct Sub {
-  static constexpr int kShift = W == 1 ? 12 : MCX_SUB2_SHIFT;
+  static constexpr int kShift = W == 1 ? 12 : 11;
   static constexpr uint64_t kSlots = 1ull << kShift;
   static constexpr uint32_t kBuckets = (uint32_t)(kSlots / kBucket);
 };
-__host__ __device__ constexpr int sub_shift_for_words(int W) { return W == 1 ? 12 : MCX_SUB2_SHIFT; }
+__host__ __device__ constexpr int sub_shift_for_words(int W) { return W == 1 ? 12 : 11; }
 
 struct TableView {
   uint64_t *rec;
@@ -599,13 +596,7 @@ constexpr int kThreads = 256;
 constexpr int kPosPerLane = 16;
 constexpr int kTile = kThreads * kPosPerLane;  // k-mer start positions per tile
 constexpr int kChunks = 272;                   // 16-byte chunks staged per tile: 1 halo + 256 + 15
-#ifndef MCX_BATCH
-#define MCX_BATCH 4
-#endif
-#ifndef MCX_MIN_WAVES
-#define MCX_MIN_WAVES 1
-#endif
-constexpr int kBatch = MCX_BATCH;              // probes in flight per lane (must divide 16)
+constexpr int kBatch = 4;              // probes in flight per lane (must divide 16)
 
 struct StreamArgs {
   const uint8_t *stream;    // ASCII stream, or nullptr when the packed form below is given
@@ -769,7 +760,7 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t h2, uint32_t nparts)
 // Fused build kernel: k-merise a stream tile by tile and insert straight into the table
 // (direct path; the deferred path of mcx_defer.h shares the front end helpers).
 template <int W, bool ONECOL, bool PK>
-__global__ __launch_bounds__(kThreads, MCX_MIN_WAVES) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink)
+__global__ __launch_bounds__(kThreads, 1) void k_stream(StreamArgs a, InsertSink<W, ONECOL> isink)
 {
   if (blockIdx.x == 0 && threadIdx.x == 0) table_mark_written(isink.t);
   __shared__ uint32_t s_code[kChunks + 4];
