@@ -10,7 +10,11 @@ see `host_fed` and `e2e`); 10 steps are the 50M x 150bp set.  The same run also 
 JSON line: `host_fed` (the same reads handed over in host memory: staging + PCIe inside the clock),
 `e2e` (`mccortex31 build --sort` on a FASTQ file of the same shape: process start, parse, build, sort,
 .ctx write), `default_defer` (the library's own flush size instead of the bench's), `other_configs`
-(C4: k=63; C5-like: 4 colours) and `cpu_baseline` (the oracle on the host cores).
+(C4: k=63; C5-like: 4 colours; C2-stress: iid reads; `hashtest`: the reference's own published table benchmark),
+`e2e_full` (the CLI on the whole 50M x 150bp FASTQ) and `cpu_baseline` (the oracle on the host cores, on the SAME
+reads and the same `-n 1G` table; its records' checksum must equal the GPU graph's: `config.checksum_matches_oracle`).
+`roofline` carries the device's MEASURED ceilings (streaming copy, random 64-byte-sector RMW over a table-sized
+working set: mcx_ubench_*) next to the nominal 8 TB/s, and per-kernel durations from a second, non-overlapped pass.
 
 N>1 (one process per GPU, torchrun).  Default `--scaling strong` = BASELINE config C3: the SAME reads
 as N=1 (step i is the same 5M-read batch, every rank takes reads [r B/N, (r+1) B/N) of it), the same
@@ -107,6 +111,8 @@ def csrc_digest():
     h = hashlib.sha1()
     d = os.path.join(ROOT, "mccortex_amd", "csrc")
     for n in sorted(os.listdir(d)):
+        if not n.endswith((".h", ".hip")):
+            continue
         h.update(n.encode())
         h.update(open(os.path.join(d, n), "rb").read())
     return h.hexdigest()[:16]
@@ -143,13 +149,44 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(stream_dev, fastq_sample=None):
-    """The CPU oracle (port of the reference algorithm: bucket-locked table, pthreads) on the host's
-    cores, bounded samples of the same reads.  Insert phase from memory at -t {1, 8, 32, nproc} on
-    500k reads per point (the arrays are prefaulted by the same number of threads first, see
-    orc_graph_tune: first-touch faults made the short samples of round 1 scale negatively), and the
-    reference-shaped end-to-end run -- ONE reader thread parsing the FASTQ file into a 2048-slot pool,
-    -t workers (src/basic/async_read_io.c:145-175,283-310) -- on a 500k-read file."""
+def oracle_full_size(batches_dev, nsteps, table_slots, nthreads):
+    """The oracle on the SAME reads and the same `-n` as the GPU build: the first `nsteps`
+    steps of the workload into a table of `table_slots` slots (2^30: 14 GB of keys, coverages, edges, bucket
+    bytes), timed; then the order-independent checksum of its records (mcx_records_checksum over the unsorted
+    .ctx body the oracle writes) for comparison with the GPU graph of the same steps."""
+    from oracle import orc
+    import mccortex_amd as mcx
+    g = orc.Graph(K, 1, table_slots)
+    g.tune(nthreads)  # prefault with the worker threads, huge pages, per-worker node tallies (outside the clock, like calloc + first touch)
+    kmers, dt = 0, 0.0
+    for b in batches_dev[:nsteps]:
+        n = b.numel() // (READ_LEN + 1)
+        host = b.reshape(n, READ_LEN + 1)[:, :READ_LEN].contiguous().cpu().numpy().reshape(-1)
+        offs = np.arange(n + 1, dtype=np.uint64) * READ_LEN
+        t0 = time.perf_counter()
+        st = g.add_reads(0, host, offs, nthreads=nthreads)
+        dt += time.perf_counter() - t0
+        kmers += st.num_kmers_loaded
+        del host
+    t0 = time.perf_counter()
+    body = g.body_array(False)
+    cs = mcx.records_checksum(body, K, 1)
+    t_cs = time.perf_counter() - t0
+    nodes = g.nkmers
+    del body, g
+    return {"kmers_per_s": kmers / dt, "seconds": dt, "kmers": int(kmers), "nodes": int(nodes), "checksum": "%016x" % cs,
+            "threads": nthreads, "steps": nsteps, "table_slots": table_slots, "dump_and_checksum_s": round(t_cs, 2)}
+
+
+def cpu_baseline(stream_dev, fastq_sample=None, batches_dev=None, oracle_steps=0, table_slots=TABLE_SLOTS):
+    """The CPU oracle (port of the reference algorithm: bucket-locked table, pthreads) on the host's cores.
+    (a) thread scan: insert phase from memory at -t {1, 8, 32, nproc} on 500k reads per point (the arrays are
+    prefaulted by the same number of threads first, see orc_graph_tune: first-touch faults made the short
+    samples of round 1 scale negatively); (b) `value`: the best thread count on the first `oracle_steps` steps of
+    the SAME workload into the SAME `-n 1G` table as the GPU build (oracle_full_size; BASELINE.md section 3: "same
+    input files and -n"), whose records' checksum bench.py compares with the GPU graph of those steps; (c) the
+    reference-shaped end-to-end run -- ONE reader thread parsing the FASTQ file into a 2048-slot pool, -t
+    workers (src/basic/async_read_io.c:145-175,283-310) -- on a 500k-read file."""
     from oracle import orc
     ncores = os.cpu_count() or 1
     nsample = 500_000
@@ -176,6 +213,18 @@ def cpu_baseline(stream_dev, fastq_sample=None):
                      "bucket-locked table build from memory, arrays prefaulted; value = best thread count" % (nsample, kmers),
            "host_cpus": ncores, "cpu_model": cpu_model(),
            "threads_kmers_per_s": {str(k): round(v) for k, v in sorted(scan.items())}}
+    if oracle_steps and batches_dev is not None:
+        try:
+            full = oracle_full_size(batches_dev, oracle_steps, table_slots, best)
+            out["thread_scan_value"] = out["value"]
+            out["value"] = full["kmers_per_s"]
+            out["sample"] = ("the first %d step(s) of the SAME workload (%d reads x %d bp each, %d k-mer occurrences) into the SAME table size as the GPU "
+                             "build (-n %d slots), oracle/mcx_oracle.c bucket-locked table build from memory at the best thread count of the scan "
+                             "(threads_kmers_per_s: 500k reads per point into a small table), arrays prefaulted"
+                             % (oracle_steps, batches_dev[0].numel() // (READ_LEN + 1), READ_LEN, full["kmers"], table_slots))
+            out["full_size"] = full
+        except Exception as e:  # (host memory: the table needs 14 GB)
+            out["full_size"] = {"error": str(e)[:300]}
     if fastq_sample:
         e2e = {}
         for nt in sorted({t for t in (best,) if t <= ncores}):
@@ -221,12 +270,14 @@ def kernel_table(prof, kmers, W=1, bases_per_kmer=1.25):
     return out
 
 
-def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packed=None):
+def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packed=None, cfg=None, checksum=False):
     """one device-resident build of `batches` (fresh graph; `packed`: their packed form) -> record"""
     import torch
     g = mcx.Graph(k, ncols, table_slots)
     if defer_tuples:
         g.configure("defer_tuples", defer_tuples)
+    for key, v in (cfg or {}).items():
+        g.configure(key, v)
     g.add_stream_dev(0, batches[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
     g.sync(); g.reset(); g.sync()
     g.configure("profile", 1)
@@ -242,17 +293,115 @@ def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packe
     dt = time.perf_counter() - t0
     st = g.device_stats()
     prof = g.profile()
+    cs = g.checksum() if checksum else None
     g.close()
     torch.cuda.empty_cache()
     W = (2 * k + 63) // 64
     kt = kernel_table(prof, st.num_kmers_loaded, W, (0.375 if packed is not None else 1.0) * (READ_LEN + 1) / (READ_LEN - k + 1.0))
     dom = max(kt, key=lambda n: kt[n]["total_ms"])
-    return {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(batches), "steps": len(batches),
-            "kmers_inserted": int(st.num_kmers_loaded), "distinct_kmers": int(st.num_kmers_novel),
-            "dominant_kernel": dom, "dominant_frac": kt[dom]["frac"], "kernels": kt}
+    alg = (ALG_BYTES_PER_KMER if W == 1 else 29.70) * st.num_kmers_loaded + 8.0 * W * st.num_kmers_novel
+    out = {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(batches), "steps": len(batches),
+           "kmers_inserted": int(st.num_kmers_loaded), "distinct_kmers": int(st.num_kmers_novel),
+           "roofline_frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+           "dominant_kernel": dom, "dominant_frac": kt[dom]["frac"], "kernels": kt,
+           "kernels_note": "HIP-event spans on the handle's streams; with the flush overlap on (default) the spans of k_tuples_bin and "
+                           "k_lds_insert include each other's interference (isolated durations: roofline.kernels of the headline)"}
+    if cs is not None:
+        out["graph_checksum"], out["nodes"] = "%016x" % cs[0], int(cs[1])
+    return out
 
 
-def extras(mcx, batches, packed, nsteps, table_slots):
+def ceilings(mcx, table_bytes):
+    """the streaming and the random-RMW ceiling of THIS device, measured in this run (mcx_ubench_*)"""
+    out = {}
+    try:
+        st = mcx.ubench_stream(8 << 30)
+        out.update(measured_copy_gbs=round(st["copy"], 1), measured_read_gbs=round(st["read"], 1), measured_write_gbs=round(st["write"], 1))
+        rw = mcx.ubench_random_rmw(table_bytes, 1 << 29)
+        out.update(measured_random_rmw_per_s=round(rw["rmw"]), measured_random_load16_per_s=round(rw["load16"]),
+                   measured_random_load_rmw_per_s=round(rw["load_rmw"]), random_working_set_bytes=int(table_bytes))
+    except Exception as e:
+        out["ceilings_error"] = str(e)[:200]
+    return out
+
+
+def hashtest(mcx, device, table_slots, nkeys=800_000_000):
+    """The reference's own published benchmark: `mccortex31 hashtest -k 31 -n 1G 800000000`
+    = hash_table_find_or_insert of the integer keys 0 .. N-1 (BinaryKmer b[0] = i; src/commands/ctx_exp_hashtest.c:40-69)
+    into 1,073,741,824 slots (results/hash_table_benchmark/benchmark-tables.sh:53): 136.2 s = 5.9 M inserts/s on
+    the reference's 2015 Xeon box (results20150409thurs.linux.txt:10; whole process, table calloc included).
+    Here: the same keys, resident in HBM, through mcx_graph_insert_tuples_dev (full keys + an empty edge byte ->
+    region bins -> split -> LDS insert; every insert also counts coverage, which the reference's loop does not)."""
+    import torch
+    keys = torch.arange(nkeys, dtype=torch.int64, device=device)
+    edges = torch.zeros(nkeys, dtype=torch.uint8, device=device)
+    g = mcx.Graph(K, 1, table_slots)
+    g.insert_tuples_dev(0, keys[:65536], edges[:65536], 65536)
+    g.sync(); g.reset(); g.sync()
+    g.configure("profile", 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    chunk = 100_000_000
+    for lo in range(0, nkeys, chunk):
+        n = min(chunk, nkeys - lo)
+        g.insert_tuples_dev(0, keys[lo:lo + n], edges[lo:lo + n], n)
+    g.sync()
+    dt = time.perf_counter() - t0
+    nk = g.nkmers
+    prof = g.profile()
+    nkc, sc = g.kmer_covg()
+    g.close()
+    del keys, edges
+    torch.cuda.empty_cache()
+    alg = 24.0 * nkeys  # key in (8) + key slot read (8) + key write (8): every key is new
+    return {"value": nkeys / dt, "unit": "inserts/s", "seconds": dt, "keys": nkeys, "table_slots": table_slots,
+            "distinct_keys_in_table": int(nk), "all_inserted_once": bool(nk == nkeys and int(sc[0]) == nkeys),
+            "roofline_frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_per_insert": 24.0,
+            "reference_published": {"seconds": 136.2, "inserts_per_s": 5.9e6, "threads": "-t 0 (single-thread code; its -t 1/2/4 runs are slower: 216 / 325 / 404 s)",
+                                    "hardware": "8x 8-core Xeon 2.70 GHz, 2015 (other hardware: not a same-run comparison)",
+                                    "source": "results/hash_table_benchmark/results20150409thurs.linux.txt:10"},
+            "vs_reference_published": nkeys / dt / 5.9e6,
+            "kernels": {n: {"launches": c, "total_ms": round(t, 3)} for n, (c, t) in prof.items()},
+            "what": "mccortex31 hashtest -k 31 -n 1G 800000000: integer keys 0..N-1, device-resident, mcx_graph_insert_tuples_dev in chunks of 100 M + sync"}
+
+
+def c2_stress(mcx, device, nsteps, batch_reads, slots=1 << 33):
+    """50 M x 150 bp iid random reads (every k-mer novel: insert-bound worst case), a table of
+    2^33 slots (128 GiB of records) so that the 6 G distinct k-mers fit at load 0.7; one flush."""
+    import torch
+    steps = [make_batch_iid(batch_reads, seed=7000 + i, device=device) for i in range(nsteps)]
+    try:
+        r = run_config(mcx, steps, K, 1, [0] * nsteps, slots, int(nsteps * batch_reads * (READ_LEN - K + 1) * 1.02) + (1 << 24))
+    finally:
+        del steps
+        torch.cuda.empty_cache()
+    r["workload"] = ("C2-stress: k=31, 1 colour, %d iid random reads x %d bp per step (every k-mer novel), table %d slots (%d GiB), 1 GPU, one flush"
+                     % (batch_reads, READ_LEN, slots, slots * 16 >> 30))
+    return r
+
+
+def write_fastq(path, batches, sample_path=None, sample_reads=500_000):
+    """device-resident read batches -> a 4-line FASTQ file (constant quality 'I')"""
+    import torch
+    B = batches[0].numel() // (READ_LEN + 1)
+    hdr = torch.tensor(list(b"@r\n"), dtype=torch.uint8, device=batches[0].device)
+    mid = torch.tensor(list(b"+\n"), dtype=torch.uint8, device=batches[0].device)
+    with open(path, "wb") as f:
+        for i, b in enumerate(batches):
+            rec = torch.empty((B, 3 + (READ_LEN + 1) + 2 + (READ_LEN + 1)), dtype=torch.uint8, device=b.device)
+            rec[:, :3] = hdr
+            rec[:, 3:3 + READ_LEN + 1] = b.reshape(B, READ_LEN + 1)
+            rec[:, 3 + READ_LEN + 1:3 + READ_LEN + 3] = mid
+            rec[:, 3 + READ_LEN + 3:-1] = ord("I")
+            rec[:, -1] = ord("\n")
+            a = rec.cpu().numpy()
+            a.tofile(f)
+            if i == 0 and sample_path:
+                a[:sample_reads].tofile(sample_path)
+            del rec, a
+
+
+def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=True):
     """host-fed, end-to-end, default flush size and the other BASELINE configs (rank 0, N = 1)"""
     import subprocess
     import tempfile
@@ -261,6 +410,15 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     B = batches[0].numel() // (READ_LEN + 1)
     steps = batches[:nsteps]
     pk = packed[:nsteps] if packed is not None else None
+    device = batches[0].device
+    # the GPU graphs the oracle leg (cpu_baseline.full_size) and the full-size CLI run (e2e_full) are compared with
+    if oracle_steps:
+        r = run_config(mcx, batches[:oracle_steps], K, 1, [0] * oracle_steps, table_slots, DEFER_TUPLES, None, checksum=True)
+        out["_gpu_oracle_steps"] = {"steps": oracle_steps, "graph_checksum": r["graph_checksum"], "nodes": r["nodes"], "kmers": r["kmers_inserted"]}
+    n_c2 = 50_000_000 // B if B and 50_000_000 % B == 0 else 0  # steps of the whole 50 M-read set
+    if full_e2e and n_c2 and nsteps >= n_c2:
+        r = run_config(mcx, batches[:n_c2], K, 1, [0] * n_c2, table_slots, DEFER_TUPLES, None, checksum=True)
+        out["_gpu_c2"] = {"steps": n_c2, "graph_checksum": r["graph_checksum"], "nodes": r["nodes"], "kmers": r["kmers_inserted"]}
     # (d) the library's own flush size (64 occurrences per slot within 30 % of the free HBM) instead of the bench's
     r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, 0, pk)
     r["what"] = "as `value`, but with the library's default flush size instead of %d occurrences" % DEFER_TUPLES
@@ -291,6 +449,14 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     r = run_config(mcx, steps, K, 4, cols, table_slots, c5_defer, pk)
     r["workload"] = "C5-like, colours interleaved: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
     out["other_configs"]["C5_like_interleaved_colours_1gpu"] = r
+    # the reference's own published table benchmark, and the insert-bound worst case of SURVEY 8(d)
+    for name, fn in (("hashtest", lambda: hashtest(mcx, device, table_slots)),
+                     ("C2_stress", lambda: c2_stress(mcx, device, min(10, nsteps), B))):
+        try:
+            out["other_configs"][name] = fn()
+        except Exception as e:
+            out["other_configs"][name] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
     # (f) the multi-GPU table of the C ABI (mcx_graph_create_multi) with BOTH shards on this one GPU:
     # sender kernel -> peer copy (device-local here) -> owner split -> LDS insert; a check of the
     # code path and of its overheads, not a scaling figure
@@ -350,21 +516,7 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     fq, fq_small, ctx = os.path.join(tmp, "reads.fq"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "out.ctx")
     try:
         ne = min(2, len(steps))
-        hdr = torch.tensor(list(b"@r\n"), dtype=torch.uint8, device=steps[0].device)
-        mid = torch.tensor(list(b"+\n"), dtype=torch.uint8, device=steps[0].device)
-        with open(fq, "wb") as f:
-            for i, b in enumerate(steps[:ne]):
-                rec = torch.empty((B, 3 + (READ_LEN + 1) + 2 + (READ_LEN + 1)), dtype=torch.uint8, device=b.device)
-                rec[:, :3] = hdr
-                rec[:, 3:3 + READ_LEN + 1] = b.reshape(B, READ_LEN + 1)
-                rec[:, 3 + READ_LEN + 1:3 + READ_LEN + 3] = mid
-                rec[:, 3 + READ_LEN + 3:-1] = ord("I")
-                rec[:, -1] = ord("\n")
-                a = rec.cpu().numpy()
-                a.tofile(f)
-                if i == 0:
-                    a[:500_000].tofile(fq_small)
-                del rec, a
+        write_fastq(fq, steps[:ne], fq_small)
         nthreads = min(32, os.cpu_count() or 1)
         cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-m", "%dG" % (table_slots * 21 // (1 << 30) + 2), "-t", str(nthreads),
                "--sort", "--sample", "bench", "--seq", fq, ctx]
@@ -403,6 +555,50 @@ def extras(mcx, batches, packed, nsteps, table_slots):
     except Exception as e:  # the extras must never cost the headline its line
         out["e2e"] = {"error": str(e)[:300]}
         out["_tmpdir"] = tmp
+    # (c') BASELINE config 2 end to end at its full size: the CLI on the whole 50 M x 150 bp FASTQ (15 GB), once;
+    # the body of the .ctx it writes must have the checksum of the device-resident build of the same reads
+    if "_gpu_c2" in out:
+        try:
+            import shutil
+            n_c2 = out["_gpu_c2"]["steps"]
+            need = n_c2 * B * (2 * READ_LEN + 7) + 13 * out["_gpu_c2"]["nodes"] + (2 << 30)
+            if shutil.disk_usage(tmp).free < need:
+                raise RuntimeError("not enough scratch space in %s for a %d GB FASTQ + .ctx" % (tmp, need >> 30))
+            for f_ in (fq, ctx):
+                if os.path.exists(f_):
+                    os.unlink(f_)
+            t0 = time.perf_counter()
+            write_fastq(fq, batches[:n_c2])
+            t_write = time.perf_counter() - t0
+            nthreads = min(32, os.cpu_count() or 1)
+            cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-m", "%dG" % (table_slots * 21 // (1 << 30) + 2), "-t", str(nthreads),
+                   "--sort", "--sample", "bench", "--seq", fq, ctx]
+            time.sleep(2.0)
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MCX_TIMING="1"))
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                raise RuntimeError("mccortex31 build failed: " + p.stderr.decode(errors="replace")[-400:])
+            stages = [ln.strip() for ln in p.stderr.decode(errors="replace").splitlines() if ln.startswith("[timing]") and "epoch_" not in ln]
+            fq_bytes, ctx_bytes = os.path.getsize(fq), os.path.getsize(ctx)
+            os.unlink(fq)
+            hdr = 6 + 16 + 4 + 8 + (4 + len("bench")) + 16 + (12 + 4 + 9) + 6   # .ctx v6 header, one colour named "bench"
+            body = np.fromfile(ctx, dtype=np.uint8, offset=hdr)
+            assert body.size % 13 == 0, "unexpected .ctx size"
+            cs = mcx.records_checksum(body, K, 1)
+            nrec = body.size // 13
+            del body
+            os.unlink(ctx)
+            kmers = out["_gpu_c2"]["kmers"]
+            out["e2e_full"] = {"value": kmers / dt, "unit": "k-mers/s", "seconds": dt, "reads": n_c2 * B, "kmers": kmers, "fastq_bytes": fq_bytes, "ctx_bytes": ctx_bytes,
+                               "ctx_records": int(nrec), "ctx_body_checksum": "%016x" % cs,
+                               "checksum_matches_device_resident_build": ("%016x" % cs) == out["_gpu_c2"]["graph_checksum"] and nrec == out["_gpu_c2"]["nodes"],
+                               "command": "mccortex31 build -k %d -n %d -m %dG -t %d --sort --seq <%d-read FASTQ> out.ctx" % (K, table_slots, table_slots * 21 // (1 << 30) + 2, nthreads, n_c2 * B),
+                               "what": "BASELINE config 2 end to end at full size, ONE run: process start, HIP init, parse of the %.1f GB FASTQ (page cache), build, device sort, "
+                                       ".ctx write; the written body's order-independent checksum against the device-resident build of the same %d steps" % (fq_bytes / 1e9, n_c2),
+                               "fastq_write_s_outside_clock": round(t_write, 1), "stages": stages[-14:]}
+        except Exception as e:
+            out["e2e_full"] = {"error": str(e)[:300]}
     return out
 
 
@@ -414,6 +610,10 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the device-resident figure (profiling passes)")
+    ap.add_argument("--oracle-steps", type=int, default=2,
+                    help="steps of the workload the CPU oracle builds into the same -n table (timed = cpu_baseline.value; its records' checksum "
+                         "is compared with the GPU graph of the same steps).  About 20 s of 32 host threads per step; 10 = the whole 50M-read set")
+    ap.add_argument("--no-full-e2e", action="store_true", help="skip e2e_full (the CLI on the whole 50M-read FASTQ: a 15 GB scratch file)")
     ap.add_argument("--input", choices=("packed", "ascii"), default="ascii",
                     help="form of the resident stream: ASCII (default: the 2-bit packing is inside the clock), or the packed "
                          "form the host entry stages (2-bit codes + invalid flags; reported as packed_resident by default)")
@@ -488,6 +688,8 @@ def main():
     # k allows it, else v2 (packed tuples, table sharded by quotient-hash prefix); MCX_EXCHANGE=v2 forces v2
     slots_per_gpu = max(1 << 20, args.table_slots // world) if strong else args.table_slots
     use_v3 = sharded and mcx.superk_supported(K) and os.environ.get("MCX_EXCHANGE", "v3") != "v2"
+    # the device's streaming and random-RMW ceilings, measured in this run (rank 0, N = 1)
+    ceil = ceilings(mcx, slots_per_gpu * 16) if (rank == 0 and not sharded) else {}
     if use_v3:
         graph = mcx.Graph(K, 1, slots_per_gpu, device=local_rank)
     else:
@@ -567,6 +769,27 @@ def main():
     kmers_local = st.num_kmers_loaded  # k-mer occurrences this rank k-merised (== inserted job-wide)
     prof = graph.profile()  # {kernel: (launches, total ms)} of the timed region, measured live with HIP events
     cs_local, nodes_local = graph.checksum()   # order-independent checksum of this rank's k-mers
+    # Per-kernel durations that mean something: with the flush overlap on (the default, and what `value` is
+    # measured with) the insert of one region group runs beside the split of the next, and the HIP-event spans
+    # of the two kernels contain each other.  A second pass over the same steps with the overlap off gives
+    # isolated durations (one kernel at a time on one stream); roofline.kernels / roofline.dominant use those.
+    prof_iso, gpu_ms_iso = None, None
+    if not sharded and not args.direct:
+        graph.reset()
+        graph.configure("flush_overlap", 0)
+        fence()
+        graph.configure("profile", 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(ext)
+        run_steps(range(nsteps))
+        fence()
+        e1.record(ext)
+        torch.cuda.synchronize()
+        prof_iso, gpu_ms_iso = graph.profile(), e0.elapsed_time(e1)
+        cs_iso, nodes_iso = graph.checksum()
+        if (cs_iso, nodes_iso) != (cs_local, nodes_local):
+            raise SystemExit("bench: the non-overlapped pass built another graph (%016x / %d against %016x / %d)" % (cs_iso, nodes_iso, cs_local, nodes_local))
+        graph.configure("flush_overlap", 1)
     ident = torch.tensor([cs_local & 0xFFFFFFFF, cs_local >> 32, nodes_local], dtype=torch.int64, device=device)
     if world > 1:
         dist.all_reduce(ident, op=dist.ReduceOp.SUM)   # 32-bit halves: the sums cannot overflow
@@ -618,8 +841,9 @@ def main():
                 and READ_LEN == 150 and nsteps in N1_CHECKSUMS:
             out["config"]["checksum_matches_n1"] = ("%016x" % cs_total) == N1_CHECKSUMS[nsteps]
         gpu_ms = ev0.elapsed_time(ev1)
-        dom = max(prof, key=lambda n: prof[n][1])
-        calls, tot_ms = prof[dom]
+        kprof = prof_iso if prof_iso is not None else prof  # isolated durations where they exist
+        dom = max(kprof, key=lambda n: kprof[n][1])
+        calls, tot_ms = kprof[dom]
         avg_ms = tot_ms / calls
         # ROOFLINE, as SURVEY.md 8(d) defines it: algorithmic bytes of the path -- 21.25 B per k-mer occurrence
         # (1.25 input + 8 key read + 8 coverage RMW + ~4 edge RMW) + 8 B per novel key -- over the GPU time of
@@ -632,7 +856,7 @@ def main():
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         pipe_bytes = ALG_BYTES_PER_KMER * kmers_local + ALG_BYTES_PER_NOVEL * st.num_kmers_novel
         pipe_ach = pipe_bytes / (gpu_ms * 1e-3) / 1e9
-        ktab = kernel_table(prof, kmers_local, 1, in_b)
+        ktab = kernel_table(kprof, kmers_local, 1, in_b)
         # HBM bytes of the whole path per occurrence from the newest PMC summary taken on these kernel sources
         tr_total, tr_src = 0.0, None
         for kn in ktab:
@@ -648,26 +872,47 @@ def main():
                                    "traffic = PMC HBM bytes of the three kernels over the same region (null: no summary for these sources)",
                            "alg_bytes": pipe_bytes, "gpu_ms": gpu_ms, "alg_bytes_per_kmer": ALG_BYTES_PER_KMER, "alg_bytes_per_novel_key": ALG_BYTES_PER_NOVEL,
                            "kernels": ktab,
+                           "kernels_what": ("ISOLATED durations: a second pass over the same steps with the flush overlap off (one kernel at a time on one stream, "
+                                            "HIP events around every launch; same graph checksum); their sum is the GPU time of that pass (gpu_ms_isolated_pass), "
+                                            "the timed region itself (gpu_ms) runs with the overlap on") if prof_iso is not None else "HIP-event spans of the timed region",
+                           "gpu_ms_isolated_pass": gpu_ms_iso,
+                           "kernels_sum_ms": round(sum(v["total_ms"] for v in ktab.values()), 3),
+                           "spans_overlapped": {n: {"launches": c, "total_ms": round(t, 3)} for n, (c, t) in prof.items()} if prof_iso is not None else None,
                            "dominant": {"kernel": dom, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_kernel_ms": avg_ms, "launches": calls,
                                         "alg_bytes_per_launch": alg_bytes,
-                                        "note": "the dominant kernel's OWN design bytes (stream + packed tuples) over its average launch"}}
+                                        "note": "the kernel with the largest isolated total; its OWN design bytes (stream + packed tuples) over its average isolated launch"}}
+        out["roofline"].update(ceil)
+        if ceil.get("measured_copy_gbs"):
+            out["roofline"]["frac_of_measured_copy"] = pipe_ach / ceil["measured_copy_gbs"]
         # SURVEY 8(d)'s second ceiling: one random 64-byte sector RMW per occurrence is what the
         # reference's algorithm (and the direct path here) costs; the chip does 17.3 G of those per
         # second on a 16 GiB table (tools/ubench_atomics*.hip, profiles/r01_ubench_atomics*.log).
         # The partition + LDS-insert path is not bound by it: that is the point of the design.
+        rmw_peak = ceil.get("measured_random_rmw_per_s") or 17.3e9
         out["roofline"]["random_access"] = {"occurrences_per_s": kmers_local / (gpu_ms * 1e-3),
-                                            "measured_random_rmw_peak_per_s": 17.3e9,
-                                            "ratio": kmers_local / (gpu_ms * 1e-3) / 17.3e9}
+                                            "measured_random_rmw_peak_per_s": rmw_peak,
+                                            "peak_source": "mcx_ubench_random_rmw in this run" if ceil.get("measured_random_rmw_per_s") else "profiles/r01_ubench_atomics.log (round 1)",
+                                            "ratio": kmers_local / (gpu_ms * 1e-3) / rmw_peak}
         ex = {}
         if not sharded and not args.no_extras and not args.iid and not args.direct:
             graph.close()
             torch.cuda.empty_cache()
-            ex = extras(mcx, batches, packed, nsteps, args.table_slots)
-            for key in ("host_fed", "e2e", "default_defer", "ascii_resident", "packed_resident", "other_configs", "inprocess_2_shards_1gpu"):
+            osteps = 0 if args.no_cpu_baseline else max(0, min(args.oracle_steps, nsteps))
+            ex = extras(mcx, batches, packed, nsteps, args.table_slots, osteps, not args.no_full_e2e)
+            for key in ("host_fed", "e2e", "e2e_full", "default_defer", "ascii_resident", "packed_resident", "other_configs", "inprocess_2_shards_1gpu"):
                 if key in ex:
                     out[key] = ex[key]
         if not args.no_cpu_baseline and not sharded:
-            out["cpu_baseline"] = cpu_baseline(batches[0], ex.get("_fastq_sample"))
+            gref = ex.get("_gpu_oracle_steps")
+            out["cpu_baseline"] = cpu_baseline(batches[0], ex.get("_fastq_sample"), batches, gref["steps"] if gref else 0, args.table_slots)
+            full = out["cpu_baseline"].get("full_size", {})
+            if gref and "checksum" in full:
+                # the oracle and the GPU built the same steps into the same table size: same records?
+                same = full["checksum"] == gref["graph_checksum"] and full["nodes"] == gref["nodes"] and full["kmers"] == gref["kmers"]
+                out["config"]["checksum_matches_oracle"] = bool(same)
+                out["config"]["oracle_check"] = {"steps": gref["steps"], "of_steps": nsteps, "gpu_checksum": gref["graph_checksum"], "oracle_checksum": full["checksum"],
+                                                 "gpu_nodes": gref["nodes"], "oracle_nodes": full["nodes"], "kmers": gref["kmers"],
+                                                 "covers_the_headline_graph": gref["steps"] == nsteps and gref["graph_checksum"] == out["config"]["graph_checksum"]}
         if ex.get("_tmpdir"):
             import shutil
             shutil.rmtree(ex["_tmpdir"], ignore_errors=True)

@@ -287,6 +287,18 @@ int mcx_graph_covg_histogram(mcx_graph *g, uint64_t *hist, uint32_t nbins);
 int mcx_graph_checksum(mcx_graph *g, uint64_t *checksum, uint64_t *nkmers);
 uint64_t mcx_records_checksum(const void *recs, uint64_t nrecs, int kmer_size, int ncols);
 
+/* The two ceilings of the device the build's roofline figures are quoted against ("to be
+ * measured on the box by an in-repo microbenchmark and quoted next to the nominal figure"; the reference
+ * times its table and the competitor in one script as well, results/hash_table_benchmark/benchmark-tables.sh:14-59).
+ * mcx_ubench_stream      streaming rates in GB/s over two buffers of `bytes` each (far beyond the 256 MiB Infinity
+ *                        Cache): copy (read + write bytes counted), read only, write only; 16-byte accesses
+ * mcx_ubench_random_rmw  random 64-byte-sector rates per second over a `table_bytes` working set of 16-byte
+ *                        records: agent-scope atomic add (what an occurrence costs the direct insert), 16-byte
+ *                        load, load + atomic.  Any out pointer may be NULL. */
+int mcx_ubench_stream(int device, uint64_t bytes, double *copy_gbs, double *read_gbs, double *write_gbs);
+int mcx_ubench_random_rmw(int device, uint64_t table_bytes, uint64_t nupdates, double *rmw_per_s,
+                          double *load16_per_s, double *load_rmw_per_s);
+
 /* `.ctx` records on the device without a graph handle (host buffers, .ctx body layout).
  * mcx_sort_records    sort in place by k-mer, most significant word first -- what `sort` does with
  *                     qsort (src/commands/ctx_sort.c:133-152; binary_kmers_qcmp_unaligned_ptrs)

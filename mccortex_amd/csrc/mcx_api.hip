@@ -25,6 +25,7 @@
 #include "../../include/mcx_gpu.h"
 #include "mcx_kernels.h"
 #include "mcx_superk.h"
+#include "mcx_ubench.h"
 
 using namespace mcx;
 
@@ -162,6 +163,11 @@ struct mcx_graph {
                                 // the L1 bins in groups of this many regions, reusing the same bins
   uint32_t flush_regions = 0;   // configured group size (0 = automatic)
   uint32_t idle_next = 0;       // next region group the idle-device flush takes (flush_if_device_idle)
+  // idle flush bookkeeping: with A = idle_base + pending = occurrences handed to the L1 bins since the last whole
+  // flush, idle_mark[i] = A when region group i was last emptied and idle_base = min(idle_mark): `pending` is what
+  // the group that has waited LONGEST may hold per its share -- the bound the segments' capacity is sized for
+  uint64_t idle_base = 0;
+  std::vector<uint64_t> idle_mark;
   // ---- build --intersect (ctx_build.c:341-363,384-413) ----
   int hidden = -1;              // colour that holds the intersection graphs' edges, or -1
   int ncols_vis = 0;            // colours that are exported / scanned (ncols, or ncols - 1)
@@ -170,6 +176,7 @@ struct mcx_graph {
   int pending_colour = 0;
   // ---- optional per-kernel timing (mcx_graph_configure("profile", 1)) ----
   bool profile = false;
+  int overlap = -1;  // flush overlap: -1 = MCX_FLUSH_OVERLAP / default (on), 0 / 1 = mcx_graph_configure("flush_overlap", v)
   struct Span { const char *name; hipEvent_t a, b; };
   std::vector<Span> spans;
   // ---- multi-GPU table (mcx_multi.h): a shard knows its group; the handle the caller holds is a
@@ -394,6 +401,7 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->l2_regions * g->subs_per_bin * 8, g->stream));
   if (g->d_readstrt) HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
   g->pending = g->pending_l2 = 0;  // buffered tuples are discarded with the table
+  g->idle_next = 0; g->idle_base = 0; g->idle_mark.clear();
   sets_release(g);
   return MCX_OK;
 }
@@ -621,10 +629,10 @@ static int ensure_l2(mcx_graph *g, uint32_t regions)
 // bins).  Worth 1.3-2.8 % of the C2 step (tools/sweep.sh, round 3); the per-kernel durations of the
 // two kernels then include each other's interference (a co-running insert launch takes about twice
 // as long as alone), so kernel-by-kernel profiles are taken with it off (tools/prof.sh).
-static bool flush_overlap()
+static bool flush_overlap(const mcx_graph *g)
 {
   static const bool on = [] { const char *e = getenv("MCX_FLUSH_OVERLAP"); return !e || atoi(e) != 0; }();
-  return on;
+  return g->overlap < 0 ? on : g->overlap != 0;  // (mcx_graph_configure("flush_overlap", 0 | 1) overrides the environment)
 }
 
 // regions per flush group: enough sub-tables for one full wave of LDS-insert workgroups, few
@@ -689,7 +697,7 @@ static int ensure_defer(mcx_graph *g)
     const uint64_t n1 = (uint64_t)g->nsets * g->b1 * g->rep1 * g->cap1;
     const bool ok = hipMalloc((void **)&g->l1_keys, n1 * 8 * g->W) == hipSuccess &&
                     hipMalloc((void **)&g->l1_cnt, (size_t)g->nsets * g->b1 * g->rep1 * 8) == hipSuccess &&
-                    ensure_l2(g, flush_overlap() ? std::min<uint32_t>(2 * flush_group(g), g->b1) : flush_group(g)) == MCX_OK;
+                    ensure_l2(g, flush_overlap(g) ? std::min<uint32_t>(2 * flush_group(g), g->b1) : flush_group(g)) == MCX_OK;
     if (ok) break;
     free_defer(g);
     (void)hipGetLastError();  // clear the sticky out-of-memory error
@@ -719,7 +727,7 @@ static int flush_deferred(mcx_graph *g)
   // Flush overlap (MCX_FLUSH_OVERLAP=1, experiment): the split is HBM-bound, the LDS insert bound by
   // instruction issue; with two halves of sub-table bins the insert of group g runs on a second
   // stream beside the split of group g + 1 (grids sized to share the CUs: grid_split / grid_insert).
-  const bool overlap = flush_overlap() && g->pending && !g->pending_l2 && g->l2_regions >= 2 * G && G < g->b1;
+  const bool overlap = flush_overlap(g) && g->pending && !g->pending_l2 && g->l2_regions >= 2 * G && G < g->b1;
   hipStream_t s1 = g->stream;
   if (overlap) {
     if (!g->stream2) {
@@ -785,6 +793,7 @@ static int flush_deferred(mcx_graph *g)
   if (g->pending) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->nsets * g->b1 * g->rep1 * 8, g->stream));
   g->pending = 0;
   g->pending_l2 = 0;
+  g->idle_next = 0; g->idle_base = 0; g->idle_mark.clear();
   sets_release(g);
   return MCX_OK;
 }
@@ -870,14 +879,18 @@ static int ensure_stage(mcx_graph *g);
 extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value)
 {
   if (g && key && g->as_group) {
-    if (!strcmp(key, "intersect")) {  // the facade's view of the colours follows its shards'
-      if (g->ncols < 2) return fail(MCX_ERR_ARG, "intersect mode needs one colour more than the output has");
-      g->hidden = g->ncols - 1;
-      g->ncols_vis = g->ncols - 1;
-    }
+    const bool isec = !strcmp(key, "intersect");
+    if (isec && g->ncols < 2) return fail(MCX_ERR_ARG, "intersect mode needs one colour more than the output has");
     if (!strcmp(key, "defer") && !value) return fail(MCX_ERR_ARG, "a multi-GPU table always uses the partitioned insert");
     int rc = grp_drain(g->as_group);
     for (int i = 0; rc == MCX_OK && i < grp_n(g->as_group); i++) rc = mcx_graph_configure(grp_part(g->as_group, i), key, value);
+    // the facade's view of the colours follows its shards' -- only once every shard has accepted the key
+    // (a shard that failed leaves the handle in its old view; intersect mode cannot be switched off again,
+    // so a partial failure is reported and the caller must destroy the handle)
+    if (isec && rc == MCX_OK) {
+      g->hidden = g->ncols - 1;
+      g->ncols_vis = g->ncols - 1;
+    }
     return rc;
   }
   if (!g || !key) return fail(MCX_ERR_ARG, "null argument");
@@ -894,6 +907,14 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     HIP_TRY(hipStreamSynchronize(g->stream));
     free_defer(g);
     g->defer_tuples = value;
+    return MCX_OK;
+  }
+  if (!strcmp(key, "flush_overlap")) {  // 1: the insert of region group g runs beside the split of g + 1 (default); 0: one kernel at a time
+    int rc = flush_deferred(g);        // (isolated per-kernel durations: bench.py's roofline.kernels, tools/prof.sh)
+    if (rc != MCX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->overlap = value != 0;
+    if (g->l1_keys && g->overlap) return ensure_l2(g, std::min<uint32_t>(2 * flush_group(g), g->b1));
     return MCX_OK;
   }
   if (!strcmp(key, "flush_regions")) {  // regions split + applied per step of a flush (0 = automatic)
@@ -1425,7 +1446,11 @@ static int stage_threads()
 // flushes.  One-colour graphs on one device only; MCX_IDLE_FLUSH=0 switches it off.
 static int flush_if_device_idle(mcx_graph *g)
 {
-  static const int mode = [] { const char *e = getenv("MCX_IDLE_FLUSH"); return e ? atoi(e) : 1; }();  // 2: take every chance (tests)
+  // 2: take every chance (tests); 3: every chance once 3/4 of the flush size is buffered (tests: a device that was
+  // busy first, so that the idle flushes start on a nearly full workspace)
+  static const int mode_env = [] { const char *e = getenv("MCX_IDLE_FLUSH"); return e ? atoi(e) : 1; }();
+  if (mode_env == 3 && !(g->idle_base || g->pending >= g->defer_tuples / 4 * 3)) return MCX_OK;
+  const int mode = mode_env == 3 ? 2 : mode_env;
   const bool on = mode != 0;
   if (!on || !g->defer || g->group || g->nsets != 1 || !g->pending || g->pending_l2 || g->set_colour.empty() || g->set_colour[0] < 0) return MCX_OK;
   const uint32_t G = std::min(flush_group(g), g->l2_regions);
@@ -1448,10 +1473,19 @@ static int flush_if_device_idle(mcx_graph *g)
   HIP_TRY(hipGetLastError());
   for (uint32_t rep = 0; rep < g->rep1; rep++)  // the group's L1 bins are empty again
     HIP_TRY(hipMemsetAsync(g->l1_cnt + (uint64_t)rep * g->b1 + r0, 0, (size_t)ng * 8, g->stream));
-  // (the bound on what is buffered: the group held its share of it)
-  const uint64_t share = g->pending / ngroups;
-  g->pending -= share;
-  g->set_pending[0] -= std::min(g->set_pending[0], share);
+  // The bound on what is buffered.  A region group that has not been emptied since A_i occurrences had been
+  // handed over holds its share of A - A_i; the flush trigger (defer_reserve) compares `pending` with the
+  // capacity the segments were sized for, so `pending` must stay A - min_i(A_i): it only drops once the group
+  // that has waited longest is emptied.  (Until round 3 a flushed group's share was subtracted at once: after
+  // the first idle flush of a nearly full workspace the other groups could then be filled beyond their
+  // segments -- correct through the direct-insert fallback, but slow and silent.)
+  if (g->idle_mark.size() != ngroups) g->idle_mark.assign(ngroups, g->idle_base);
+  g->idle_mark[r0 / G] = g->idle_base + g->pending;
+  const uint64_t base = *std::min_element(g->idle_mark.begin(), g->idle_mark.end());
+  const uint64_t freed = base - g->idle_base;
+  g->idle_base = base;
+  g->pending -= std::min(g->pending, freed);
+  g->set_pending[0] -= std::min(g->set_pending[0], freed);
   return MCX_OK;
 }
 
@@ -2378,6 +2412,64 @@ extern "C" uint64_t mcx_records_checksum(const void *recs, uint64_t nrecs, int k
     sum += record_hash(kw, W, cv.data(), p + 8 * W + 4 * ncols, (uint32_t)ncols);
   }
   return sum;
+}
+
+// ---------------------------------------------------------------------------
+// device ceilings (mcx_ubench.h)
+// ---------------------------------------------------------------------------
+extern "C" int mcx_ubench_stream(int device, uint64_t bytes, double *copy_gbs, double *read_gbs, double *write_gbs)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(MCX_ERR_NODEVICE, "no HIP device %d", device);
+  HIP_TRY(hipSetDevice(device));
+  const uint64_t n = bytes / 16;
+  if (n < (1u << 20)) return fail(MCX_ERR_ARG, "buffers of at least 16 MiB");
+  ulonglong2 *a = nullptr, *b = nullptr;
+  unsigned long long *sink = nullptr;
+  if (hipMalloc((void **)&a, n * 16) != hipSuccess || hipMalloc((void **)&b, n * 16) != hipSuccess || hipMalloc((void **)&sink, 8) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+    return fail(MCX_ERR_NOMEM, "out of device memory for the streaming microbenchmark");
+  }
+  (void)hipMemset(a, 1, n * 16); (void)hipMemset(b, 2, n * 16);
+  const int grid = 8192;
+  double ms[3] = {0, 0, 0};
+  int rc = ubench_time([&] { k_ubench_stream<0, 8><<<grid, 256>>>(a, b, n, sink); }, 5, &ms[0]);
+  if (!rc) rc = ubench_time([&] { k_ubench_stream<1, 8><<<grid, 256>>>(a, b, n, sink); }, 5, &ms[1]);
+  if (!rc) rc = ubench_time([&] { k_ubench_stream<2, 8><<<grid, 256>>>(a, b, n, sink); }, 5, &ms[2]);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+  if (rc) return fail(MCX_ERR_HIP, "streaming microbenchmark failed");
+  if (copy_gbs) *copy_gbs = 2.0 * n * 16 / ms[0] / 1e6;
+  if (read_gbs) *read_gbs = 1.0 * n * 16 / ms[1] / 1e6;
+  if (write_gbs) *write_gbs = 1.0 * n * 16 / ms[2] / 1e6;
+  return MCX_OK;
+}
+
+extern "C" int mcx_ubench_random_rmw(int device, uint64_t table_bytes, uint64_t nupdates, double *rmw_per_s, double *load16_per_s,
+                                     double *load_rmw_per_s)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(MCX_ERR_NODEVICE, "no HIP device %d", device);
+  HIP_TRY(hipSetDevice(device));
+  const uint64_t nrec = table_bytes / 16;
+  if (nrec < 1024 || nupdates < (1u << 20)) return fail(MCX_ERR_ARG, "table of at least 16 KiB, at least 1 M updates");
+  uint64_t *tab = nullptr;
+  unsigned long long *sink = nullptr;
+  if (hipMalloc((void **)&tab, nrec * 16) != hipSuccess || hipMalloc((void **)&sink, 8) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(tab); (void)hipFree(sink);
+    return fail(MCX_ERR_NOMEM, "out of device memory for the random-access microbenchmark");
+  }
+  (void)hipMemset(tab, 0, nrec * 16);
+  double ms[3] = {0, 0, 0};
+  uint64_t seed = 7;
+  int rc = ubench_time([&] { k_ubench_rmw<1, 4><<<2048, 256>>>(tab, nrec, nupdates, seed++, sink); }, 2, &ms[0]);
+  if (!rc) rc = ubench_time([&] { k_ubench_rmw<0, 4><<<2048, 256>>>(tab, nrec, nupdates, seed++, sink); }, 2, &ms[1]);
+  if (!rc) rc = ubench_time([&] { k_ubench_rmw<2, 4><<<2048, 256>>>(tab, nrec, nupdates, seed++, sink); }, 2, &ms[2]);
+  (void)hipFree(tab); (void)hipFree(sink);
+  if (rc) return fail(MCX_ERR_HIP, "random-access microbenchmark failed");
+  if (rmw_per_s) *rmw_per_s = (double)nupdates / ms[0] * 1e3;
+  if (load16_per_s) *load16_per_s = (double)nupdates / ms[1] * 1e3;
+  if (load_rmw_per_s) *load_rmw_per_s = (double)nupdates / ms[2] * 1e3;
+  return MCX_OK;
 }
 
 extern "C" int mcx_graph_kmer_covg(mcx_graph *g, uint64_t *nkmers, uint64_t *sumcov)

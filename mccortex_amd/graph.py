@@ -20,6 +20,7 @@ SYMBOLS = [
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
     "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash", "mcx_pack_bases", "mcx_pack_stream_dev", "mcx_graph_add_packed_dev",
+    "mcx_ubench_stream", "mcx_ubench_random_rmw",
 ]
 
 
@@ -100,6 +101,8 @@ def lib():
     L.mcx_graph_checksum.argtypes = [vp, u64p, u64p]
     L.mcx_records_checksum.restype = C.c_uint64
     L.mcx_records_checksum.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
+    L.mcx_ubench_stream.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.mcx_ubench_random_rmw.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mcx_graph_key_owner.restype = C.c_uint32
     L.mcx_graph_key_owner.argtypes = [vp, u64p]
     L.mcx_graph_destroy.argtypes = [vp]
@@ -426,8 +429,26 @@ def pack_stream_dev(d_stream, nbytes, d_code, d_inv, hip_stream=None):
     _check(lib().mcx_pack_stream_dev(_ptr(d_stream), int(nbytes), _ptr(d_code), _ptr(d_inv), C.c_void_p(hip_stream) if hip_stream else None))
 
 
+def ubench_stream(nbytes=8 << 30, device=0):
+    """measured streaming ceilings of the device in GB/s: {"copy", "read", "write"} (mcx_ubench_stream)"""
+    c, r, w = C.c_double(0), C.c_double(0), C.c_double(0)
+    _check(lib().mcx_ubench_stream(device, C.c_uint64(nbytes), C.byref(c), C.byref(r), C.byref(w)))
+    return {"copy": c.value, "read": r.value, "write": w.value}
+
+
+def ubench_random_rmw(table_bytes=16 << 30, nupdates=1 << 29, device=0):
+    """measured random 64-byte-sector rates per second over a working set of `table_bytes`:
+    {"rmw" (agent-scope atomic), "load16", "load_rmw"} (mcx_ubench_random_rmw)"""
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    _check(lib().mcx_ubench_random_rmw(device, C.c_uint64(table_bytes), C.c_uint64(nupdates), C.byref(a), C.byref(b), C.byref(c)))
+    return {"rmw": a.value, "load16": b.value, "load_rmw": c.value}
+
+
 def records_checksum(recs, kmer_size, ncols):
-    a = np.frombuffer(bytes(recs), dtype=np.uint8)
+    if isinstance(recs, np.ndarray) and recs.dtype == np.uint8 and recs.flags.c_contiguous:
+        a = recs  # (no copy: bodies of hundreds of millions of records)
+    else:
+        a = np.frombuffer(bytes(recs), dtype=np.uint8)
     rs = 8 * _words(kmer_size) + 5 * ncols
     assert a.size % rs == 0
     return int(lib().mcx_records_checksum(_ptr(a), a.size // rs, kmer_size, ncols))

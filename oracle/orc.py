@@ -261,6 +261,15 @@ class Graph:
     def header_size(self):
         return int(self.L.orc_graph_header_size(self.h))
 
+    def body_array(self, sorted_=False):
+        """the records of the .ctx (no header) as a uint8 array, without the extra copies of ctx_bytes():
+        for graphs of hundreds of millions of k-mers (full-size parity checks, bench.py's cpu_baseline)"""
+        n = self.L.orc_graph_ctx_size(self.h)
+        buf = np.empty(n, dtype=np.uint8)
+        w = self.L.orc_graph_write_ctx(self.h, 1 if sorted_ else 0, _ptr(buf))
+        assert w == n, (w, n)
+        return buf[self.header_size():]
+
     def lookup(self, kmer):
         cov = np.zeros(self.ncols, np.uint32)
         edg = np.zeros(self.ncols, np.uint8)

@@ -1,13 +1,20 @@
-"""Parity at BASELINE.json's full sizes through size-independent properties.
+"""Parity at BASELINE.json's full sizes.
 
-At 6 G occurrences the oracle is out of reach (hours) and byte-wise comparison of exports is
-impractical, so the graph is reduced to an order-independent checksum of its exported records
-(mcx_graph_checksum; pinned to the oracle's records at small size below) and independent ways of
-building the same graph must agree on it: the partition + LDS-insert path with one flush and with
-many, the direct HBM-atomics path, and the sharded builds (exchange formats v2 and v3, shards
-simulated on one GPU: the sum of the shard checksums is the checksum of the union).  Plus counting
-identities: every occurrence is counted exactly once (sum of coverage == k-mers loaded), every node
-has coverage (histogram bin 0 empty), node count == novel counter."""
+Byte-wise comparison of multi-GB exports is impractical, so a graph is reduced to an order-independent
+checksum of its exported records (mcx_graph_checksum; pinned to the oracle's records at small size below).
+
+* Against the ORACLE at the benchmark's own table geometry (2^30 slots = 512 regions x 512 sub-tables, the
+  shape every bench.py number is measured on): one C2 step (5 M reads, 600 M occurrences; the oracle takes
+  about 20 s with 32 threads) for k = 31 and k = 63, through the partition + LDS-insert path, the direct
+  HBM-atomics path and eight in-process shards -- checksum, node count and loading statistics must equal
+  those of the oracle's records.  (bench.py's cpu_baseline leg does the same on its timed oracle run, up to
+  the whole 50 M-read set with --oracle-steps 10: `config.checksum_matches_oracle`.)
+* At the whole 6 G occurrences, where the oracle needs minutes rather than seconds, independent ways of
+  building the same graph must agree on the checksum: the partition + LDS-insert path with one flush and
+  with many, the direct HBM-atomics path, and the sharded builds (exchange formats v2 and v3, shards
+  simulated on one GPU: the sum of the shard checksums is the checksum of the union).  Plus counting
+  identities: every occurrence is counted exactly once (sum of coverage == k-mers loaded), every node
+  has coverage (histogram bin 0 empty), node count == novel counter."""
 import os
 import sys
 
@@ -74,6 +81,44 @@ def _build(mcx, batches, k, ncols, slots, cfg, colours=None):
                covg_nodes=nk.tolist(), covg_sum=sc.tolist(), hist0=int(hist[0]), hist_total=int(hist.sum()))
     g.close()
     return out
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_benchmark_geometry_matches_oracle(mcx, orc, c2_batches, k):
+    """GPU vs ORACLE at the table geometry of the benchmark (2^30 slots: lb1 = 9, 512 sub-tables per region;
+    k = 63: 1024 sub-tables of 2048 slots), on the first C2 step.  The direct and the deferred path share
+    their front end and the quotient addressing, so their agreement alone would not exclude a common error
+    that only shows at this geometry: the oracle shares nothing with them."""
+    import bench
+    SLOTS = 1 << 30
+    b = c2_batches[0]
+    n = bench.BATCH_READS
+    host = b.reshape(n, bench.READ_LEN + 1)[:, :bench.READ_LEN].contiguous().cpu().numpy().reshape(-1)
+    offs = np.arange(n + 1, dtype=np.uint64) * bench.READ_LEN
+    nt = min(32, os.cpu_count() or 1)
+    og = orc.Graph(k, 1, 1 << 29)      # (the oracle's own capacity does not enter its records)
+    og.tune(nt)
+    st = og.add_reads(0, host, offs, nthreads=nt)
+    body = og.body_array(False)
+    want = (mcx.records_checksum(body, k, 1), og.nkmers)
+    assert body.size == og.nkmers * (8 * og.W + 5)
+    del body, og
+    assert want[1] > 150_000_000
+    for name, kw, cfg in (("deferred", {}, {"defer_tuples": 1_000_000_000}),
+                          ("direct", {}, {"defer": 0}),
+                          ("8 in-process shards", {"devices": [0] * 8}, {"defer_tuples": 125_000_000})):
+        g = mcx.Graph(k, 1, SLOTS, **kw)
+        for key, v in cfg.items():
+            g.configure(key, v)
+        g.add_stream_dev(0, b, b.numel())
+        g.sync()
+        ds = g.device_stats()
+        got = g.checksum()
+        nk, sc = g.kmer_covg()
+        g.close()
+        assert got == want, (k, name)
+        assert (ds.num_kmers_loaded, ds.contigs_parsed, ds.num_kmers_novel) == (st.num_kmers_loaded, st.contigs_parsed, st.num_kmers_novel), (k, name)
+        assert (int(nk[0]), int(sc[0])) == (want[1], st.num_kmers_loaded), (k, name)
 
 
 def test_c2_full_size_all_paths_agree(mcx, c2_batches):

@@ -26,6 +26,8 @@ offs = np.arange(B + 1, dtype=np.uint64) * L
 res = []
 for mode in ("host", "dev"):
     g = mcx.Graph(31, 1, 1 << 27)
+    if DEFER:
+        g.configure("defer_tuples", DEFER)
     g.configure("profile", 1)
     for rep in range(3):
         if mode == "host":
@@ -39,15 +41,30 @@ for mode in ("host", "dev"):
     res.append((cs, n, st.num_kmers_loaded, st.contigs_parsed, prof["k_lds_insert"][0]))
     g.close()
 print("RESULT", res)
-''' % ROOT
+'''
+
+
+def _run(env, defer=0):
+    p = subprocess.run([sys.executable, "-c", "DEFER = %d\n" % defer + CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("RESULT")][-1]
+    return eval(line[len("RESULT"):])
 
 
 def test_host_fed_build_with_background_flush_matches_device_resident_build():
     env = dict(os.environ, MCX_IDLE_FLUSH="2", MCX_STAGE_BYTES=str(32 << 20))  # 20 chunks per call: 20 chances to flush a group
-    p = subprocess.run([sys.executable, "-c", CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
-    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("RESULT")][-1]
-    host, dev = eval(line[len("RESULT"):])
+    host, dev = _run(env)
     assert host[:4] == dev[:4]          # checksum, nodes, k-mers loaded, contigs
     assert host[2] > 700_000_000 and host[1] > 10_000_000
     assert host[4] > dev[4]             # ... and the background flush did run (more LDS-insert launches than one closing flush)
+
+
+def test_idle_flushes_that_start_on_a_nearly_full_workspace():
+    """The device was busy first: the idle flushes only start once 3/4 of the flush size is buffered
+    (MCX_IDLE_FLUSH=3), with a flush size the three calls exceed.  A flushed region group must not make room
+    in the books for the groups that have not been emptied yet (flush_if_device_idle: `pending` follows the
+    group that has waited longest): same graph as the device-resident build, whole flushes in between included."""
+    env = dict(os.environ, MCX_IDLE_FLUSH="3", MCX_STAGE_BYTES=str(32 << 20))
+    host, dev = _run(env, defer=400_000_000)   # 3 x 240 M occurrences through a 400 M workspace
+    assert host[:4] == dev[:4]
+    assert host[2] > 700_000_000

@@ -580,3 +580,27 @@ def test_interleaved_colours_keep_their_tuples_apart(mcx, orc, k, ncols, sets, m
             groups = prof["k_lds_insert"][0]
             assert groups % ncols == 0 and prof["k_tuples_bin"][0] == groups
         g.close()
+
+
+def test_device_ceiling_microbenchmarks_and_flush_overlap_switch(mcx, orc):
+    """mcx_ubench_stream / mcx_ubench_random_rmw (the ceilings bench.py quotes are measured in its own
+    run) return plausible figures for an MI355X, and mcx_graph_configure("flush_overlap", 0 | 1) -- the switch behind
+    bench.py's isolated per-kernel pass -- does not change the graph."""
+    st = mcx.ubench_stream(1 << 30)
+    assert 1000 < st["copy"] < 8000 and 1000 < st["read"] < 8000 and 1000 < st["write"] < 8000   # GB/s; 8 TB/s is the datasheet
+    rw = mcx.ubench_random_rmw(1 << 30, 1 << 24)
+    assert 1e9 < rw["rmw"] < 1e11 and rw["load16"] > rw["rmw"]
+    with pytest.raises(mcx.McxError):
+        mcx.ubench_stream(1 << 20)
+    g0 = synth.genome(300000, 3)
+    b, o = synth.reads(60000, 120, seed=11, g=g0, n_frac=0.02)
+    og = orc.Graph(31, 1, 1 << 22)
+    og.add_reads(0, b, o)
+    want = og.body_bytes(True)
+    for ov in (0, 1):
+        g = mcx.Graph(31, 1, 1 << 24)      # 8 regions: two flush groups with flush_regions = 4 (the overlap needs two)
+        g.configure("flush_regions", 4)
+        g.configure("flush_overlap", ov)
+        g.add_reads(0, b, o)
+        assert g.export(True) == want
+        g.close()
