@@ -1404,14 +1404,42 @@ __attribute__((target("avx2"))) static void pack_block_avx2(const uint8_t *src, 
     memcpy(inv + i / 16, &bad, 4);
   }
 }
+
+// 64 positions per iteration with AVX-512 (BW + VL; the hosts of MI355X nodes are Zen 4 / Zen 5 or Sapphire Rapids):
+// the same two multiply-adds fold the codes, vpmovdb gathers the sixteen result bytes and one 128-bit shuffle puts
+// them in the order of the four code words; validity is ONE table lookup (the low nibble of an upper-cased base picks
+// the letter that has it: 1 A, 3 C, 4 T, 7 G) and one compare into a mask register, on the byte-reversed lanes so
+// that the first base of a word is its bit 15.  ~17 micro-ops per 64 bytes (AVX2: 22 per 32).
+__attribute__((target("avx512f,avx512bw,avx512vl"))) static void pack_block_avx512(const uint8_t *src, size_t n, uint32_t *code, uint16_t *inv)
+{
+  const __m512i m3 = _mm512_set1_epi8(3), mdf = _mm512_set1_epi8((char)0xDF), m0f = _mm512_set1_epi8(0x0F);
+  const __m512i w1 = _mm512_set1_epi16(0x0104), w2 = _mm512_set1_epi32(0x00010010);
+  const __m128i bswap = _mm_setr_epi8(3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12);
+  const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0));
+  const __m512i rev = _mm512_broadcast_i32x4(_mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0));
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m512i v = _mm512_loadu_si512((const void *)(src + i));
+    const __m512i t = _mm512_ternarylogic_epi64(_mm512_srli_epi16(v, 1), _mm512_srli_epi16(v, 2), m3, 0x28);  // (a ^ b) & c
+    const __m512i byt = _mm512_madd_epi16(_mm512_maddubs_epi16(t, w1), w2);  // 32-bit lanes: four bases, the first on top
+    _mm_storeu_si128((__m128i *)(code + i / 16), _mm_shuffle_epi8(_mm512_cvtepi32_epi8(byt), bswap));
+    const __m512i u = _mm512_shuffle_epi8(_mm512_and_si512(v, mdf), rev);   // upper-cased, each 16-byte lane reversed
+    const __mmask64 ok = _mm512_cmpeq_epi8_mask(_mm512_shuffle_epi8(lut, _mm512_and_si512(u, m0f)), u);
+    const uint64_t bad = ~(uint64_t)ok;  // bit 16 g + 15 - j = byte j of lane g is not a base
+    memcpy(inv + i / 16, &bad, 8);
+  }
+  if (i < n) pack_block_avx2(src + i, n - i, code + i / 16, inv + i / 16);  // (n is a multiple of 32)
+}
 #endif
 
 // n is a multiple of 32
 static void pack_block(const uint8_t *src, size_t n, uint32_t *code, uint16_t *inv)
 {
 #if defined(__x86_64__)
-  static const bool fast = __builtin_cpu_supports("avx2") && !getenv("MCX_NO_AVX2");
-  if (fast) { pack_block_avx2(src, n, code, inv); return; }
+  static const int level = getenv("MCX_NO_AVX2") ? 0 : (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && !getenv("MCX_NO_AVX512")) ? 2
+                           : __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (level == 2) { pack_block_avx512(src, n, code, inv); return; }
+  if (level == 1) { pack_block_avx2(src, n, code, inv); return; }
 #endif
   for (size_t i = 0; i < n; i += 16) pack16_swar(src + i, code + i / 16, inv + i / 16);
 }
@@ -2417,6 +2445,15 @@ extern "C" uint64_t mcx_records_checksum(const void *recs, uint64_t nrecs, int k
 // ---------------------------------------------------------------------------
 // device ceilings (mcx_ubench.h)
 // ---------------------------------------------------------------------------
+#ifdef MCX_PHASES  // tools/variants.sh build only (mcx_defer.h: per-phase time of the build kernels)
+extern "C" int mcx_debug_phases(uint64_t *out24, int reset)
+{
+  if (out24) HIP_TRY(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 24));
+  if (reset) { unsigned long long z[24] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z))); }
+  return MCX_OK;
+}
+#endif
+
 extern "C" int mcx_ubench_stream(int device, uint64_t bytes, double *copy_gbs, double *read_gbs, double *write_gbs)
 {
   int ndev = 0;

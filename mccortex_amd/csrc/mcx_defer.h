@@ -72,6 +72,23 @@ struct BinOut {
 };
 
 #define MCX_LDS_AS __attribute__((address_space(3)))
+
+// Per-phase time of the three build kernels (tools/exp_phases.py, profiles/r04_phases.md): compiled in ONLY with
+// -DMCX_PHASES (a tools/variants.sh build); in the product build the hooks expand to nothing.  Thread 0 of every
+// block reads the 100 MHz clock at the phase boundaries (most of them barriers) and the per-block sums are added
+// to g_phase[kernel][phase]; phase 7 counts the tiles / sub-table visits.
+#ifdef MCX_PHASES
+__device__ unsigned long long g_phase[3][8];
+#define MCX_PH_DECL unsigned long long ph_t = wall_clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MCX_PH(i) { const unsigned long long n_ = wall_clock64(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
+#define MCX_PH_COUNT ph_acc[7]++;
+#define MCX_PH_DUMP(kid) { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_phase[kid][i_], ph_acc[i_]); }
+#else
+#define MCX_PH_DECL
+#define MCX_PH(i)
+#define MCX_PH_COUNT
+#define MCX_PH_DUMP(kid)
+#endif
 constexpr int kMaxBins = 2048;
 constexpr uint64_t kQMask = (1ull << 56) - 1;  // quotient bits of the top tuple word
 
@@ -417,10 +434,12 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
     const uint64_t t0 = a_tile0 + blockIdx.x;
     if (t0 < a_ntiles) tile_fetch<PK>(a_arg, t0, tid0, pre);
   }
+  MCX_PH_DECL
   for (uint64_t tile = a_tile0 + blockIdx.x; tile < a_ntiles; tile += gridDim.x) {
     // (opaque: what is derived from the thread index -- LDS addresses, masks -- is recomputed per
     // tile in an instruction or two; hoisted out of the loop it was spilled to scratch)
     const int tid = (int)tid_now();
+    MCX_PH(6) MCX_PH_COUNT
     // (No barrier here: what is written before the next one -- the tile's codes and flags, the
     // zeroed counters -- was last read before the write-out's entry barrier of the previous tile;
     // what a slower wave may still be reading, the staging area and the bin bases, is next
@@ -433,6 +452,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
       if (tn < a_ntiles) tile_fetch<PK>(a_arg, tn, tid, pre);
     }
     __syncthreads();
+    MCX_PH(0)
 
     const uint32_t pl = 16u * (uint32_t)(tid + 1);
     const uint64_t Vh = inv_win64(s_inv, pl);
@@ -586,8 +606,10 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
         }
       }
     }
+    MCX_PH(1)
     BinRes<NB> res;
     bin_reserve<LDS, NB>(L, bs, out, ob0, res, !FULL);
+    MCX_PH(2)
 #pragma unroll
     for (int j = 0; j < kPosPerLane; j++) {  // sorted position goes into bits 12..24 of tle (FULL: 12..23)
       tle[j] += L.off[tle[j] & 0xfffu] << 12;  // arrival index -> sorted position
@@ -597,13 +619,16 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
       if ((j & 3) == 3) asm volatile("" : "+v"(tle[j - 3]), "+v"(tle[j - 2]), "+v"(tle[j - 1]), "+v"(tle[j]));
     }
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
+    MCX_PH(3)
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
         bin_place<W, FULL, LDS>(L, round, FULL ? (tle[j] >> 12) & 0xfffu : tle[j] >> 12, tle[j] & 0xfffu, tk[j], tle[j] >> 24);
       bin_writeout<W, ONECOL, FULL, SH, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
+      if (round == 0) { MCX_PH(4) } else { MCX_PH(5) }
     }
   }
+  MCX_PH_DUMP(0)
 
   block_add(&a.ctr->kmers, n_kmers);
   block_add(&a.ctr->contigs, n_contigs);
@@ -682,6 +707,7 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
   const uint64_t nchunks = xcd ? (uint64_t)nwin * chunks_per_seg * win_segs : chunks_per_seg * nseg_g;
   const uint64_t v0 = xcd ? blockIdx.x / 8 : blockIdx.x, vstep = xcd ? gridDim.x / 8 : gridDim.x;
   const uint32_t lmask = (1u << t_lb1) - 1u;
+  MCX_PH_DECL
   for (uint64_t v = v0; v < nchunks; v += vstep) {
     uint32_t seg;
     uint64_t start;
@@ -706,9 +732,11 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
     const uint32_t lregion = bs.mode == BIN_SUBLOCAL ? seg % bs.seg_mod : 0;  // block-uniform
     const uint32_t region = bs.region0 + lregion;
     const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? lregion * t_spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
+    MCX_PH(6) MCX_PH_COUNT
     __syncthreads();
     for (uint32_t b = tid; b < bs.nlocal + 64; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
     __syncthreads();
+    MCX_PH(0)
     const uint32_t trash = bs.nlocal + 1u + ((uint32_t)tid & 31u);
     const uint64_t *kin = in.keys + (pseg * in.seg_cap + start) * W;
     const uint8_t *ein = IN_FULL ? in.edges + pseg * in.seg_cap + start : nullptr;
@@ -783,19 +811,24 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
       atomicAdd(&L.cnt[loc[q]], 1u);
       (void)i;
     }
+    MCX_PH(1)
     BinRes<NB, T> res;
     bin_reserve<LDS, NB>(L, bs, out, ob0, res, true);
+    MCX_PH(2)
 #pragma unroll
     for (int q = 0; q < PER; q++)  // sorted position goes into the high half of loc
       loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
+    MCX_PH(3)
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int q = 0; q < PER; q++)
         bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);
       bin_writeout<W, ONECOL, false, 0, LDS>(L, round, bs, out, ob0, region, isink, n_novel, full);
+      if (round == 0) { MCX_PH(4) } else { MCX_PH(5) }
     }
   }
+  MCX_PH_DUMP(1)
   block_add(&ctr->novel, n_novel);
   if (full == 1) ctr->full = 1;
   if (full == 2) ctr->bin_over = 1;
@@ -1170,17 +1203,21 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
     }
   };
   constexpr uint64_t kStep = (uint64_t)kLdsThreads * kLdsBatch;
+  MCX_PH_DECL
   while (bi < nsub) {
     const uint32_t sub = sub0 + bi;
     const uint32_t region = sub / t.spb;  // uniform
+    MCX_PH(6) MCX_PH_COUNT
     uint64_t n = bins.counts[bi];
     if (n > bins.cap) n = bins.cap;
     const uint32_t nb = next_bin(bi + gridDim.x);
     __syncthreads();  // every thread has read the fills; the previous slice has left LDS
+    MCX_PH(0)
     if (tid == 0) bins.counts[bi] = 0;
     if (!kPrefetch) slice_fetch<W, ONECOL, kLdsThreads>(t, sub, col, tid, v, zeros_known);
     slice_to_lds<W, ONECOL, kLdsThreads>(lds, tid, v);
     __syncthreads();
+    MCX_PH(1)
 
     auto load_batch = [&](uint64_t j0, Kmer<W> (&tk)[kLdsBatch]) { load_batch_of(bi, n, j0, tk); };
     // packed tuple + region -> full key, start bucket, edge byte
@@ -1229,7 +1266,9 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
       }
     };
     if (kPrefetch && nb < nsub) run(std::true_type{}); else run(std::false_type{});
+    MCX_PH(2)
     __syncthreads();
+    MCX_PH(3)
     {  // the occurrences set aside: every lane takes one, all of them run the general probe loop
       const uint32_t nq = min(s_nq, kQueueCap);
       for (uint32_t i = tid; i < nq; i += kLdsThreads) {
@@ -1243,10 +1282,13 @@ __global__ __launch_bounds__(LdsCfg<W>::kThreads, LdsCfg<W>::kMinWaves) void k_l
       __syncthreads();
       if (tid == 0) s_nq = 0;
     }
+    MCX_PH(4)
     slice_store<W, ONECOL, kLdsThreads>(t, sub, col, tid, lds);
     if (tid == 0 && t.touch) atomicOr(&t.touch[1 + (sub >> 5)], 1u << (sub & 31u));
     bi = nb;
+    MCX_PH(5)
   }
+  MCX_PH_DUMP(2)
   block_add(&ctr->novel, n_novel);
   if (full) ctr->full = 1;
 }

@@ -85,7 +85,7 @@ def test_ctx_header_matches_oracle(mcx, orc):
 
 
 def test_host_packer_matches_the_base_codes(mcx):
-    """mcx_pack_bases (the staging path's packer, AVX2 and the portable SWAR version): codes as
+    """mcx_pack_bases (the staging path's packer: AVX-512, AVX2 and the portable SWAR version): codes as
     src/basic/dna.c:8-25, validity = one of ACGTacgt; every byte value, random mixes."""
     import ctypes as C
     import os
@@ -96,7 +96,7 @@ def test_host_packer_matches_the_base_codes(mcx):
     L.mcx_pack_bases.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(3)
     src = np.concatenate([np.arange(256, dtype=np.uint8),
-                          np.frombuffer(b"ACGTacgtNn\n\r .-*", dtype=np.uint8)[rng.integers(0, 16, 4096 - 256)]])
+                          np.frombuffer(b"ACGTacgtNn\n\r .-*", dtype=np.uint8)[rng.integers(0, 16, 4096 + 32 - 256)]])  # (an odd number of 32-byte blocks: the AVX-512 tail)
     code = np.zeros(len(src) // 16, dtype=np.uint32)
     inv = np.zeros(len(src) // 16, dtype=np.uint16)
     L.mcx_pack_bases(src.ctypes.data, len(src), code.ctypes.data, inv.ctypes.data)
@@ -113,5 +113,6 @@ def test_host_packer_matches_the_base_codes(mcx):
             "L.mcx_pack_bases.restype = None; L.mcx_pack_bases.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]; "
             "s = np.frombuffer(sys.stdin.buffer.read(), np.uint8).copy(); c = np.zeros(len(s) // 16, np.uint32); i = np.zeros(len(s) // 16, np.uint16); "
             "L.mcx_pack_bases(s.ctypes.data, len(s), c.ctypes.data, i.ctypes.data); sys.stdout.buffer.write(c.tobytes() + i.tobytes())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", prog], input=src.tobytes(), stdout=subprocess.PIPE, env=dict(os.environ, MCX_NO_AVX2="1")).stdout
-    assert out == code.tobytes() + inv.tobytes()
+    for off in ("MCX_NO_AVX2", "MCX_NO_AVX512"):   # SWAR; AVX2 where the host's default is AVX-512
+        out = subprocess.run([sys.executable, "-c", prog], input=src.tobytes(), stdout=subprocess.PIPE, env=dict(os.environ, **{off: "1"})).stdout
+        assert out == code.tobytes() + inv.tobytes(), off

@@ -29,6 +29,8 @@ for rep in range(2):
 print("; ".join(res))
 ''' % ROOT
 variants = [dict(), dict(MCX_IDLE_FLUSH="0"), dict(MCX_STAGE_THREADS="24")]
+if len(sys.argv) > 1:  # variants from the command line: "A=1,B=2" per argument ("-" = the defaults)
+    variants = [dict(kv.split("=") for kv in a.split(",")) if a != "-" else dict() for a in sys.argv[1:]]
 for env in variants:
     p = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     print(env, p.stdout.decode().strip().splitlines()[-1:], flush=True)
