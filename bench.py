@@ -435,7 +435,9 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
         del pk2
         torch.cuda.empty_cache()
     # (e) C4: k = 63 (two-word keys); C5-like: 4 colours on one GPU
-    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, 5_000_000_000, pk)
+    # (flush size: the stream positions of all steps -- the library books a device-resident stream launch with the
+    # positions it covers, 1.7x the k-mers it yields at k = 63 -- so that the build makes ONE table pass like C2's)
+    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, max(5_000_000_000, len(steps) * B * (READ_LEN + 1) + (1 << 26)), pk)
     r["workload"] = "C4: k=63 (2-word BinaryKmer), 1 colour, %d reads x %d bp per step, table %d slots, 1 GPU" % (B, READ_LEN, table_slots)
     out["other_configs"] = {"C4_k63": r}
     # (4 colours: the L1 workspace is a pool of bin sets shared by the colours, sized here to hold all 20 steps,

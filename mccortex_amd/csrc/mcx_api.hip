@@ -17,6 +17,7 @@
 #include <memory>
 #include <vector>
 #include <thread>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <condition_variable>
@@ -168,6 +169,20 @@ struct mcx_graph {
   // the group that has waited LONGEST may hold per its share -- the bound the segments' capacity is sized for
   uint64_t idle_base = 0;
   std::vector<uint64_t> idle_mark;
+  // Settled launches (snap_*): `pending` counts a stream launch with the number of START POSITIONS it covers, an
+  // upper bound of the tuples it yields (20 % above the truth for 150 bp reads at k = 31, 72 % at k = 63: a flush
+  // -- a whole table pass -- came that much too early).  After every such launch the device's k-mer counter is
+  // copied to a pinned ring slot behind the kernel; when the copy has landed (event query, never a wait) the
+  // launches up to it are "settled": what they really yielded is known, and the difference is taken off `pending`.
+  static constexpr uint32_t kSnap = 32;
+  struct Snap { uint64_t cum_ub; bool is_base; hipEvent_t ev; };
+  unsigned long long *h_snap = nullptr;  // pinned [kSnap]: the counter as of slot i
+  Snap snap[kSnap] = {};
+  uint32_t snap_head = 0, snap_tail = 0;  // ring: [tail, head) in flight
+  uint64_t snap_base = 0;                 // the counter when the L1 bins were last empty
+  bool snap_base_known = true;            // (a new graph: counters and bins are zero)
+  uint64_t snap_cum_ub = 0;               // start positions handed to stream launches since then
+  uint64_t snap_slack = 0;                // of those, known not to have yielded a tuple (already taken off `pending`)
   // ---- build --intersect (ctx_build.c:341-363,384-413) ----
   int hidden = -1;              // colour that holds the intersection graphs' edges, or -1
   int ncols_vis = 0;            // colours that are exported / scanned (ncols, or ncols - 1)
@@ -196,6 +211,7 @@ static OwnerSpec owner_spec(const mcx_graph *g)
 
 static int flush_deferred(mcx_graph *g);
 static void free_defer(mcx_graph *g);
+static void snap_push(mcx_graph *g, bool is_base);
 static void sets_release(mcx_graph *g)
 {
   std::fill(g->set_colour.begin(), g->set_colour.end(), -1);
@@ -381,6 +397,10 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
   if (g->d_ctr) (void)hipFree(g->d_ctr);
   if (g->d_readstrt) (void)hipFree(g->d_readstrt);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
+  if (g->h_snap) {
+    (void)hipHostFree(g->h_snap);
+    for (uint32_t i = 0; i < mcx_graph::kSnap; i++) (void)hipEventDestroy(g->snap[i].ev);
+  }
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -403,6 +423,7 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   g->pending = g->pending_l2 = 0;  // buffered tuples are discarded with the table
   g->idle_next = 0; g->idle_base = 0; g->idle_mark.clear();
   sets_release(g);
+  snap_push(g, true);
   return MCX_OK;
 }
 
@@ -669,7 +690,7 @@ static int ensure_defer(mcx_graph *g)
       tcap = strtoull(e, nullptr, 10);
     } else {
       // Default flush size.  Every flush streams the whole table through LDS once (2 x 16 B per
-      // slot), so the more occurrences a flush applies the better: up to 64 per slot, within 30 %
+      // slot), so the more occurrences a flush applies the better: up to 64 per slot, within 40 %
       // of the HBM that is free once the table stands (the part has 288 GB: a 16 GiB table leaves
       // room for 8 G occurrences per flush), never below 1 M.
       size_t fr = 0, tot = 0;
@@ -677,7 +698,7 @@ static int ensure_defer(mcx_graph *g)
       // L1 segments (x 1.06) + the group's sub-table bins; a shard of a multi-GPU table splits on arrival
       // and needs sub-table bins for the whole table (x 1.25) as well
       const uint64_t per_tuple = 8ull * g->W * (g->t.lbo ? 240 : 118) / 100 + 1;
-      const uint64_t by_mem = (uint64_t)((double)fr * 0.30) / per_tuple;
+      const uint64_t by_mem = (uint64_t)((double)fr * 0.40) / per_tuple;
       tcap = std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(64 * g->t.nslots, by_mem), 1ull << 33), 1ull << 20);
     }
   }
@@ -795,6 +816,7 @@ static int flush_deferred(mcx_graph *g)
   g->pending_l2 = 0;
   g->idle_next = 0; g->idle_base = 0; g->idle_mark.clear();
   sets_release(g);
+  snap_push(g, true);
   return MCX_OK;
 }
 
@@ -802,11 +824,62 @@ static int flush_deferred(mcx_graph *g)
 // that is bound to the colour and has room, else a free set, else a flush (which frees them all).
 // `ub` beyond a set's capacity is accepted for an EMPTY set (callers that only know an upper bound
 // of what a device-side fill holds): a segment that overflows falls back to the direct insert.
+// settled launches (mcx_graph::snap_*): record the k-mer counter behind what has been enqueued so far
+static void snap_push(mcx_graph *g, bool is_base)
+{
+  if (g->group || g->nsets != 1) return;
+  if (!g->h_snap) {
+    if (hipHostMalloc((void **)&g->h_snap, sizeof(unsigned long long) * mcx_graph::kSnap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g->h_snap = nullptr; return; }
+    for (uint32_t i = 0; i < mcx_graph::kSnap; i++)
+      if (hipEventCreateWithFlags(&g->snap[i].ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(g->h_snap); g->h_snap = nullptr; return; }
+  }
+  if (is_base) {  // the bins are empty: what is in flight describes launches that no longer count
+    g->snap_tail = g->snap_head;
+    g->snap_base_known = false;
+    g->snap_cum_ub = 0;
+    g->snap_slack = 0;
+  }
+  if (g->snap_head - g->snap_tail >= mcx_graph::kSnap) return;  // ring full: this launch settles with a later one
+  const uint32_t i = g->snap_head % mcx_graph::kSnap;
+  if (hipMemcpyAsync(&g->h_snap[i], &g->d_ctr->kmers, sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+      hipEventRecord(g->snap[i].ev, g->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+  g->snap[i].cum_ub = g->snap_cum_ub;
+  g->snap[i].is_base = is_base;
+  g->snap_head++;
+}
+
+// ... and take what the settled launches did not yield off the books (never waits)
+static void snap_poll(mcx_graph *g)
+{
+  if (!g->h_snap || g->group || g->nsets != 1) return;
+  while (g->snap_tail != g->snap_head) {
+    const uint32_t i = g->snap_tail % mcx_graph::kSnap;
+    if (hipEventQuery(g->snap[i].ev) != hipSuccess) { (void)hipGetLastError(); break; }
+    const uint64_t v = g->h_snap[i];
+    if (g->snap[i].is_base) {
+      g->snap_base = v;
+      g->snap_base_known = true;
+    } else if (g->snap_base_known && g->idle_mark.empty() && !g->set_pending.empty()) {
+      // (once an idle flush has marked a region group the books are kept in its units: flush_if_device_idle)
+      const uint64_t yielded = std::min<uint64_t>(g->snap[i].cum_ub, v - g->snap_base);  // (other entries count k-mers too: still an upper bound)
+      const uint64_t slack = g->snap[i].cum_ub - yielded;
+      if (slack > g->snap_slack) {
+        const uint64_t d = slack - g->snap_slack;
+        g->snap_slack = slack;
+        g->pending -= std::min(g->pending, d);
+        g->set_pending[0] -= std::min(g->set_pending[0], d);
+      }
+    }
+    g->snap_tail++;
+  }
+}
+
 static int defer_reserve(mcx_graph *g, int colour, uint64_t ub, int *set_out = nullptr)
 {
   if (set_out) *set_out = 0;
   int rc = ensure_defer(g);
   if (rc != MCX_OK || !g->defer) return rc;
+  snap_poll(g);
   for (int pass = 0; pass < 2; pass++) {
     int free_set = -1;
     for (uint32_t s = 0; s < g->nsets; s++) {
@@ -853,6 +926,7 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     return MCX_OK;
   }
   // pieces of at most defer_tuples start positions (an upper bound of the tuples they yield)
+  snap_poll(g);
   for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
     // a piece goes to ONE set: what is left of the colour's current set, or a fresh set
     uint64_t room = g->set_cap;
@@ -869,6 +943,8 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     BinOut out = l1_out(g, set);
     DISPATCH_WC(g, launch_bin_region_stream, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
+    g->snap_cum_ub += hi - lo;
+    snap_push(g, false);
     lo = hi;
   }
   return MCX_OK;
@@ -1597,16 +1673,21 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
     memcpy(hinv, carry_inv, sizeof(carry_inv));
     // position p of the chunk (p >= kCarry): base of a read, or a separator
     const int T = stage_threads();
+    // The threads take runs of kRun blocks from a shared counter (not a fixed share each): on a host that is shared
+    // with other jobs a thread that loses its core for a moment would otherwise hold up the whole chunk.
+    std::atomic<uint64_t> next_run{0};
     auto work = [&](int ti) {
-      constexpr uint64_t BLK = 16384;
+      constexpr uint64_t BLK = 16384, kRun = 16;
       uint8_t buf[BLK];
       const uint64_t nblk = (Lp + BLK - 1) / BLK;
-      const uint64_t b_lo = nblk * (uint64_t)ti / (uint64_t)T, b_hi = nblk * (uint64_t)(ti + 1) / (uint64_t)T;
       // the staged offsets of this thread's share of the reads (k_read_flags_packed reads them)
       for (uint64_t q = nwhole * (uint64_t)ti / (uint64_t)T, qe = nwhole * (uint64_t)(ti + 1) / (uint64_t)T; q < qe; q++) hoff[q] = start_of(q);
-      // first read that reaches into the thread's range of positions
+      for (;;) {
+      const uint64_t b_lo = next_run.fetch_add(kRun, std::memory_order_relaxed), b_hi = std::min(nblk, b_lo + kRun);
+      if (b_lo >= nblk) break;
+      // first read that reaches into the run's range of positions
       uint64_t i = 0;
-      if (piece_of < 0 && b_lo < b_hi && nwhole) {
+      if (piece_of < 0 && nwhole) {
         const uint64_t p0 = kCarry + b_lo * BLK;
         uint64_t lo = 0, hi = nwhole;  // last read that starts at or before p0
         while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (start_of(mid) <= p0) lo = mid; else hi = mid; }
@@ -1635,6 +1716,7 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
           }
         }
         pack_block(buf, (size_t)n, hcode + p0 / 16, hinv + p0 / 16);
+      }
       }
     };
     if (T > 1 && Lp >= (1u << 20)) {
