@@ -304,7 +304,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   const uint32_t lb1_max = lbo ? std::min<uint32_t>(9, 11 - lbo) : 9;  // shards x regions <= 2048 sender bins
   while (lb1 < lb1_max && (2ull << lb1) <= nsub) lb1++;             // up to 512 regions ...
   while (lb1 < 11 && ((nsub + (1ull << lb1) - 1) >> lb1) > (uint64_t)kMaxBins) lb1++;  // ... more for huge tables
-  if (const char *e = getenv("MCX_LB1")) { const uint32_t v = (uint32_t)atoi(e); if (!lbo && v >= lb1 && v <= 11) lb1 = v; }  // experiments
+  if (const char *e = getenv("MCX_LB1")) { const uint32_t v = (uint32_t)atoi(e); if (!lbo && v >= 6 && v <= 11 && ((nsub + (1ull << v) - 1) >> v) <= (uint64_t)kMaxBins && ((nsub + (1ull << v) - 1) >> v) >= 1) lb1 = v; }  // experiments
   if (lbo && lb1 + lbo > 11) {
     // (owner, region) bins of the sender kernel: at most 2048, and mix_bucket() takes its bits below
     // the lb1 + lbo <= 12 it assumes.  Per shard that is 2048 / shards regions x 2048 sub-tables.
@@ -543,7 +543,7 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   // 8192 tuples (MCX_SPLIT_T=256 for the old geometry)
   constexpr bool kWide = W == 1 && !IN_FULL;
   static const bool wide = kWide && [] { const char *e = getenv("MCX_SPLIT_T"); return !e || atoi(e) == 512; }();
-  const bool use_wide = wide && bs.nlocal <= 512;
+  const bool use_wide = wide && bs.nlocal <= 1024;
   const uint64_t tile = use_wide ? 512 * 16 : kTile;
   const uint64_t nchunks = (in.seg_cap + tile - 1) / tile * in.nseg;
   if (!nchunks) return;
@@ -556,6 +556,7 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
     allow_lds(k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD>, sizeof(BinLds<W, 1024, false>));
     allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD>, sizeof(BinLds<W, kMaxBins, false>));
     if constexpr (kWide) allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD, 512>, sizeof(BinLds<W, 512, false, GeoW>));
+    if constexpr (kWide) allow_lds(k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD, 512>, sizeof(BinLds<W, 1024, false, GeoW>));
     once = true;
   }
   SpanGuard sp(g, "k_tuples_bin");
@@ -563,7 +564,10 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   if constexpr (kWide) {
     if (use_wide) {
       const dim3 gridw((unsigned)std::min<uint64_t>(nchunks, g->grid_split ? gmax : gmax / 2));
-      hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD, 512>), gridw, dim3(512), sizeof(BinLds<W, 512, false, GeoW>), g->stream, in, bs, out, is, g->d_ctr);
+      if (bs.nlocal <= 512)
+        hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD, 512>), gridw, dim3(512), sizeof(BinLds<W, 512, false, GeoW>), g->stream, in, bs, out, is, g->d_ctr);
+      else
+        hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD, 512>), gridw, dim3(512), sizeof(BinLds<W, 1024, false, GeoW>), g->stream, in, bs, out, is, g->d_ctr);
       return;
     }
   }

@@ -388,20 +388,6 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
   probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
 }
 
-// A packed tuple of region `region` that does not fit its bin: lock-free insert into the HBM table (the rare path
-// of the register-to-HBM scatter below; bin_writeout carries the same code inline).
-template <int W, bool ONECOL>
-__device__ __noinline__ void scatter_fallback(const InsertSink<W, ONECOL> &isink, uint32_t region, Kmer<W> tq, uint32_t &novel, uint32_t &full)
-{
-  const uint32_t e = (uint32_t)(tq.w[0] >> 56);
-  const Kmer<W> qq = tuple_q<W>(tq);
-  table_mark_written(isink.t);
-  const Kmer<W> key = key_unquot<W>(qq, lbq_of(isink.t), r_of<W>(isink.t, region, qq));
-  const uint64_t slot = key_slot<W>(isink.t, key);
-  const uint64_t cur = *key_ptr_t<W, ONECOL>(isink.t, slot);
-  probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);
-}
-
 // ---------------------------------------------------------------------------
 // 1. reads -> bins.  FULL = owner bins (key words + edge byte, nparts bins);
 //    !FULL = region bins (packed tuples): SH 0 of an unsharded table, SH 1 of this shard (keys of
@@ -634,31 +620,6 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
     }
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
     MCX_PH(3)
-#ifdef MCX_SCATTER
-    // EXPERIMENT (tools/variants.sh): no LDS staging of the sorted tile -- every lane stores its 16 tuples straight
-    // from registers to where the sorted write-out would have put them (bin base + sorted position).  Saves the
-    // placement and the write-out loop (about a quarter of the kernel's instructions and two barriers per tile);
-    // costs 64 separate 8-byte store requests per wave instruction instead of runs of ~8 neighbours.
-    if (!FULL && SH == 0) {
-      __syncthreads();  // the bases of all bins are published
-      const uint32_t n_tile = L.off[bs.nlocal];
-#pragma unroll
-      for (int j = 0; j < kPosPerLane; j++) {
-        const uint32_t p = tle[j] >> 12, b = tle[j] & 0xfffu;
-        if (p < n_tile) {  // (positions without a k-mer were ranked beyond the tile)
-          const unsigned long long gb = L.gbase[b];
-          if (p < (uint32_t)(gb >> 48)) {
-            uint64_t *kd = out.keys + ((gb + p) & kDstMask) * W;
-            kd[0] = tk[j].w[0];
-            if (W == 2) kd[1] = tk[j].w[W - 1];
-          } else {
-            scatter_fallback<W, ONECOL>(isink, b, tk[j], n_novel, full);
-          }
-        }
-      }
-      MCX_PH(4)
-    } else
-#endif
     for (int round = 0; round < kRounds; round++) {
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
@@ -746,44 +707,25 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
   const uint64_t nchunks = xcd ? (uint64_t)nwin * chunks_per_seg * win_segs : chunks_per_seg * nseg_g;
   const uint64_t v0 = xcd ? blockIdx.x / 8 : blockIdx.x, vstep = xcd ? gridDim.x / 8 : gridDim.x;
   const uint32_t lmask = (1u << t_lb1) - 1u;
-  // The fills of a window's segments are fetched ONCE per window into LDS (a block meets a window for dozens of
-  // chunks).  Until round 4 every chunk started with a dependent global load of its segment's fill -- a memory
-  // round trip before the tile's tuple loads could be issued, and all a chunk beyond the fill (a quarter of them
-  // when the bins are 3 / 4 full) ever did: 10 % of the kernel (profiles/r04_phases.md).
-  constexpr uint32_t kWinFills = 512;
-  __shared__ unsigned long long s_wfill[kWinFills];
-  const bool win_lds = xcd && win_segs <= kWinFills && in.counts;
-  uint32_t cur_win = 0xFFFFFFFFu;
   MCX_PH_DECL
   for (uint64_t v = v0; v < nchunks; v += vstep) {
     uint32_t seg;
-    uint64_t start, cnt;
+    uint64_t start;
     if (xcd) {
       const uint64_t per_win = chunks_per_seg * win_segs;
       const uint32_t win = (uint32_t)(v / per_win);
       const uint64_t rem = v % per_win;
       const uint32_t s = (uint32_t)(rem % win_segs);  // segment-interleaved inside the window
       const uint32_t rgi = win * kWin + s % kWin;      // region index inside this XCD's group
-      if (win_lds && win != cur_win) {                 // (uniform)
-        __syncthreads();
-        for (uint32_t s2 = tid; s2 < win_segs; s2 += kThreads) {
-          const uint32_t rgi2 = win * kWin + s2 % kWin;
-          s_wfill[s2] = rgi2 < bins_g ? (unsigned long long)in.counts[tuple_seg_phys(in, (s2 / kWin) * bs.seg_mod + group + 8 * rgi2)] : 0ULL;
-        }
-        __syncthreads();
-        cur_win = win;
-      }
       if (rgi >= bins_g) continue;                     // uniform
       seg = (s / kWin) * bs.seg_mod + group + 8 * rgi; // replica-major segment index
       start = (rem / win_segs) * kTile;
-      cnt = win_lds ? (uint64_t)s_wfill[s] : in.seg_cap;
     } else {
       seg = (uint32_t)(v % nseg_g);  // segment-interleaved
       start = (v / nseg_g) * kTile;
-      cnt = in.seg_cap;
     }
     const uint64_t pseg = tuple_seg_phys(in, seg);
-    if (!win_lds && in.counts) cnt = (uint64_t)in.counts[pseg];
+    uint64_t cnt = in.counts ? (uint64_t)in.counts[pseg] : in.seg_cap;
     if (cnt > in.seg_cap) cnt = in.seg_cap;
     if (start >= cnt) continue;  // uniform across the block
     const uint32_t n = (uint32_t)min((uint64_t)kTile, cnt - start);
@@ -791,6 +733,10 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
     const uint32_t region = bs.region0 + lregion;
     const uint32_t ob0 = (bs.mode == BIN_SUBLOCAL ? lregion * t_spb : 0) + (blockIdx.x % bs.rep) * bs.nout;
     MCX_PH(6) MCX_PH_COUNT
+    __syncthreads();
+    for (uint32_t b = tid; b < bs.nlocal + 64; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
+    __syncthreads();
+    MCX_PH(0)
     const uint32_t trash = bs.nlocal + 1u + ((uint32_t)tid & 31u);
     const uint64_t *kin = in.keys + (pseg * in.seg_cap + start) * W;
     const uint8_t *ein = IN_FULL ? in.edges + pseg * in.seg_cap + start : nullptr;
@@ -837,11 +783,6 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
       }
     }
     }
-    // (the tile's loads are on their way: the counters are zeroed and the barriers passed under them)
-    __syncthreads();
-    for (uint32_t b = tid; b < bs.nlocal + 64; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
-    __syncthreads();
-    MCX_PH(0)
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       const uint32_t i = (uint32_t)q * kThreads + tid;
