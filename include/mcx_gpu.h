@@ -340,6 +340,15 @@ int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_recs, const
  * for every character that is not one of ACGTacgt). */
 void mcx_pack_bases(const uint8_t *src, uint64_t n, uint32_t *code, uint16_t *inv);
 
+/* The one-pass packer of the same staging path (round 4), exported for its test: the reads
+ * bases[off[i] .. off[i+1]) as the stream "128 separators, read 0, separator, read 1, separator, ...,
+ * separators up to a multiple of 64 positions" -> code[p / 16], inv[p / 16]; returns the number of
+ * positions (0: cap_pos too small, or fused != 0 on a host without AVX-512).  fused == 0 assembles
+ * the ASCII stream and packs it with mcx_pack_bases: both must give the same words.  Replaces the
+ * per-read copy of the reference's workers (src/basic/async_read_io.c:283-310 hands whole reads over). */
+uint64_t mcx_pack_reads_host(const uint8_t *bases, const uint64_t *off, uint64_t nreads, uint32_t *code,
+                             uint16_t *inv, uint64_t cap_pos, int fused);
+
 /* Wait for all submitted work; reports MCX_ERR_FULL if any insert ran out of
  * slots (the reference dies with "Hash table is full"). */
 int mcx_graph_sync(mcx_graph *g);

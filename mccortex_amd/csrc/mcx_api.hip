@@ -131,6 +131,12 @@ struct mcx_graph {
   uint8_t *h_stage[2] = {nullptr, nullptr};
   uint8_t *d_stage[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
+  // the packed host entry copies on a stream of its own (cstream), so that the graph's stream only holds compute:
+  // ev_copy[b] = chunk b has arrived; ev_wait0 / ev_wait1[b] bracket the compute stream's wait for it (timing events:
+  // their distance is how long the device sat idle waiting for PCIe -- add_reads_packed)
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_wait0[2] = {nullptr, nullptr}, ev_wait1[2] = {nullptr, nullptr};
+  bool ev_wait_used[2] = {false, false};
   uint64_t stage_alloc = 0;
   int cur = 0;
   int grid = 0;
@@ -381,10 +387,14 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
   if (!g) return;
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->cstream) { (void)hipStreamSynchronize(g->cstream); (void)hipStreamDestroy(g->cstream); }
   for (int i = 0; i < 2; i++) {
     if (g->h_stage[i]) (void)hipHostFree(g->h_stage[i]);
     if (g->d_stage[i]) (void)hipFree(g->d_stage[i]);
     if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+    if (g->ev_copy[i]) (void)hipEventDestroy(g->ev_copy[i]);
+    if (g->ev_wait0[i]) (void)hipEventDestroy(g->ev_wait0[i]);
+    if (g->ev_wait1[i]) (void)hipEventDestroy(g->ev_wait1[i]);
   }
   free_defer(g);
   for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -1495,7 +1505,7 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) static void pack_block_avx5
   const __m512i m3 = _mm512_set1_epi8(3), mdf = _mm512_set1_epi8((char)0xDF), m0f = _mm512_set1_epi8(0x0F);
   const __m512i w1 = _mm512_set1_epi16(0x0104), w2 = _mm512_set1_epi32(0x00010010);
   const __m128i bswap = _mm_setr_epi8(3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12);
-  const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0));
+  const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8((char)0xFF /* never equal: a NUL byte is no base */, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0));
   const __m512i rev = _mm512_broadcast_i32x4(_mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0));
   size_t i = 0;
   for (; i + 64 <= n; i += 64) {
@@ -1512,6 +1522,88 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) static void pack_block_avx5
 }
 #endif
 
+// ---- reads -> packed stream in ONE pass (no intermediate ASCII block) ------------------------------
+// What add_reads_packed() stages is the virtual stream "read, separator, read, separator, ..." in packed form.
+// Until round 4 a staging thread first assembled 16 KiB of that stream as ASCII (a memcpy per read) and then packed
+// the block: two passes over every base and a libc call per 150-base read -- 3.5 GB/s of bases per core, and the
+// hosts of the GPU boxes give a job 16 cores' worth of time (cgroup cpu.max).  Here the reads are packed straight
+// from where they lie (pack_reads_avx512).
+struct PackReads {
+  const uint8_t *bases;  // all reads, concatenated
+  const uint64_t *off;   // off[r0 + i] .. off[r0 + i + 1]: read i of the chunk
+  uint64_t r0, nreads;   // reads of the chunk (a piece of one long read: nreads = 1 with piece_from / piece_len)
+  uint64_t pos0;         // position of the first base of read 0 (kCarry)
+  bool piece;            // the chunk holds `piece_len` bases from bases + piece_from (and a separator if there is room)
+  uint64_t piece_from, piece_len;
+  uint64_t start_of(uint64_t i) const { return piece ? pos0 : pos0 + (off[r0 + i] - off[r0]) + i; }
+  uint64_t len_of(uint64_t i) const { return piece ? piece_len : off[r0 + i + 1] - off[r0 + i]; }
+  const uint8_t *ptr_of(uint64_t i) const { return piece ? bases + piece_from : bases + off[r0 + i]; }
+};
+
+#if defined(__x86_64__)
+// positions [p_lo, p_hi) of the chunk's stream (both multiples of 64) -> code[p / 16], inv[p / 16].
+// The reads lie back to back in `bases`, so the 64 positions of a block are 64 - m CONSECUTIVE source bytes with m
+// separators dropped in where reads end: one load, one byte-expand under the mask of the non-separator lanes
+// (vpexpandb, AVX-512 VBMI2) onto a vector of separators, then the same ~17 micro-ops as pack_block_avx512.  The
+// only per-read work is one bit of the separator mask (150-base reads: 0.42 per block).
+__attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi2,popcnt"))) static void pack_reads_avx512(const PackReads &R, uint64_t p_lo, uint64_t p_hi, uint32_t *code, uint16_t *inv)
+{
+  const __m512i m3 = _mm512_set1_epi8(3), mdf = _mm512_set1_epi8((char)0xDF), m0f = _mm512_set1_epi8(0x0F), nl = _mm512_set1_epi8('\n');
+  const __m512i w1 = _mm512_set1_epi16(0x0104), w2 = _mm512_set1_epi32(0x00010010);
+  const __m128i bswap = _mm_setr_epi8(3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12);
+  const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8((char)0xFF, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0));
+  const __m512i rev = _mm512_broadcast_i32x4(_mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0));
+  constexpr uint64_t kNever = ~0ULL;
+  const uint64_t n = R.nreads;
+  // the read that holds position p_lo or whose separator it is (reads before it end before p_lo), and the source
+  // byte that belongs at p_lo (reads are contiguous: position - pos0 - separators so far)
+  uint64_t i = 0;
+  if (n) {
+    uint64_t lo = 0, hi = n;
+    while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (R.start_of(mid) <= p_lo) lo = mid; else hi = mid; }
+    i = lo;
+  }
+  const uint64_t end_pos = n ? R.start_of(n - 1) + R.len_of(n - 1) + 1 : R.pos0;  // first position behind the last separator
+  uint64_t next_sep = n ? R.start_of(i) + R.len_of(i) : kNever;
+  while (next_sep < p_lo) { i++; next_sep = i < n ? R.start_of(i) + R.len_of(i) : kNever; }  // (p_lo behind the last read)
+  const uint8_t *src = n ? R.ptr_of(0) + (std::min(p_lo, end_pos) - R.pos0 - std::min(i, n)) : nullptr;
+  for (uint64_t P = p_lo; P < p_hi; P += 64) {
+    uint64_t sepm = 0;  // lanes that hold a separator
+    while (next_sep < P + 64) {
+      sepm |= 1ULL << (next_sep - P);
+      i++;
+      next_sep = i < n ? R.start_of(i) + R.len_of(i) : kNever;
+    }
+    if (P + 64 > end_pos) sepm |= end_pos <= P ? ~0ULL : ~0ULL << (end_pos - P);  // padding behind the last read
+    if (P < R.pos0) sepm |= R.pos0 >= P + 64 ? ~0ULL : (1ULL << (R.pos0 - P)) - 1;  // (the carry's positions: not ours)
+    const unsigned nsrc = 64u - (unsigned)__builtin_popcountll(sepm);
+    __m512i v = nl;
+    if (nsrc) {
+      const __m512i x = _mm512_maskz_loadu_epi8(nsrc == 64 ? ~0ULL : (1ULL << nsrc) - 1, (const void *)src);
+      v = _mm512_mask_expand_epi8(nl, (__mmask64)~sepm, x);
+      src += nsrc;
+    }
+    const __m512i t = _mm512_ternarylogic_epi64(_mm512_srli_epi16(v, 1), _mm512_srli_epi16(v, 2), m3, 0x28);  // (a ^ b) & c
+    const __m512i byt = _mm512_madd_epi16(_mm512_maddubs_epi16(t, w1), w2);  // 32-bit lanes: four bases, the first on top
+    _mm_storeu_si128((__m128i *)(code + P / 16), _mm_shuffle_epi8(_mm512_cvtepi32_epi8(byt), bswap));
+    const __m512i u = _mm512_shuffle_epi8(_mm512_and_si512(v, mdf), rev);   // upper-cased, each 16-byte lane reversed
+    const uint64_t bad = ~(uint64_t)_mm512_cmpeq_epi8_mask(_mm512_shuffle_epi8(lut, _mm512_and_si512(u, m0f)), u);
+    memcpy(inv + P / 16, &bad, 8);
+  }
+}
+#endif
+
+static bool pack_reads_available()
+{
+#if defined(__x86_64__)
+  static const bool ok = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512vbmi2") &&
+                         !getenv("MCX_NO_AVX512") && !getenv("MCX_NO_AVX2") && !(getenv("MCX_FUSED_PACK") && atoi(getenv("MCX_FUSED_PACK")) == 0);
+  return ok;
+#else
+  return false;
+#endif
+}
+
 // n is a multiple of 32
 static void pack_block(const uint8_t *src, size_t n, uint32_t *code, uint16_t *inv)
 {
@@ -1522,6 +1614,40 @@ static void pack_block(const uint8_t *src, size_t n, uint32_t *code, uint16_t *i
   if (level == 1) { pack_block_avx2(src, n, code, inv); return; }
 #endif
   for (size_t i = 0; i < n; i += 16) pack16_swar(src + i, code + i / 16, inv + i / 16);
+}
+
+// test hook: the reads as the stream "128 separators, read, separator, read, separator, ..., padding to a multiple of 64"
+// -> code[p / 16], inv[p / 16] for p < the returned number of positions; fused != 0: the one-pass packer (returns 0 if
+// this host cannot run it), else assemble the ASCII stream and pack it block by block
+extern "C" uint64_t mcx_pack_reads_host(const uint8_t *bases, const uint64_t *off, uint64_t nreads, uint32_t *code, uint16_t *inv, uint64_t cap_pos, int fused)
+{
+  const uint64_t L = nreads ? off[nreads] - off[0] + nreads : 0, total = kCarry + ((L + 63) & ~63ull);
+  if (total > cap_pos) return 0;
+  if (fused) {
+    if (!pack_reads_available()) return 0;
+#if defined(__x86_64__)
+    uint8_t sep[kCarry];
+    memset(sep, '\n', sizeof(sep));
+    pack_block(sep, (size_t)kCarry, code, inv);
+    const PackReads PR{bases, off, 0, nreads, kCarry, false, 0, 0};
+    // in uneven pieces, as the staging threads take them
+    uint64_t p = kCarry;
+    for (uint64_t step = 64; p < total; step = total > (1u << 24) ? (1u << 18) : step * 3 % 8191 / 64 * 64 + 64) {
+      const uint64_t q = std::min(total, p + step);
+      pack_reads_avx512(PR, p, q, code, inv);
+      p = q;
+    }
+#endif
+    return total;
+  }
+  std::vector<uint8_t> txt(total, (uint8_t)'\n');
+  for (uint64_t i = 0, p = kCarry; i < nreads; i++) {
+    const uint64_t len = off[i + 1] - off[i];
+    memcpy(txt.data() + p, bases + off[i], len);
+    p += len + 1;
+  }
+  pack_block(txt.data(), (size_t)total, code, inv);
+  return total;
 }
 
 extern "C" void mcx_pack_bases(const uint8_t *src, uint64_t n, uint32_t *code, uint16_t *inv)
@@ -1542,6 +1668,15 @@ static int stage_threads()
   return n;
 }
 
+// where the host entry's wall clock goes (MCX_STAGE_TIMING=1: printed when the process ends)
+struct StageTiming {
+  double wait = 0, prep = 0, pack = 0, submit = 0; uint64_t chunks = 0, flushes = 0;
+  ~StageTiming() { if (chunks && getenv("MCX_STAGE_TIMING")) fprintf(stderr, "[stage] %llu chunks: wait for buffer %.1f ms, prepare %.1f ms, pack %.1f ms, copy + launches %.1f ms (%llu background flushes)\n",
+                                          (unsigned long long)chunks, wait * 1e3, prep * 1e3, pack * 1e3, submit * 1e3, (unsigned long long)flushes); }
+};
+static StageTiming g_stage_timing;
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // Host-fed builds: when the device has caught up with the host (nothing queued on the graph's stream
 // at the moment a packed chunk is about to be copied) the host is the bottleneck -- parsing, packing,
 // PCIe -- and the device would sit idle until the last batch, then flush everything while the host
@@ -1552,7 +1687,7 @@ static int stage_threads()
 // once was tried first: 15 ms during which the two staging buffers run dry and the HOST waits --
 // 35.6 -> 27 G k-mers/s.)  A device that is the bottleneck is never idle here and keeps its large
 // flushes.  One-colour graphs on one device only; MCX_IDLE_FLUSH=0 switches it off.
-static int flush_if_device_idle(mcx_graph *g)
+static int flush_if_device_idle(mcx_graph *g, int starved = -1 /* -1: ask the stream; 0 / 1: the caller knows (add_reads_packed) */)
 {
   // 2: take every chance (tests); 3: every chance once 3/4 of the flush size is buffered (tests: a device that was
   // busy first, so that the idle flushes start on a nearly full workspace)
@@ -1566,9 +1701,11 @@ static int flush_if_device_idle(mcx_graph *g)
   const uint32_t ngroups = (g->b1 + G - 1) / G;
   // worth a group's table pass: its share of 1 / 8 of the flush size, at least 16 M occurrences
   if (mode != 2 && g->pending / ngroups < std::max<uint64_t>(g->defer_tuples / 8 / ngroups, 1ull << 24)) return MCX_OK;
-  if (mode != 2 && hipStreamQuery(g->stream) != hipSuccess) { (void)hipGetLastError(); return MCX_OK; }  // busy: the device is not waiting for us
+  if (mode != 2 && starved == 0) return MCX_OK;
+  if (mode != 2 && starved < 0 && hipStreamQuery(g->stream) != hipSuccess) { (void)hipGetLastError(); return MCX_OK; }  // busy: the device is not waiting for us
   const uint32_t r0 = g->idle_next * G < g->b1 ? g->idle_next * G : 0;
   g->idle_next = (r0 / G + 1) % ngroups;
+  g_stage_timing.flushes++;
   const uint32_t ng = std::min(G, g->b1 - r0);
   const int colour = g->set_colour[0];
   g->l2_off = 0;
@@ -1608,7 +1745,11 @@ static int ensure_stage(mcx_graph *g)
     HIP_TRY(hipHostMalloc((void **)&g->h_stage[i], bytes, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&g->d_stage[i], bytes));
     HIP_TRY(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g->ev_copy[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&g->ev_wait0[i]));
+    HIP_TRY(hipEventCreate(&g->ev_wait1[i]));
   }
+  HIP_TRY(hipStreamCreateWithFlags(&g->cstream, hipStreamNonBlocking));
   g->stage_alloc = bytes;
   return MCX_OK;
 }
@@ -1638,7 +1779,9 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
   while (r < nreads) {
     const int b = g->cur;
     g->cur ^= 1;
+    const double tq0 = now_s();
     HIP_TRY(hipEventSynchronize(g->ev[b]));  // previous use of this buffer finished
+    const double tq1 = now_s();
     uint8_t *hs = g->h_stage[b];
     uint32_t *hcode = reinterpret_cast<uint32_t *>(hs);
     uint16_t *hinv = reinterpret_cast<uint16_t *>(hs + inv_at);
@@ -1723,20 +1866,57 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
       }
       }
     };
+    // one pass from the reads to the packed chunk where the host has AVX-512 (pack_reads_avx512); else assemble + pack
+    const PackReads PR{bases, off, r0, piece_of >= 0 ? 1 : nwhole, kCarry, piece_of >= 0, piece_from, piece_data};
+    auto work_fused = [&](int ti) {
+#if defined(__x86_64__)
+      constexpr uint64_t BLK = 16384, kRun = 16;
+      const uint64_t nblk = (Lp + BLK - 1) / BLK;
+      for (uint64_t q = nwhole * (uint64_t)ti / (uint64_t)T, qe = nwhole * (uint64_t)(ti + 1) / (uint64_t)T; q < qe; q++) hoff[q] = start_of(q);
+      for (;;) {
+        const uint64_t b_lo = next_run.fetch_add(kRun, std::memory_order_relaxed), b_hi = std::min(nblk, b_lo + kRun);
+        if (b_lo >= nblk) break;
+        pack_reads_avx512(PR, kCarry + b_lo * BLK, std::min(kCarry + b_hi * BLK, kCarry + Lp), hcode, hinv);
+      }
+#else
+      (void)ti;
+#endif
+    };
+    const bool fused = pack_reads_available();
+    const double tq2 = now_s();
     if (T > 1 && Lp >= (1u << 20)) {
-      StagePool::get().run(T, work);
+      if (fused) StagePool::get().run(T, work_fused); else StagePool::get().run(T, work);
     } else {
-      for (int ti = 0; ti < T; ti++) work(ti);  // small chunk: every share on this thread
+      for (int ti = 0; ti < T; ti++) { if (fused) work_fused(ti); else work(ti); }  // small chunk: every share on this thread
     }
+    const double tq3 = now_s();
     memcpy(carry_code, hcode + total / 16 - kCarry / 16, sizeof(carry_code));
     memcpy(carry_inv, hinv + total / 16 - kCarry / 16, sizeof(carry_inv));
     uint8_t *ds = g->d_stage[b];
-    // (the chunk is packed: if the device has meanwhile finished everything it was given, it is waiting for the host)
-    { int rc_ = flush_if_device_idle(g); if (rc_ != MCX_OK) return rc_; }
-    HIP_TRY(hipMemcpyAsync(ds, hcode, total / 16 * 4, hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(hipMemcpyAsync(ds + inv_at, hinv, total / 16 * 2, hipMemcpyHostToDevice, g->stream));
+    // The chunk travels on the copy stream; the graph's stream waits for it between two timing events.  How long the
+    // previous use of this buffer pair made the compute stream wait (the events' distance) says whether the device
+    // is starved by the host side -- packing or PCIe: then one region group is flushed in that idle time, ahead of
+    // the wait.  (Until round 4 the copies ran on the graph's stream and "idle" was hipStreamQuery of it: with PCIe
+    // as the bottleneck that stream is never empty, no background flush ever ran, and the whole flush -- 39 ms for
+    // the bench's 6 G occurrences -- came after the last chunk.)
+    HIP_TRY(hipMemcpyAsync(ds, hcode, total / 16 * 4, hipMemcpyHostToDevice, g->cstream));
+    HIP_TRY(hipMemcpyAsync(ds + inv_at, hinv, total / 16 * 2, hipMemcpyHostToDevice, g->cstream));
     if (nwhole)
-      HIP_TRY(hipMemcpyAsync(ds + off_region, hoff, (nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
+      HIP_TRY(hipMemcpyAsync(ds + off_region, hoff, (nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->cstream));
+    HIP_TRY(hipEventRecord(g->ev_copy[b], g->cstream));
+    {
+      int starved = hipStreamQuery(g->stream) == hipSuccess ? 1 : 0;  // nothing queued at all: certainly waiting for us
+      (void)hipGetLastError();
+      float wait_ms = 0.f;
+      if (!starved && g->ev_wait_used[b] && hipEventElapsedTime(&wait_ms, g->ev_wait0[b], g->ev_wait1[b]) == hipSuccess) starved = wait_ms > 0.15f;
+      (void)hipGetLastError();
+      int rc_ = flush_if_device_idle(g, starved);
+      if (rc_ != MCX_OK) return rc_;
+    }
+    HIP_TRY(hipEventRecord(g->ev_wait0[b], g->stream));
+    HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_copy[b], 0));
+    HIP_TRY(hipEventRecord(g->ev_wait1[b], g->stream));
+    g->ev_wait_used[b] = true;
     StreamLaunch SL{nullptr, total, kCarry - (uint64_t)g->k, total - (uint64_t)g->k, piece_of >= 0 ? d_flags + piece_of : nullptr,
                     reinterpret_cast<const uint32_t *>(ds), reinterpret_cast<const uint16_t *>(ds + inv_at)};
     int rc = submit_stream(g, SL, colour);
@@ -1748,6 +1928,9 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(g->ev[b], g->stream));
+    const double tq4 = now_s();
+    g_stage_timing.wait += tq1 - tq0; g_stage_timing.prep += tq2 - tq1; g_stage_timing.pack += tq3 - tq2; g_stage_timing.submit += tq4 - tq3;
+    g_stage_timing.chunks++;
   }
   return MCX_OK;
 }

@@ -116,3 +116,44 @@ def test_host_packer_matches_the_base_codes(mcx):
     for off in ("MCX_NO_AVX2", "MCX_NO_AVX512"):   # SWAR; AVX2 where the host's default is AVX-512
         out = subprocess.run([sys.executable, "-c", prog], input=src.tobytes(), stdout=subprocess.PIPE, env=dict(os.environ, **{off: "1"})).stdout
         assert out == code.tobytes() + inv.tobytes(), off
+
+
+def test_one_pass_read_packer_matches_assemble_then_pack(mcx):
+    """mcx_pack_reads_host: the staging threads' one-pass packer (reads -> 2-bit codes + invalid flags, round 4)
+    against the stream assembled as ASCII and packed block by block, on ragged reads of arbitrary bytes: empty reads,
+    reads shorter than one step, lengths around the 32 / 64 / 128 boundaries, every byte value."""
+    import ctypes as C
+    L = mcx.lib()
+    L.mcx_pack_reads_host.restype = C.c_uint64
+    L.mcx_pack_reads_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTacgtNn\n\r .-*\x00\xff", dtype=np.uint8)
+    for case in range(12):
+        if case == 0:
+            lens = np.array([0, 1, 0, 31, 32, 33, 63, 64, 65, 127, 128, 129, 150, 0, 0, 191, 192, 193, 1000, 0], dtype=np.int64)
+        elif case == 1:
+            lens = np.full(3000, 150, dtype=np.int64)
+        elif case == 2:
+            lens = np.array([200000], dtype=np.int64)
+        elif case == 3:
+            lens = np.zeros(0, dtype=np.int64)
+        else:
+            lens = rng.integers(0, [4, 40, 151, 300, 70, 2000, 10, 129][case % 8], size=int(rng.integers(1, 2500))).astype(np.int64)
+        off = np.zeros(len(lens) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        n = int(off[-1])
+        bases = (alphabet[rng.integers(0, len(alphabet), n)] if case % 2 else rng.integers(0, 256, n).astype(np.uint8))
+        bases = np.concatenate([bases, np.zeros(1, np.uint8)])[:n].copy()  # exactly n bytes: a step's load must not run past the end
+        cap = 128 + ((n + len(lens) + 63) // 64) * 64
+        out = []
+        for fused in (0, 1):
+            code = np.zeros(cap // 16, dtype=np.uint32)
+            inv = np.zeros(cap // 16, dtype=np.uint16)
+            total = L.mcx_pack_reads_host(bases.ctypes.data if n else None, off.ctypes.data, len(lens), code.ctypes.data, inv.ctypes.data, cap, fused)
+            if fused and total == 0:
+                pytest.skip("no AVX-512 on this host: the one-pass packer is not used")
+            assert total == cap
+            out.append((code, inv))
+        assert np.array_equal(out[0][1], out[1][1]), "invalid flags, case %d" % case
+        # codes only have to agree where a position is valid; the packers agree everywhere, which is simpler to state
+        assert np.array_equal(out[0][0], out[1][0]), "codes, case %d" % case
