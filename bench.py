@@ -106,13 +106,13 @@ def make_batch_iid(nreads, seed, device):
 
 
 def csrc_digest():
-    """sha1 over the kernel sources: a PMC traffic figure is only valid for the code it was taken on"""
+    """sha1 over the sources of the three build kernels (k_stream_bin, k_tuples_bin, k_lds_insert and what they
+    include): a PMC traffic figure is only valid for the kernels it was taken on.  (Until round 4 the digest covered
+    every file under csrc/, so host-side edits -- staging threads, the multi-GPU facade -- voided it as well.)"""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "mccortex_amd", "csrc")
-    for n in sorted(os.listdir(d)):
-        if not n.endswith((".h", ".hip")):
-            continue
+    for n in ("mcx_defer.h", "mcx_kernels.h", "mcx_kmer.h"):
         h.update(n.encode())
         h.update(open(os.path.join(d, n), "rb").read())
     return h.hexdigest()[:16]
@@ -462,9 +462,10 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
     # (f) the multi-GPU table of the C ABI (mcx_graph_create_multi) with BOTH shards on this one GPU:
     # sender kernel -> peer copy (device-local here) -> owner split -> LDS insert; a check of the
     # code path and of its overheads, not a scaling figure
-    try:
-        g = mcx.Graph(K, 1, table_slots, devices=[0, 0])
-        g.configure("defer_tuples", 3_000_000_000)
+    for nsh, defer_sh in ((2, 3_000_000_000), (8, 1_000_000_000)):
+      try:
+        g = mcx.Graph(K, 1, table_slots, devices=[0] * nsh)
+        g.configure("defer_tuples", defer_sh)
         if pk is not None:
             g.add_packed_dev(0, pk[0][0][:4096], pk[0][1][:4096], 65536)
         else:
@@ -483,12 +484,14 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
         cs, nk = g.checksum()
         g.close()
         torch.cuda.empty_cache()
-        out["inprocess_2_shards_1gpu"] = {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(steps),
+        out["inprocess_%d_shards_1gpu" % nsh] = {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(steps),
                                           "distinct_kmers": int(st.num_kmers_novel), "graph_checksum": "%016x" % cs,
-                                          "what": "mcx_graph_create_multi with devices [0, 0]: two hash-prefix shards on ONE GPU, exchange v2 through "
-                                                  "hipMemcpyPeerAsync (device-local); the graph checksum must equal config.graph_checksum"}
-    except Exception as e:
-        out["inprocess_2_shards_1gpu"] = {"error": str(e)[:300]}
+                                          "what": "mcx_graph_create_multi with device 0 named %d times: %d shards on ONE GPU, exchange v3 (super-k-mer records, "
+                                                  "minimizer owners), the filled parts copied by a kernel through peer-mapped pointers (device-local here); a "
+                                                  "measure of the path's overhead, not of scaling; the graph checksum must equal config.graph_checksum" % (nsh, nsh)}
+      except Exception as e:
+        out["inprocess_%d_shards_1gpu" % nsh] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
     # (b) the same reads handed over in HOST memory through mcx_graph_add_reads (pinned buffers):
     # staging, PCIe and the kernels inside the clock
     nh = len(steps)

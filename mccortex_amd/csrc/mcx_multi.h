@@ -73,6 +73,7 @@ struct mcx_group {
   std::vector<int> cur;
   std::vector<std::array<bool, 2>> used;
   bool buffers = false;
+  bool peer_ok = true;  // every pair of distinct devices can map each other's memory (kernels may write to a peer)
 };
 
 #define GRP_TRY(expr)                                                                              \
@@ -159,7 +160,7 @@ static int group_ensure_buffers(mcx_group *G)
   // mean + 8 sigma of the Poisson fill + room for a short run of one k-mer; what does not fit goes
   // to the owner's overflow bin (hot k-mers), and beyond that raises MCX_ERR_FULL on the sender
   G->seg_cap = ((uint64_t)(mean + 8.0 * sqrt(mean + 1.0)) + 64 + 1) & ~1ull;
-  G->ov_cap = std::max<uint64_t>(1u << 16, G->max_pos / (uint64_t)N / 16);
+  G->ov_cap = (std::max<uint64_t>(1u << 16, G->max_pos / (uint64_t)N / 16) + 15) & ~15ull;  // (16-byte aligned edge-byte rows: k_copy_filled)
   G->sp_cap = G->max_pos;
   G->send.resize(N);
   G->h_spill.assign(N, {nullptr, nullptr});
@@ -190,6 +191,14 @@ static int group_ensure_buffers(mcx_group *G)
   }
   G->buffers = true;
   return MCX_OK;
+}
+
+// copies between the shards: k_copy_filled over peer-mapped pointers (default) or whole blocks with hipMemcpyPeerAsync
+// (MCX_MULTI_COPY=memcpy; also what is used when a pair of devices has no peer access)
+static bool group_copy_kernel(const mcx_group *G)
+{
+  static const bool want = [] { const char *e = getenv("MCX_MULTI_COPY"); return !(e && !strcmp(e, "memcpy")); }();
+  return want && G->peer_ok;
 }
 
 // Hot k-mers.  A segment holds mean + 8 sigma, an owner's overflow bin max(64 K, piece / N / 16) more;
@@ -295,6 +304,18 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
       GRP_TRY(hipEventRecord(G->filled[idx][b], me->stream));
       // 2. one copy of the fills and one of the records per owner: whole segments, so no count is read on the host
       GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->filled[idx][b], 0));
+      if (group_copy_kernel(G)) {  // the filled parts only, one launch (k_copy_filled)
+        PeerDst pd{};
+        for (int j = 0; j < N; j++) {
+          if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->consumed[j][idx][b], 0));  // the slot is free again
+          pd.data[j] = G->recv[j][idx][b].recs;
+          pd.fills[j] = G->recv[j][idx][b].fills;
+        }
+        hipLaunchKernelGGL(k_copy_filled, dim3(2048), dim3(256), 0, G->cs[idx], (const ulonglong2 *)s.recs, (const unsigned long long *)s.fills, pd,
+                           (uint32_t)N, G->sk_segs, G->sk_cap, (uint32_t)recb);
+        GRP_TRY(hipGetLastError());
+        for (int j = 0; j < N; j++) GRP_TRY(hipEventRecord(G->arrived[j][idx][b], G->cs[idx]));
+      } else
       for (int j = 0; j < N; j++) {
         mcx_graph *own = G->part[j];
         XBuf &r = G->recv[j][idx][b];
@@ -344,15 +365,36 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
     // 2. one copy per (owner, buffer): fixed sizes, so the fills travel with the blocks and the host
     // never has to read them
     GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->filled[idx][b], 0));
+    const bool ck = group_copy_kernel(G);
+    if (ck) {  // the packed tuples: filled parts of all (owner, segment) bins in one launch; the overflow bins below as before
+      PeerDst pd{};
+      for (int j = 0; j < N; j++) {
+        if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->consumed[j][idx][b], 0));  // the slot is free again
+        pd.data[j] = G->recv[j][idx][b].keys;
+        pd.fills[j] = G->recv[j][idx][b].counts;
+      }
+      hipLaunchKernelGGL(k_copy_filled, dim3(2048), dim3(256), 0, G->cs[idx], (const ulonglong2 *)s.keys, (const unsigned long long *)s.counts, pd,
+                         (uint32_t)N, G->segs, G->seg_cap, (uint32_t)(8 * W));
+      // the owners' overflow bins (full tuples: key words, then edge bytes): one segment per owner, filled part only
+      for (int j = 0; j < N; j++) { pd.data[j] = G->recv[j][idx][b].ov_keys; pd.fills[j] = G->recv[j][idx][b].ov_counts; }
+      hipLaunchKernelGGL(k_copy_filled, dim3(256), dim3(256), 0, G->cs[idx], (const ulonglong2 *)s.ov_keys, (const unsigned long long *)s.ov_counts, pd,
+                         (uint32_t)N, 1u, G->ov_cap, (uint32_t)(8 * W));
+      for (int j = 0; j < N; j++) pd.data[j] = G->recv[j][idx][b].ov_edges;
+      hipLaunchKernelGGL(k_copy_filled, dim3(256), dim3(256), 0, G->cs[idx], (const ulonglong2 *)s.ov_edges, (const unsigned long long *)s.ov_counts, pd,
+                         (uint32_t)N, 1u, G->ov_cap, 1u);
+      GRP_TRY(hipGetLastError());
+    }
     for (int j = 0; j < N; j++) {
       mcx_graph *own = G->part[j];
       XBuf &r = G->recv[j][idx][b];
-      if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->consumed[j][idx][b], 0));  // the slot is free again
-      GRP_TRY(hipMemcpyPeerAsync(r.counts, own->device, s.counts + (uint64_t)j * G->segs, me->device, (uint64_t)G->segs * 8, G->cs[idx]));
-      GRP_TRY(hipMemcpyPeerAsync(r.ov_counts, own->device, s.ov_counts + j, me->device, 8, G->cs[idx]));
-      GRP_TRY(hipMemcpyPeerAsync(r.keys, own->device, s.keys + (uint64_t)j * blk * W, me->device, blk * 8 * W, G->cs[idx]));
-      GRP_TRY(hipMemcpyPeerAsync(r.ov_keys, own->device, s.ov_keys + (uint64_t)j * G->ov_cap * W, me->device, G->ov_cap * 8 * W, G->cs[idx]));
-      GRP_TRY(hipMemcpyPeerAsync(r.ov_edges, own->device, s.ov_edges + (uint64_t)j * G->ov_cap, me->device, G->ov_cap, G->cs[idx]));
+      if (!ck) {
+        if (G->used[idx][b]) GRP_TRY(hipStreamWaitEvent(G->cs[idx], G->consumed[j][idx][b], 0));  // the slot is free again
+        GRP_TRY(hipMemcpyPeerAsync(r.counts, own->device, s.counts + (uint64_t)j * G->segs, me->device, (uint64_t)G->segs * 8, G->cs[idx]));
+        GRP_TRY(hipMemcpyPeerAsync(r.keys, own->device, s.keys + (uint64_t)j * blk * W, me->device, blk * 8 * W, G->cs[idx]));
+        GRP_TRY(hipMemcpyPeerAsync(r.ov_counts, own->device, s.ov_counts + j, me->device, 8, G->cs[idx]));
+        GRP_TRY(hipMemcpyPeerAsync(r.ov_keys, own->device, s.ov_keys + (uint64_t)j * G->ov_cap * W, me->device, G->ov_cap * 8 * W, G->cs[idx]));
+        GRP_TRY(hipMemcpyPeerAsync(r.ov_edges, own->device, s.ov_edges + (uint64_t)j * G->ov_cap, me->device, G->ov_cap, G->cs[idx]));
+      }
       GRP_TRY(hipEventRecord(G->arrived[j][idx][b], G->cs[idx]));
     }
     GRP_TRY(hipEventRecord(G->sent[idx][b], G->cs[idx]));
@@ -452,7 +494,9 @@ extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols,
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
           const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
-          if (e != hipSuccess) (void)hipGetLastError();  // already enabled
+          if (e != hipSuccess) { (void)hipGetLastError(); if (e != hipErrorPeerAccessAlreadyEnabled) G->peer_ok = false; }
+        } else {
+          G->peer_ok = false;
         }
       }
     MK_TRY(hipStreamCreateWithFlags(&G->cs[i], hipStreamNonBlocking));

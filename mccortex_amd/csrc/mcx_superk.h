@@ -242,6 +242,38 @@ __global__ void k_transpose_fills(const unsigned long long *in, unsigned long lo
   if (i < rep * nparts) out[(i % nparts) * rep + i / nparts] = in[i];
 }
 
+// The in-process exchange (mcx_multi.h): ONE launch on the sender's copy stream moves the FILLED part of every
+// (owner, segment) of a send set into the owners' receive slots through peer-mapped pointers, and the fills with
+// them -- the fills are read on the device, so the host still never sees a count.  (Until round 4 every owner's whole
+// block went out with hipMemcpyPeerAsync: the segments' capacity, 3.6 B per occurrence at k = 31 against 2.4 B of
+// filled records, and 2 N + N copy calls per piece on the one host thread.)  Segments are 16-byte aligned arrays of
+// `unit16` 16-byte units per item (records: 1 or 2; packed one-word tuples: half a unit -- copied in pairs).
+struct PeerDst {
+  void *data[32];                  // owner j's receive slot for this sender: [segs][cap] items
+  unsigned long long *fills[32];   // ... and its fills [segs]
+};
+constexpr uint32_t kCopyChunk = 8192;  // 16-byte units per unit of work (128 KiB)
+__global__ __launch_bounds__(256) void k_copy_filled(const ulonglong2 *src, const unsigned long long *fills, PeerDst dst, uint32_t nparts,
+                                                     uint32_t segs, uint64_t cap, uint32_t item_bytes)
+{
+  const uint64_t seg_units = (cap * item_bytes + 15) / 16;
+  const uint64_t chunks_per_seg = (seg_units + kCopyChunk - 1) / kCopyChunk;
+  const uint64_t nsegs = (uint64_t)nparts * segs, nunits = nsegs * chunks_per_seg;
+  for (uint64_t v = blockIdx.x; v < nunits; v += gridDim.x) {
+    const uint64_t js = v % nsegs, c = v / nsegs;  // segment-interleaved
+    const uint32_t j = (uint32_t)(js / segs), sg = (uint32_t)(js % segs);
+    const unsigned long long f = fills[js];
+    if (c == 0 && threadIdx.x == 0) dst.fills[j][sg] = f;
+    const uint64_t n16 = (min((uint64_t)f, cap) * item_bytes + 15) / 16;
+    const uint64_t lo = c * kCopyChunk;
+    if (lo >= n16) continue;
+    const uint64_t hi = min(n16, lo + kCopyChunk);
+    const ulonglong2 *sp = src + js * seg_units;
+    ulonglong2 *dp = reinterpret_cast<ulonglong2 *>(dst.data[j]) + (uint64_t)sg * seg_units;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) dp[i] = sp[i];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // owner: super-k-mer records -> region bins of packed tuples (same output as k_stream_bin)
 // ---------------------------------------------------------------------------
