@@ -904,7 +904,7 @@ def main():
             torch.cuda.empty_cache()
             osteps = 0 if args.no_cpu_baseline else max(0, min(args.oracle_steps, nsteps))
             ex = extras(mcx, batches, packed, nsteps, args.table_slots, osteps, not args.no_full_e2e)
-            for key in ("host_fed", "e2e", "e2e_full", "default_defer", "ascii_resident", "packed_resident", "other_configs", "inprocess_2_shards_1gpu"):
+            for key in ("host_fed", "e2e", "e2e_full", "default_defer", "ascii_resident", "packed_resident", "other_configs", "inprocess_2_shards_1gpu", "inprocess_8_shards_1gpu"):
                 if key in ex:
                     out[key] = ex[key]
         if not args.no_cpu_baseline and not sharded:

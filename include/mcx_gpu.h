@@ -124,9 +124,13 @@ int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen);
  * mcx_graph_export (sorted: one device sort merges the shards).  mcx_graph_add_stream_dev takes a
  * stream on any of the devices.  Intersect / must-exist mode works as on one device (records are
  * dealt with by the shard that owns their key; reads are walked by every shard, which exchange what
- * they found before any of them updates a node: an edge needs both of its k-mers).  Low-complexity
- * input cannot overflow the exchange: what fits neither an (owner, region) segment nor the owner's
- * overflow bin is spilled on the sender and routed by the host.  Not available on such a handle: the
+ * they found before any of them updates a node: an edge needs both of its k-mers).  Hot k-mers and
+ * low-complexity input (poly-G reads, satellite repeats) do not overflow the exchange: what fits neither
+ * its segment nor the owner's overflow bin is spilled on the sender and routed by the host.  Format v2's
+ * spill area holds a whole piece, so nothing can be lost; format v3 has room for 3 records per 16
+ * positions in the segments and 4 more in the spill area (random reads make 2.3, low-complexity input
+ * fewer: long runs) -- only a piece that changes owner at nearly every k-mer throughout could exceed
+ * that, and is then reported with MCX_ERR_FULL, never dropped silently.  Not available on such a handle: the
  * device-pointer exchange calls below (those take a single shard).  ndevices == 1 is mcx_graph_create. */
 int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers,
                            const int *devices, int ndevices);

@@ -128,15 +128,17 @@ struct mcx_graph {
   Counters *d_ctr = nullptr;
   Counters *h_ctr = nullptr;  // pinned
   // host staging (double buffered)
-  uint8_t *h_stage[2] = {nullptr, nullptr};
-  uint8_t *d_stage[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  // (three staging pairs since round 4: with two, the host waited 20 ms per 6 G occurrences for the device to release one)
+  static constexpr int kStageBufs = 3;
+  uint8_t *h_stage[kStageBufs] = {nullptr, nullptr, nullptr};
+  uint8_t *d_stage[kStageBufs] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[kStageBufs] = {nullptr, nullptr, nullptr};
   // the packed host entry copies on a stream of its own (cstream), so that the graph's stream only holds compute:
   // ev_copy[b] = chunk b has arrived; ev_wait0 / ev_wait1[b] bracket the compute stream's wait for it (timing events:
   // their distance is how long the device sat idle waiting for PCIe -- add_reads_packed)
   hipStream_t cstream = nullptr;
-  hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_wait0[2] = {nullptr, nullptr}, ev_wait1[2] = {nullptr, nullptr};
-  bool ev_wait_used[2] = {false, false};
+  hipEvent_t ev_copy[kStageBufs] = {nullptr, nullptr, nullptr}, ev_wait0[kStageBufs] = {nullptr, nullptr, nullptr}, ev_wait1[kStageBufs] = {nullptr, nullptr, nullptr};
+  bool ev_wait_used[kStageBufs] = {false, false, false};
   uint64_t stage_alloc = 0;
   int cur = 0;
   int grid = 0;
@@ -388,7 +390,7 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->cstream) { (void)hipStreamSynchronize(g->cstream); (void)hipStreamDestroy(g->cstream); }
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < mcx_graph::kStageBufs; i++) {
     if (g->h_stage[i]) (void)hipHostFree(g->h_stage[i]);
     if (g->d_stage[i]) (void)hipFree(g->d_stage[i]);
     if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
@@ -525,6 +527,18 @@ static void launch_bin_stream_pk(mcx_graph *g, const StreamArgs &a, uint64_t nt,
     once = true;
   }
   SpanGuard sp(g, "k_stream_bin");
+  // region bins of an unsharded one-word table: 512-thread blocks, two tiles sorted as one (MCX_STREAM_T=256: the old geometry)
+  if constexpr (W == 1 && !FULL && SH == 0) {
+    static const bool wide = [] { const char *e = getenv("MCX_STREAM_T"); return !e || atoi(e) == 512; }();
+    if (wide && bs.nlocal <= 512) {
+      using GeoW = Geo<512, 512 * kPosPerLane>;
+      static bool once_w[64] = {false};
+      if (!once_w[g->device & 63]) { allow_lds(k_stream_bin<W, ONECOL, 512, FULL, SH, PK, 512>, sizeof(BinLds<W, 512, FULL, GeoW>)); once_w[g->device & 63] = true; }
+      const dim3 gridw((unsigned)std::min<uint64_t>((nt + 1) / 2, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid / 2)));
+      hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL, SH, PK, 512>), gridw, dim3(512), sizeof(BinLds<W, 512, FULL, GeoW>), g->stream, a, bs, out, is);
+      return;
+    }
+  }
   const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid)));
   // the histogram capacity sets the LDS footprint and with it the blocks per CU: 512 and 1024 bins
   // leave room for 4 blocks (W=1), 2048 for 2
@@ -1741,7 +1755,7 @@ static int ensure_stage(mcx_graph *g)
   // staged in a second region sized for reads of >= 15 bytes on average and the
   // filler stops a chunk when either region is full.
   const uint64_t bytes = kCarry + kStageBytes + 256 + (kStageBytes / 16 + 2) * sizeof(uint64_t);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < mcx_graph::kStageBufs; i++) {
     HIP_TRY(hipHostMalloc((void **)&g->h_stage[i], bytes, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&g->d_stage[i], bytes));
     HIP_TRY(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
@@ -1778,7 +1792,7 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
   uint64_t r = 0, r_pos = 0;  // next read, bytes of it already staged
   while (r < nreads) {
     const int b = g->cur;
-    g->cur ^= 1;
+    g->cur = (g->cur + 1) % mcx_graph::kStageBufs;
     const double tq0 = now_s();
     HIP_TRY(hipEventSynchronize(g->ev[b]));  // previous use of this buffer finished
     const double tq1 = now_s();
@@ -1985,7 +1999,7 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
   memset(carry, '\n', kCarry);
   while (r < nreads) {
     const int b = g->cur;
-    g->cur ^= 1;
+    g->cur = (g->cur + 1) % mcx_graph::kStageBufs;
     HIP_TRY(hipEventSynchronize(g->ev[b]));  // previous use of this buffer finished
     uint8_t *hs = g->h_stage[b];
     uint64_t *hoff = reinterpret_cast<uint64_t *>(hs + off_region);

@@ -394,12 +394,18 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
 //    other shards take the direct insert), SH 2 of every shard (BIN_GLOBAL, exchange blocks).
 //    The variants are compiled apart: code of the rare paths costs the common one registers.
 // ---------------------------------------------------------------------------
-template <int W, bool ONECOL, int NB, bool FULL, int SH, bool PK>
-__global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a_arg, BinSpec bs, BinOut out_arg,
-                                                                         InsertSink<W, ONECOL> isink_arg)
+// T = 256: one tile of 4096 positions per block iteration (4 blocks per CU).  T = 512 (region bins of an unsharded
+// one-word table): the two halves of the block k-merise two neighbouring tiles, each with its own staged codes, and
+// the block sorts the 8192 tuples as ONE tile -- half as many histogram scans, reservations and commits per tuple,
+// and runs of 16 tuples (128 bytes) per bin instead of 8; 2 blocks per CU, the same 16 waves.
+template <int W, bool ONECOL, int NB, bool FULL, int SH, bool PK, int T = kThreads>
+__global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a_arg, BinSpec bs, BinOut out_arg,
+                                                                  InsertSink<W, ONECOL> isink_arg)
 {
-  __shared__ uint32_t s_code[kChunks + 4];
-  __shared__ uint32_t s_inv[kChunks / 2 + 4];
+  constexpr int H = T / kThreads;  // tiles k-merised side by side
+  static_assert(T == kThreads || (T == 2 * kThreads && !FULL), "256 threads, or 512 for packed bins");
+  __shared__ uint32_t s_code_h[H][kChunks + 4];
+  __shared__ uint32_t s_inv_h[H][kChunks / 2 + 4];
   // Arguments that are read once per tile (owned range), after the loop (counters), or
   // only by the rare paths (the table's description: bin overflow, foreign keys), are read from
   // LDS: held in scalar registers through the tile loop they exhausted the register file --
@@ -417,10 +423,11 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
   const uint64_t a_tile0 = a_arg.tile0, a_ntiles = a_arg.ntiles;
   const uint32_t t_lb1 = isink_arg.t.lb1, t_lbq = isink_arg.t.lb1 + isink_arg.t.lbo, t_part = isink_arg.t.part;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  using LDS = BinLds<W, NB, FULL>;
+  using LDS = BinLds<W, NB, FULL, Geo<T, T * kPosPerLane>>;
   LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
 
-  const int tid0 = threadIdx.x;
+  const int tid0 = threadIdx.x & (kThreads - 1);
+  const uint64_t half0 = (uint64_t)(threadIdx.x / kThreads);
   const int k = a_arg.k;
   uint32_t n_kmers = 0, n_contigs = 0, n_novel = 0, full = 0;
   const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
@@ -431,24 +438,29 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
   TileSrc pre;
   pre.a = make_uint4(0, 0, 0, 0); pre.b = make_uint4(0, 0, 0, 0);
   {
-    const uint64_t t0 = a_tile0 + blockIdx.x;
+    const uint64_t t0 = a_tile0 + (uint64_t)blockIdx.x * H + half0;
     if (t0 < a_ntiles) tile_fetch<PK>(a_arg, t0, tid0, pre);
   }
   MCX_PH_DECL
-  for (uint64_t tile = a_tile0 + blockIdx.x; tile < a_ntiles; tile += gridDim.x) {
+  for (uint64_t tile_b = a_tile0 + (uint64_t)blockIdx.x * H; tile_b < a_ntiles; tile_b += (uint64_t)gridDim.x * H) {
     // (opaque: what is derived from the thread index -- LDS addresses, masks -- is recomputed per
     // tile in an instruction or two; hoisted out of the loop it was spilled to scratch)
-    const int tid = (int)tid_now();
+    const int tid_blk = (int)tid_now();               // index in the block: bins, counters
+    const int tid = tid_blk & (kThreads - 1);         // index in the half: the tile's positions
+    const uint64_t tile = tile_b + (uint64_t)(tid_blk / kThreads);
+    const bool have_tile = H == 1 || tile < a_ntiles;  // (the last block iteration of an odd number of tiles: an empty half)
+    uint32_t *s_code = s_code_h[H == 1 ? 0 : tid_blk / kThreads];
+    uint32_t *s_inv = s_inv_h[H == 1 ? 0 : tid_blk / kThreads];
     MCX_PH(6) MCX_PH_COUNT
     // (No barrier here: what is written before the next one -- the tile's codes and flags, the
     // zeroed counters -- was last read before the write-out's entry barrier of the previous tile;
     // what a slower wave may still be reading, the staging area and the bin bases, is next
     // written after the three barriers of bin_reserve.)
     tile_stage<PK>(a_arg, pre, tid, s_code, s_inv);
-    for (uint32_t b = tid; b < bs.nlocal + 64; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
+    for (uint32_t b = tid_blk; b < bs.nlocal + 64; b += T) { L.cnt[b] = 0; L.rnk[b] = 0; }
     if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
     {
-      const uint64_t tn = tile + gridDim.x;
+      const uint64_t tn = tile + (uint64_t)gridDim.x * H;
       if (tn < a_ntiles) tile_fetch<PK>(a_arg, tn, tid, pre);
     }
     __syncthreads();
@@ -460,8 +472,8 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
     const uint32_t prev_chunk_inv = (s_inv[(pl - 1) >> 5] >> (31 - ((pl - 1) & 31))) & 1u;
     // positions owned by this launch: all 16 of every lane unless the tile straddles an end of the
     // launch's range (uniform test; the per-lane 64-bit arithmetic cost 25 instructions a tile)
-    uint32_t range = 0xFFFFu;
-    {
+    uint32_t range = have_tile ? 0xFFFFu : 0u;
+    if (have_tile) {
       const uint64_t plo = a.pos_lo, phi = a.pos_hi, T0 = tile * kTile;
       if (T0 < plo || T0 + kTile > phi) {
         const uint64_t P0 = T0 + 16ull * (uint64_t)tid;
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
     Kmer<W> tk[kPosPerLane];    // FULL: canonical key; packed: quotient | edges << 56
     uint32_t tle[kPosPerLane];  // local bin | sorted position << 12 | edge byte << 24 (FULL)
     // one trash bin per lane (no same-address LDS atomics), never [nlocal] itself: off[nlocal] is the tile's total
-    const uint32_t trash = bs.nlocal + 1u + ((uint32_t)tid & 31u);
+    const uint32_t trash = bs.nlocal + 1u + ((uint32_t)tid_blk & 31u);
     n_kmers += __popc(ok16);
     n_contigs += __popc(ok16 & ~pok16);
     {
@@ -607,7 +619,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_stream_bin(Strea
       }
     }
     MCX_PH(1)
-    BinRes<NB> res;
+    BinRes<NB, T> res;
     bin_reserve<LDS, NB>(L, bs, out, ob0, res, !FULL);
     MCX_PH(2)
 #pragma unroll

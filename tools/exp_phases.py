@@ -41,12 +41,16 @@ def main():
     dev = torch.device("cuda", 0)
     L = mcx.lib()
     L.mcx_debug_phases.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-    genome = bench.make_genome(bench.GENOME_PER_GPU, dev, seed=42)
-    batches = [bench.make_batch(genome, bench.BATCH_READS, seed=1000 + i, device=dev) for i in range(10)]
-    del genome
+    stress = os.environ.get("PHASES_CFG") == "stress"  # C2-stress: iid reads (every k-mer novel), 2^33 slots
+    if stress:
+        batches = [bench.make_batch_iid(bench.BATCH_READS, seed=7000 + i, device=dev) for i in range(10)]
+    else:
+        genome = bench.make_genome(bench.GENOME_PER_GPU, dev, seed=42)
+        batches = [bench.make_batch(genome, bench.BATCH_READS, seed=1000 + i, device=dev) for i in range(10)]
+        del genome
     torch.cuda.empty_cache()
-    for k, defer in ((31, 8_000_000_000), (63, 5_000_000_000)):
-        g = mcx.Graph(k, 1, 1 << 30)
+    for k, defer in (((31, 6_300_000_000),) if stress else ((31, 8_000_000_000), (63, 5_000_000_000))):
+        g = mcx.Graph(k, 1, (1 << 33) if stress else (1 << 30))
         g.configure("defer_tuples", defer)
         g.configure("flush_overlap", 0)
         g.add_stream_dev(0, batches[0][:1024 * 151], 1024 * 151)
