@@ -81,6 +81,28 @@ class StagePool {
     cv_done_.wait(lk, [&] { return pending_ == 0; });
     fn_ = nullptr; T_ = 0; next_ = 0;
   }
+  // Asynchronous variant: fn(0) .. fn(T - 1) all run on pool threads while the caller does something else;
+  // finish() returns when they are done.  One job at a time: begin() takes the pool's turn, finish() gives it back
+  // (both from the same thread).  `fn` must stay alive until finish().
+  void begin(int T, const std::function<void(int)> &fn)
+  {
+    call_mu_.lock();
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      while ((int)th_.size() < T) th_.emplace_back([this] { worker(); }), th_.back().detach();
+      fn_ = &fn; T_ = T; next_ = 0; pending_ = T;
+    }
+    cv_work_.notify_all();
+  }
+  void finish()
+  {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_done_.wait(lk, [&] { return pending_ == 0; });
+      fn_ = nullptr; T_ = 0; next_ = 0;
+    }
+    call_mu_.unlock();
+  }
  private:
   void worker()
   {
@@ -1790,122 +1812,147 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
   uint16_t carry_inv[kCarry / 16];
   for (uint64_t i = 0; i < kCarry / 16; i++) { carry_code[i] = 0; carry_inv[i] = 0xFFFF; }
   uint64_t r = 0, r_pos = 0;  // next read, bytes of it already staged
-  while (r < nreads) {
-    const int b = g->cur;
-    g->cur = (g->cur + 1) % mcx_graph::kStageBufs;
-    const double tq0 = now_s();
-    HIP_TRY(hipEventSynchronize(g->ev[b]));  // previous use of this buffer finished
-    const double tq1 = now_s();
-    uint8_t *hs = g->h_stage[b];
-    uint32_t *hcode = reinterpret_cast<uint32_t *>(hs);
-    uint16_t *hinv = reinterpret_cast<uint16_t *>(hs + inv_at);
-    uint64_t *hoff = reinterpret_cast<uint64_t *>(hs + off_region);
-    const uint64_t r0 = r;
-    uint64_t nwhole = 0, L = 0;  // reads wholly in this chunk, positions after the carry
+  const int T = stage_threads();
+  const bool fused = pack_reads_available();
+
+  // One chunk on its way through plan -> pack -> submit.  Two are alive at a time (round 4): while the caller
+  // enqueues chunk n (copies, background flush, kernels: ~0.15 ms of HIP calls) and waits for the staging pair of
+  // chunk n + 1 to come free, the pool already packs chunk n + 1 -- the packing threads used to idle through both.
+  struct Job {
+    int b = 0;
+    uint8_t *hs = nullptr;
+    uint32_t *hcode = nullptr;
+    uint16_t *hinv = nullptr;
+    uint64_t *hoff = nullptr;
+    uint64_t r0 = 0, nwhole = 0, L = 0, Lp = 0, total = 0;
     long long piece_of = -1;
     uint64_t piece_from = 0, piece_data = 0;  // a piece: where its bases start in `bases`, how many there are
-    {  // whole reads that fit: read i lands at position kCarry + (off[r0 + i] - off[r0]) + i (each is
-       // followed by one separator), which grows with i: the count is found by bisection, not by a walk
-      if (r_pos == 0) {
-        uint64_t lo = 0, hi = std::min<uint64_t>(nreads - r0, max_offs);  // largest n with n reads taking <= kStageBytes positions
-        auto need = [&](uint64_t n) { return off[r0 + n] - off[r0] + n; };
-        if (need(hi) <= kStageBytes) lo = hi;
-        else while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (need(mid) <= kStageBytes) lo = mid; else hi = mid; }
-        nwhole = lo;
-        L = need(nwhole);
-      }
-      r += nwhole;
-      if (nwhole == 0) {  // a read longer than a chunk (or its tail): a piece of it on its own
-        const uint64_t len = off[r + 1] - off[r], remain = len - r_pos;
-        uint64_t take = std::min(remain, kStageBytes - 64);
-        if (take < remain) take &= ~63ull;  // pieces end on a 64-position boundary: no padding inside a read
-        piece_of = (long long)r;
-        piece_from = off[r] + r_pos;
-        piece_data = take;
-        L = take;
-        r_pos += take;
-        if (r_pos == len) { L += 1; r++; r_pos = 0; }  // its separator
-      }
-    }
-    auto start_of = [&](uint64_t i) { return kCarry + (off[r0 + i] - off[r0]) + i; };  // first position of whole read i
-    hoff[nwhole] = kCarry + L;
-    const uint64_t Lp = (L + 63) & ~63ull, total = kCarry + Lp;
-    memcpy(hcode, carry_code, sizeof(carry_code));
-    memcpy(hinv, carry_inv, sizeof(carry_inv));
-    // position p of the chunk (p >= kCarry): base of a read, or a separator
-    const int T = stage_threads();
-    // The threads take runs of kRun blocks from a shared counter (not a fixed share each): on a host that is shared
-    // with other jobs a thread that loses its core for a moment would otherwise hold up the whole chunk.
     std::atomic<uint64_t> next_run{0};
-    auto work = [&](int ti) {
+    std::function<void(int)> fn;
+    bool async = false;
+  } jobs[2];
+
+  // plan: the staging pair, the reads (or the piece of a long read) the chunk holds
+  auto plan = [&](Job &J) -> int {
+    J.b = g->cur;
+    g->cur = (g->cur + 1) % mcx_graph::kStageBufs;
+    const double tq0 = now_s();
+    HIP_TRY(hipEventSynchronize(g->ev[J.b]));  // previous use of this pair finished
+    g_stage_timing.wait += now_s() - tq0;
+    J.hs = g->h_stage[J.b];
+    J.hcode = reinterpret_cast<uint32_t *>(J.hs);
+    J.hinv = reinterpret_cast<uint16_t *>(J.hs + inv_at);
+    J.hoff = reinterpret_cast<uint64_t *>(J.hs + off_region);
+    J.r0 = r;
+    J.nwhole = 0; J.L = 0; J.piece_of = -1; J.piece_from = 0; J.piece_data = 0;
+    // whole reads that fit: read i lands at position kCarry + (off[r0 + i] - off[r0]) + i (each is
+    // followed by one separator), which grows with i: the count is found by bisection, not by a walk
+    if (r_pos == 0) {
+      const uint64_t r0 = J.r0;
+      uint64_t lo = 0, hi = std::min<uint64_t>(nreads - r0, max_offs);  // largest n with n reads taking <= kStageBytes positions
+      auto need = [&](uint64_t n) { return off[r0 + n] - off[r0] + n; };
+      if (need(hi) <= kStageBytes) lo = hi;
+      else while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (need(mid) <= kStageBytes) lo = mid; else hi = mid; }
+      J.nwhole = lo;
+      J.L = need(lo);
+    }
+    r += J.nwhole;
+    if (J.nwhole == 0) {  // a read longer than a chunk (or its tail): a piece of it on its own
+      const uint64_t len = off[r + 1] - off[r], remain = len - r_pos;
+      uint64_t take = std::min(remain, kStageBytes - 64);
+      if (take < remain) take &= ~63ull;  // pieces end on a 64-position boundary: no padding inside a read
+      J.piece_of = (long long)r;
+      J.piece_from = off[r] + r_pos;
+      J.piece_data = take;
+      J.L = take;
+      r_pos += take;
+      if (r_pos == len) { J.L += 1; r++; r_pos = 0; }  // its separator
+    }
+    J.hoff[J.nwhole] = kCarry + J.L;
+    J.Lp = (J.L + 63) & ~63ull;
+    J.total = kCarry + J.Lp;
+    return MCX_OK;
+  };
+
+  // pack: the chunk's stream, position p >= kCarry = base of a read or a separator, as code words + invalid flags.
+  // The threads take runs of kRun blocks from a shared counter (not a fixed share each): on a host that is shared
+  // with other jobs a thread that loses its core for a moment would otherwise hold up the whole chunk.
+  auto pack_begin = [&](Job &J) {
+    memcpy(J.hcode, carry_code, sizeof(carry_code));  // (the previous chunk's last positions: its packing has finished)
+    memcpy(J.hinv, carry_inv, sizeof(carry_inv));
+    J.next_run.store(0, std::memory_order_relaxed);
+    Job *jp = &J;
+    J.fn = [jp, bases, off, T, fused](int ti) {
+      Job &J = *jp;
       constexpr uint64_t BLK = 16384, kRun = 16;
-      uint8_t buf[BLK];
+      const uint64_t r0 = J.r0, nwhole = J.nwhole, Lp = J.Lp;
       const uint64_t nblk = (Lp + BLK - 1) / BLK;
+      auto start_of = [&](uint64_t i) { return kCarry + (off[r0 + i] - off[r0]) + i; };  // first position of whole read i
       // the staged offsets of this thread's share of the reads (k_read_flags_packed reads them)
-      for (uint64_t q = nwhole * (uint64_t)ti / (uint64_t)T, qe = nwhole * (uint64_t)(ti + 1) / (uint64_t)T; q < qe; q++) hoff[q] = start_of(q);
-      for (;;) {
-      const uint64_t b_lo = next_run.fetch_add(kRun, std::memory_order_relaxed), b_hi = std::min(nblk, b_lo + kRun);
-      if (b_lo >= nblk) break;
-      // first read that reaches into the run's range of positions
-      uint64_t i = 0;
-      if (piece_of < 0 && nwhole) {
-        const uint64_t p0 = kCarry + b_lo * BLK;
-        uint64_t lo = 0, hi = nwhole;  // last read that starts at or before p0
-        while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (start_of(mid) <= p0) lo = mid; else hi = mid; }
-        i = lo;
+      for (uint64_t q = nwhole * (uint64_t)ti / (uint64_t)T, qe = nwhole * (uint64_t)(ti + 1) / (uint64_t)T; q < qe; q++) J.hoff[q] = start_of(q);
+#if defined(__x86_64__)
+      if (fused) {  // one pass from the reads to the packed chunk (pack_reads_avx512)
+        const PackReads PR{bases, off, r0, J.piece_of >= 0 ? 1 : nwhole, kCarry, J.piece_of >= 0, J.piece_from, J.piece_data};
+        for (;;) {
+          const uint64_t b_lo = J.next_run.fetch_add(kRun, std::memory_order_relaxed), b_hi = std::min(nblk, b_lo + kRun);
+          if (b_lo >= nblk) break;
+          pack_reads_avx512(PR, kCarry + b_lo * BLK, std::min(kCarry + b_hi * BLK, kCarry + Lp), J.hcode, J.hinv);
+        }
+        return;
       }
-      for (uint64_t bk = b_lo; bk < b_hi; bk++) {
-        const uint64_t p0 = kCarry + bk * BLK, n = std::min(BLK, kCarry + Lp - p0);
-        if (piece_of >= 0) {
-          const uint64_t at = p0 - kCarry, data = at < piece_data ? std::min(n, piece_data - at) : 0;
-          memcpy(buf, bases + piece_from + at, data);
-          memset(buf + data, '\n', n - data);  // the read's separator (if it ends here) and the padding
-        } else {
-          uint64_t p = p0;
-          while (p < p0 + n) {
-            if (i >= nwhole) { memset(buf + (p - p0), '\n', p0 + n - p); break; }
-            const uint64_t s_ = start_of(i), len = off[r0 + i + 1] - off[r0 + i];
-            if (p < s_ + len) {
-              const uint64_t cnt = std::min(s_ + len - p, p0 + n - p);
-              memcpy(buf + (p - p0), bases + off[r0 + i] + (p - s_), cnt);
-              p += cnt;
-            } else {  // the read's separator, then the next read
-              buf[p - p0] = '\n';
-              p++;
-              i++;
+#endif
+      uint8_t buf[BLK];  // hosts without AVX-512 VBMI2: assemble 16 KiB of the stream as ASCII, pack the block
+      for (;;) {
+        const uint64_t b_lo = J.next_run.fetch_add(kRun, std::memory_order_relaxed), b_hi = std::min(nblk, b_lo + kRun);
+        if (b_lo >= nblk) break;
+        uint64_t i = 0;  // first read that reaches into the run's range of positions
+        if (J.piece_of < 0 && nwhole) {
+          const uint64_t p0 = kCarry + b_lo * BLK;
+          uint64_t lo = 0, hi = nwhole;  // last read that starts at or before p0
+          while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (start_of(mid) <= p0) lo = mid; else hi = mid; }
+          i = lo;
+        }
+        for (uint64_t bk = b_lo; bk < b_hi; bk++) {
+          const uint64_t p0 = kCarry + bk * BLK, n = std::min(BLK, kCarry + Lp - p0);
+          if (J.piece_of >= 0) {
+            const uint64_t at = p0 - kCarry, data = at < J.piece_data ? std::min(n, J.piece_data - at) : 0;
+            memcpy(buf, bases + J.piece_from + at, data);
+            memset(buf + data, '\n', n - data);  // the read's separator (if it ends here) and the padding
+          } else {
+            uint64_t p = p0;
+            while (p < p0 + n) {
+              if (i >= nwhole) { memset(buf + (p - p0), '\n', p0 + n - p); break; }
+              const uint64_t s_ = start_of(i), len = off[r0 + i + 1] - off[r0 + i];
+              if (p < s_ + len) {
+                const uint64_t cnt = std::min(s_ + len - p, p0 + n - p);
+                memcpy(buf + (p - p0), bases + off[r0 + i] + (p - s_), cnt);
+                p += cnt;
+              } else {  // the read's separator, then the next read
+                buf[p - p0] = '\n';
+                p++;
+                i++;
+              }
             }
           }
+          pack_block(buf, (size_t)n, J.hcode + p0 / 16, J.hinv + p0 / 16);
         }
-        pack_block(buf, (size_t)n, hcode + p0 / 16, hinv + p0 / 16);
-      }
       }
     };
-    // one pass from the reads to the packed chunk where the host has AVX-512 (pack_reads_avx512); else assemble + pack
-    const PackReads PR{bases, off, r0, piece_of >= 0 ? 1 : nwhole, kCarry, piece_of >= 0, piece_from, piece_data};
-    auto work_fused = [&](int ti) {
-#if defined(__x86_64__)
-      constexpr uint64_t BLK = 16384, kRun = 16;
-      const uint64_t nblk = (Lp + BLK - 1) / BLK;
-      for (uint64_t q = nwhole * (uint64_t)ti / (uint64_t)T, qe = nwhole * (uint64_t)(ti + 1) / (uint64_t)T; q < qe; q++) hoff[q] = start_of(q);
-      for (;;) {
-        const uint64_t b_lo = next_run.fetch_add(kRun, std::memory_order_relaxed), b_hi = std::min(nblk, b_lo + kRun);
-        if (b_lo >= nblk) break;
-        pack_reads_avx512(PR, kCarry + b_lo * BLK, std::min(kCarry + b_hi * BLK, kCarry + Lp), hcode, hinv);
-      }
-#else
-      (void)ti;
-#endif
-    };
-    const bool fused = pack_reads_available();
-    const double tq2 = now_s();
-    if (T > 1 && Lp >= (1u << 20)) {
-      if (fused) StagePool::get().run(T, work_fused); else StagePool::get().run(T, work);
-    } else {
-      for (int ti = 0; ti < T; ti++) { if (fused) work_fused(ti); else work(ti); }  // small chunk: every share on this thread
-    }
-    const double tq3 = now_s();
-    memcpy(carry_code, hcode + total / 16 - kCarry / 16, sizeof(carry_code));
-    memcpy(carry_inv, hinv + total / 16 - kCarry / 16, sizeof(carry_inv));
+    J.async = T > 1 && J.Lp >= (1u << 20);
+    if (J.async) StagePool::get().begin(T, J.fn);
+    else for (int ti = 0; ti < T; ti++) J.fn(ti);  // small chunk: every share on this thread
+  };
+  auto pack_end = [&](Job &J) {
+    if (J.async) { StagePool::get().finish(); J.async = false; }
+    memcpy(carry_code, J.hcode + J.total / 16 - kCarry / 16, sizeof(carry_code));
+    memcpy(carry_inv, J.hinv + J.total / 16 - kCarry / 16, sizeof(carry_inv));
+  };
+  // (an error return must not leave pool threads working on this frame)
+  struct Drain { Job *jobs; ~Drain() { for (int i = 0; i < 2; i++) if (jobs[i].async) { StagePool::get().finish(); jobs[i].async = false; } } } drain{jobs};
+
+  // submit: copies on the copy stream, background flush if the device was starved, kernels
+  auto submit = [&](Job &J) -> int {
+    const int b = J.b;
     uint8_t *ds = g->d_stage[b];
     // The chunk travels on the copy stream; the graph's stream waits for it between two timing events.  How long the
     // previous use of this buffer pair made the compute stream wait (the events' distance) says whether the device
@@ -1913,10 +1960,10 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
     // the wait.  (Until round 4 the copies ran on the graph's stream and "idle" was hipStreamQuery of it: with PCIe
     // as the bottleneck that stream is never empty, no background flush ever ran, and the whole flush -- 39 ms for
     // the bench's 6 G occurrences -- came after the last chunk.)
-    HIP_TRY(hipMemcpyAsync(ds, hcode, total / 16 * 4, hipMemcpyHostToDevice, g->cstream));
-    HIP_TRY(hipMemcpyAsync(ds + inv_at, hinv, total / 16 * 2, hipMemcpyHostToDevice, g->cstream));
-    if (nwhole)
-      HIP_TRY(hipMemcpyAsync(ds + off_region, hoff, (nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->cstream));
+    HIP_TRY(hipMemcpyAsync(ds, J.hcode, J.total / 16 * 4, hipMemcpyHostToDevice, g->cstream));
+    HIP_TRY(hipMemcpyAsync(ds + inv_at, J.hinv, J.total / 16 * 2, hipMemcpyHostToDevice, g->cstream));
+    if (J.nwhole)
+      HIP_TRY(hipMemcpyAsync(ds + off_region, J.hoff, (J.nwhole + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->cstream));
     HIP_TRY(hipEventRecord(g->ev_copy[b], g->cstream));
     {
       int starved = hipStreamQuery(g->stream) == hipSuccess ? 1 : 0;  // nothing queued at all: certainly waiting for us
@@ -1931,20 +1978,43 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
     HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_copy[b], 0));
     HIP_TRY(hipEventRecord(g->ev_wait1[b], g->stream));
     g->ev_wait_used[b] = true;
-    StreamLaunch SL{nullptr, total, kCarry - (uint64_t)g->k, total - (uint64_t)g->k, piece_of >= 0 ? d_flags + piece_of : nullptr,
+    StreamLaunch SL{nullptr, J.total, kCarry - (uint64_t)g->k, J.total - (uint64_t)g->k, J.piece_of >= 0 ? d_flags + J.piece_of : nullptr,
                     reinterpret_cast<const uint32_t *>(ds), reinterpret_cast<const uint16_t *>(ds + inv_at)};
     int rc = submit_stream(g, SL, colour);
     if (rc != MCX_OK) return rc;
     HIP_TRY(hipSetDevice(g->device));
-    if (nwhole) {
-      hipLaunchKernelGGL(k_read_flags_packed, dim3((unsigned)((nwhole + 255) / 256)), dim3(256), 0, g->stream,
-                         reinterpret_cast<const uint16_t *>(ds + inv_at), (const uint64_t *)(ds + off_region), nwhole, g->k, d_flags + r0);
+    if (J.nwhole) {
+      hipLaunchKernelGGL(k_read_flags_packed, dim3((unsigned)((J.nwhole + 255) / 256)), dim3(256), 0, g->stream,
+                         reinterpret_cast<const uint16_t *>(ds + inv_at), (const uint64_t *)(ds + off_region), J.nwhole, g->k, d_flags + J.r0);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(g->ev[b], g->stream));
-    const double tq4 = now_s();
-    g_stage_timing.wait += tq1 - tq0; g_stage_timing.prep += tq2 - tq1; g_stage_timing.pack += tq3 - tq2; g_stage_timing.submit += tq4 - tq3;
     g_stage_timing.chunks++;
+    return MCX_OK;
+  };
+
+  if (!nreads) return MCX_OK;
+  int cur = 0, rc = plan(jobs[0]);
+  if (rc != MCX_OK) return rc;
+  pack_begin(jobs[0]);
+  for (;;) {
+    Job &J = jobs[cur];
+    const double t0 = now_s();
+    pack_end(J);  // (its last positions are the next chunk's carry)
+    const double t1 = now_s();
+    g_stage_timing.pack += t1 - t0;
+    const bool more = r < nreads;
+    if (more) {
+      rc = plan(jobs[cur ^ 1]);
+      if (rc != MCX_OK) return rc;
+      pack_begin(jobs[cur ^ 1]);
+    }
+    const double t2 = now_s();
+    rc = submit(J);
+    if (rc != MCX_OK) return rc;
+    g_stage_timing.submit += now_s() - t2;
+    if (!more) break;
+    cur ^= 1;
   }
   return MCX_OK;
 }

@@ -226,23 +226,22 @@ static int group_route_spill(mcx_group *G, int idx, int b)
     for (int j = 0; j < N; j++) {
       mcx_graph *own = G->part[j];
       GRP_TRY(hipSetDevice(own->device));
-      uint8_t *r = nullptr, *o = nullptr, *d = nullptr;
-      unsigned long long *cnt = nullptr;
-      GRP_TRY(hipMalloc((void **)&r, n * recb));
-      GRP_TRY(hipMalloc((void **)&o, n));
-      GRP_TRY(hipMalloc((void **)&d, n * recb));
-      GRP_TRY(hipMalloc((void **)&cnt, 8));
+      DevBuf<uint8_t> r, o, d;  // (freed on every way out; the owner's stream is synchronised before the normal one)
+      DevBuf<unsigned long long> cnt;
+      GRP_TRY(r.alloc(n * recb));
+      GRP_TRY(o.alloc(n));
+      GRP_TRY(d.alloc(n * recb));
+      GRP_TRY(cnt.alloc(1));
       GRP_TRY(hipMemcpyPeerAsync(r, own->device, s.sp_recs, me->device, n * recb, own->stream));
       GRP_TRY(hipMemcpyPeerAsync(o, own->device, s.sp_own, me->device, n, own->stream));
       GRP_TRY(hipMemsetAsync(cnt, 0, 8, own->stream));
       const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
-      if (W == 1) hipLaunchKernelGGL(k_superk_pick<1>, dim3(blocks), dim3(256), 0, own->stream, (const void *)r, (const uint8_t *)o, n, (uint32_t)j, (void *)d, cnt);
-      else hipLaunchKernelGGL(k_superk_pick<2>, dim3(blocks), dim3(256), 0, own->stream, (const void *)r, (const uint8_t *)o, n, (uint32_t)j, (void *)d, cnt);
+      if (W == 1) hipLaunchKernelGGL(k_superk_pick<1>, dim3(blocks), dim3(256), 0, own->stream, (const void *)r.p, (const uint8_t *)o.p, n, (uint32_t)j, (void *)d.p, cnt.p);
+      else hipLaunchKernelGGL(k_superk_pick<2>, dim3(blocks), dim3(256), 0, own->stream, (const void *)r.p, (const uint8_t *)o.p, n, (uint32_t)j, (void *)d.p, cnt.p);
       GRP_TRY(hipGetLastError());
-      int rc = mcx_graph_add_superk_dev(own, colour, d, cnt, 1, n, n * 16);
+      int rc = mcx_graph_add_superk_dev(own, colour, d.p, cnt.p, 1, n, n * 16);
+      (void)hipStreamSynchronize(own->stream);  // the buffers are released when this scope ends
       if (rc != MCX_OK) return rc;
-      GRP_TRY(hipStreamSynchronize(own->stream));
-      (void)hipFree(r); (void)hipFree(o); (void)hipFree(d); (void)hipFree(cnt);
     }
     GRP_TRY(hipSetDevice(me->device));
     return MCX_OK;
@@ -251,16 +250,16 @@ static int group_route_spill(mcx_group *G, int idx, int b)
   for (int j = 0; j < N; j++) {
     mcx_graph *own = G->part[j];
     GRP_TRY(hipSetDevice(own->device));
-    uint64_t *k = nullptr;
-    uint8_t *e = nullptr;
-    GRP_TRY(hipMalloc((void **)&k, n * 8 * W));
-    GRP_TRY(hipMalloc((void **)&e, n));
-    GRP_TRY(hipMemcpyPeerAsync(k, own->device, s.ov_keys + at * W, me->device, n * 8 * W, own->stream));
-    GRP_TRY(hipMemcpyPeerAsync(e, own->device, s.ov_edges + at, me->device, n, own->stream));
-    DISPATCH_WC(own, launch_insert_tuples_t, own, colour, (const uint64_t *)k, (const uint8_t *)e, n, 1u);
-    GRP_TRY(hipGetLastError());
-    GRP_TRY(hipStreamSynchronize(own->stream));
-    (void)hipFree(k); (void)hipFree(e);
+    DevBuf<uint64_t> k;
+    DevBuf<uint8_t> e;
+    GRP_TRY(k.alloc(n * W));
+    GRP_TRY(e.alloc(n));
+    GRP_TRY(hipMemcpyPeerAsync(k.p, own->device, s.ov_keys + at * W, me->device, n * 8 * W, own->stream));
+    GRP_TRY(hipMemcpyPeerAsync(e.p, own->device, s.ov_edges + at, me->device, n, own->stream));
+    DISPATCH_WC(own, launch_insert_tuples_t, own, colour, (const uint64_t *)k.p, (const uint8_t *)e.p, n, 1u);
+    const hipError_t le = hipGetLastError();
+    (void)hipStreamSynchronize(own->stream);  // the buffers are released when this scope ends
+    GRP_TRY(le);
   }
   GRP_TRY(hipSetDevice(me->device));
   return MCX_OK;
