@@ -371,7 +371,9 @@ def c2_stress(mcx, device, nsteps, batch_reads, slots=1 << 33):
     import torch
     steps = [make_batch_iid(batch_reads, seed=7000 + i, device=device) for i in range(nsteps)]
     try:
-        r = run_config(mcx, steps, K, 1, [0] * nsteps, slots, int(nsteps * batch_reads * (READ_LEN - K + 1) * 1.02) + (1 << 24))
+        # (flush size: the stream positions of all steps, as for C4 -- a device-resident launch is booked with the positions
+        # it covers until it has settled -- so that the build really makes ONE table pass: 2 M sub-table visits, not 4 M)
+        r = run_config(mcx, steps, K, 1, [0] * nsteps, slots, nsteps * batch_reads * (READ_LEN + 1) + (1 << 26))
     finally:
         del steps
         torch.cuda.empty_cache()

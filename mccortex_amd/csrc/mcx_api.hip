@@ -590,7 +590,10 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
   constexpr bool kWide = W == 1 && !IN_FULL;
   static const bool wide = kWide && [] { const char *e = getenv("MCX_SPLIT_T"); return !e || atoi(e) == 512; }();
   const bool use_wide = wide && bs.nlocal <= 1024;
-  const uint64_t tile = use_wide ? 512 * 16 : kTile;
+  // ... and into up to 2048 bins (tables beyond 2^32 slots) with ONE 1024-thread block per CU and tiles of 16384 tuples:
+  // 8 tuples per bin and tile where the 256-thread kernel has 2 (C2-stress, 2^33 slots: 56 -> 36 ms per 6 G tuples, round 4)
+  const bool use_huge = wide && !use_wide && bs.nlocal <= (uint32_t)kMaxBins;
+  const uint64_t tile = use_huge ? 1024 * 16 : use_wide ? 512 * 16 : kTile;
   const uint64_t nchunks = (in.seg_cap + tile - 1) / tile * in.nseg;
   if (!nchunks) return;
   InsertSink<W, ONECOL> is{g->t, (uint32_t)colour};
@@ -603,11 +606,18 @@ static void launch_bin_tuples_t(mcx_graph *g, TupleIn in, int colour, BinSpec bs
     allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD>, sizeof(BinLds<W, kMaxBins, false>));
     if constexpr (kWide) allow_lds(k_tuples_bin<W, ONECOL, 512, IN_FULL, SHARD, 512>, sizeof(BinLds<W, 512, false, GeoW>));
     if constexpr (kWide) allow_lds(k_tuples_bin<W, ONECOL, 1024, IN_FULL, SHARD, 512>, sizeof(BinLds<W, 1024, false, GeoW>));
+    if constexpr (kWide) allow_lds(k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD, 1024>, sizeof(BinLds<W, kMaxBins, false, Geo<1024, 1024 * 16>>));
     once = true;
   }
   SpanGuard sp(g, "k_tuples_bin");
   const uint64_t gmax = (uint64_t)(g->grid_split ? g->grid_split : g->grid * 4);
   if constexpr (kWide) {
+    if (use_huge) {
+      using GeoH = Geo<1024, 1024 * 16>;
+      const dim3 gridh((unsigned)std::min<uint64_t>(nchunks, g->grid_split ? gmax : gmax / 4));
+      hipLaunchKernelGGL((k_tuples_bin<W, ONECOL, kMaxBins, IN_FULL, SHARD, 1024>), gridh, dim3(1024), sizeof(BinLds<W, kMaxBins, false, GeoH>), g->stream, in, bs, out, is, g->d_ctr);
+      return;
+    }
     if (use_wide) {
       const dim3 gridw((unsigned)std::min<uint64_t>(nchunks, g->grid_split ? gmax : gmax / 2));
       if (bs.nlocal <= 512)

@@ -121,6 +121,36 @@ def test_benchmark_geometry_matches_oracle(mcx, orc, c2_batches, k):
         assert (int(nk[0]), int(sc[0])) == (want[1], st.num_kmers_loaded), (k, name)
 
 
+def test_huge_table_geometry_matches_oracle(mcx, orc):
+    """GPU vs ORACLE on a table beyond 2^32 slots (2^33 slots = 128 GiB: 1024 regions x 2048 sub-tables, the C2-stress
+    shape): the split into 2048 sub-table bins runs with 1024-thread blocks and tiles of 16384 tuples (round 4), the
+    k-merising kernel with 1024 region bins.  300 k reads; both split geometries must give the oracle's records."""
+    import subprocess
+    b, o = synth.reads(300_000, 150, genome_len=3_000_000, seed=33, n_frac=0.02)
+    og = orc.Graph(31, 1, 1 << 26)
+    st = og.add_reads(0, b, o)
+    body = og.body_array(False)
+    want = (mcx.records_checksum(body, 31, 1), og.nkmers)
+    del body, og
+    g = mcx.Graph(31, 1, 1 << 33)
+    g.add_reads(0, b, o)
+    g.sync()
+    ds = g.device_stats()
+    got = g.checksum()
+    prof_ok = g.nkmers == want[1]
+    g.close()
+    assert got == want and prof_ok
+    assert (ds.num_kmers_loaded, ds.contigs_parsed) == (st.num_kmers_loaded, st.contigs_parsed)
+    # ... and the 256-thread split of the same bins (MCX_SPLIT_T=256), in a process of its own (the choice is read once)
+    prog = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import synth, mccortex_amd as mcx; "
+            "b, o = synth.reads(300_000, 150, genome_len=3_000_000, seed=33, n_frac=0.02); g = mcx.Graph(31, 1, 1 << 33); "
+            "g.add_reads(0, b, o); g.sync(); print('CS', *g.checksum())") % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, MCX_SPLIT_T="256"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-1500:]
+    line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("CS")][-1].split()
+    assert (int(line[1]), int(line[2])) == want
+
+
 def test_c2_full_size_all_paths_agree(mcx, c2_batches):
     import torch
     from mccortex_amd import shard
