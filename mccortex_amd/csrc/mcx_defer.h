@@ -114,8 +114,8 @@ constexpr int kStage = kTile / kRounds;
 // Geometry of a binning block: T threads, TILE tuples per tile (staged in kRounds rounds).  The
 // k-merising kernel and the super-k-mer kernels use 256 x 16; the split uses 512 x 16: its runs per
 // sub-table bin are twice as long (128 B), so fewer of its lines are written in two halves.
-template <int T_, int TILE_> struct Geo {
-  static constexpr int kT = T_, kTileG = TILE_, kStageG = TILE_ / kRounds;
+template <int T_, int TILE_, int R_ = kRounds> struct Geo {
+  static constexpr int kT = T_, kTileG = TILE_, kRoundsG = R_, kStageG = TILE_ / R_;
 };
 using Geo256 = Geo<kThreads, kTile>;
 
@@ -336,7 +336,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
     const uint32_t b = L.sbin[q];
     emit(p, b, L.gbase[b], L.skey[q * W], W == 2 ? L.skey[q * W + W - 1] : 0);
   }
-  if (round + 1 < kRounds) __syncthreads();  // staging is reused by the next round
+  if (round + 1 < LDS::geo::kRoundsG) __syncthreads();  // staging is reused by the next round
 }
 
 // The lane's 16 k-mers and their reverse complements as windows of two 96-bit registers (one-word
@@ -682,13 +682,16 @@ __device__ __forceinline__ uint64_t tuple_seg_phys(const TupleIn &in, uint32_t s
 // T threads x 16 tuples per tile: 256 (4 blocks per CU), or 512 (2 blocks per CU, one-word keys; the launch
 // bound is waves per SIMD, 4 either way): runs of
 // 16 tuples = 128 bytes per sub-table bin and tile instead of 8.
-template <int W, bool ONECOL, int NB, bool IN_FULL, bool SHARD, int T = kThreads>
-__global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
+// (R staging rounds, P tuples per lane.  Tried for two-word tuples in round 4, C4, isolated split 32.6 ms: 512 x 16 in
+// four rounds: 109 ms, 432 bytes of scratch per lane; 512 x 8 -- 16 waves per CU instead of 8 -- 31.9 ms: that split
+// moves its 140 GB at 4.4 TB/s either way.  Neither is launched.)
+template <int W, bool ONECOL, int NB, bool IN_FULL, bool SHARD, int T = kThreads, int R = kRounds, int P = 16>
+__global__ __launch_bounds__(T, (W == 1 || T > kThreads ? 4 : 3)) void k_tuples_bin(TupleIn in, BinSpec bs, BinOut out,
                                                                          InsertSink<W, ONECOL> isink_arg, Counters *ctr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  using LDS = BinLds<W, NB, false, Geo<T, T * 16>>;
-  constexpr int kThreads = T, kTile = T * 16;  // (shadow the 256 x 16 geometry of the other kernels)
+  using LDS = BinLds<W, NB, false, Geo<T, T * P, R>>;
+  constexpr int kThreads = T, kTile = T * P;  // (shadow the 256 x 16 geometry of the other kernels)
   LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
   // (as in k_stream_bin: the table's description is read from LDS by the rare paths, so that its
   // twenty arguments do not occupy scalar registers through the tile loop)
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_tuples_bin(TupleIn in, 
       loc[q] |= bin_rank<LDS>(L, loc[q]) << 16;
     bin_commit<LDS, NB>(L, bs, out, ob0, res);
     MCX_PH(3)
-    for (int round = 0; round < kRounds; round++) {
+    for (int round = 0; round < R; round++) {
 #pragma unroll
       for (int q = 0; q < PER; q++)
         bin_place<W, false, LDS>(L, round, loc[q] >> 16, loc[q] & 0xffffu, tk[q], 0);

@@ -36,7 +36,7 @@ def run(name, k, ncols, colours, slots=1 << 30, defer_tuples=6_000_000_000):
 if "c2" in what:
     run("C2 k=31", 31, 1, [0] * nsteps, defer_tuples=8_000_000_000)
 if "c4" in what:
-    run("C4 k=63", 63, 1, [0] * nsteps, defer_tuples=5_000_000_000)
+    run("C4 k=63", 63, 1, [0] * nsteps, defer_tuples=int(os.environ.get("C4_DEFER", "5000000000")))
 if "c5" in what:
     run("C5-like 4 colours blocks", 31, 4, [min(3, 4 * i // nsteps) for i in range(nsteps)], defer_tuples=int(os.environ.get("C5_DEFER", "6000000000")))
 if "c5i" in what:
