@@ -800,7 +800,15 @@ static BinOut l1_out(const mcx_graph *g, int set)
 // one group of regions at a time.
 static int flush_deferred(mcx_graph *g)
 {
-  if (!g->pending && !g->pending_l2) return MCX_OK;
+  if (!g->pending && !g->pending_l2) {
+    // Nothing buffered -- but a set may still be bound to a colour: the settled-launch bookkeeping (snap_poll) takes
+    // what a launch did not yield off the books, down to zero for launches that yielded no k-mer at all (reads
+    // shorter than k, all-N batches).  The bins are empty then, so the sets are free again; without this a later
+    // request larger than a set (accepted only for a FREE set) found neither room nor a free set after "the flush"
+    // ("internal: no L1 bin set after a flush": seed 210 of the round-4 soak).
+    sets_release(g);
+    return MCX_OK;
+  }
   HIP_TRY(hipSetDevice(g->device));
   // tuples that were split on arrival occupy bins of all regions: everything goes through them
   const uint32_t G = g->pending_l2 ? g->b1 : std::min(flush_group(g), g->l2_regions);

@@ -604,3 +604,24 @@ def test_device_ceiling_microbenchmarks_and_flush_overlap_switch(mcx, orc):
         g.add_reads(0, b, o)
         assert g.export(True) == want
         g.close()
+
+
+def test_batch_without_kmers_then_another_colour(mcx, orc, monkeypatch):
+    """A batch that yields no k-mer at all (reads shorter than k) leaves its bin set bound to its colour with nothing
+    on the books once its launch has settled; with ONE bin set the next colour needs that set back, and the flush that
+    would release it has nothing to flush.  Seed 210 of the round-4 soak: "no L1 bin set after a flush"."""
+    import time
+    monkeypatch.setenv("MCX_L1_SETS", "1")
+    short_b, short_o = synth.reads(66, 17, genome_len=3000, seed=5)
+    big_b, big_o = synth.reads(1600, 170, genome_len=40_000, seed=6, n_frac=0.02)
+    og = orc.Graph(29, 2, 1 << 20)
+    og.add_reads(1, short_b, short_o)
+    og.add_reads(0, big_b, big_o)
+    g = mcx.Graph(29, 2, 1 << 20)
+    g.configure("defer_tuples", 1 << 20)
+    g.add_reads(1, short_b, short_o)
+    time.sleep(0.3)              # (the launch settles: its counter snapshot reaches the host)
+    g.add_reads(0, big_b, big_o)
+    g.sync()
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    g.close()
