@@ -42,7 +42,7 @@ def test_every_odd_k(mcx, orc, k):
     g.close()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MCX_FUZZ_SEEDS_BYTES", "6"))))
 def test_arbitrary_bytes_and_ragged_lengths(mcx, orc, seed):
     rng = np.random.default_rng(100 + seed)
     alphabet = np.concatenate([np.frombuffer(b"ACGT" * 40 + b"acgtNn\n\r\t @+>", np.uint8), rng.integers(0, 256, 30).astype(np.uint8)])
@@ -75,7 +75,7 @@ def test_stream_boundaries_are_separators(mcx, orc):
     g.close()
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MCX_FUZZ_SEEDS_BYTES", "4"))))
 def test_superkmer_records_on_arbitrary_bytes(mcx, orc, seed):
     """Exchange format v3 on arbitrary byte streams and ragged lengths: the union of the owner
     tables (simulated shards) is the oracle's graph."""

@@ -1,4 +1,6 @@
 """build --remove-pcr on the GPU (mcx_graph_add_reads_pcr) against the restatement walking the reads in order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -138,7 +140,7 @@ def test_argument_errors(mcx, orc):
     g.close()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MCX_FUZZ_SEEDS_BYTES", "6"))))
 def test_fuzz_arbitrary_bytes_lengths_and_cutoffs(mcx, orc, seed):
     """reads of arbitrary bytes and lengths (0 .. 3 k), arbitrary qualities, random preferences, in several batches"""
     rng = np.random.default_rng(300 + seed)
