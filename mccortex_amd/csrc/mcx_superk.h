@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(Super
     const SkRec<W> *recs = reinterpret_cast<const SkRec<W> *>(in.recs) + (uint64_t)seg * in.seg_cap;
     for (uint64_t pos = c0; pos < c1;) {  // uniform
       __syncthreads();
-      for (uint32_t b = tid; b < bs.nlocal; b += kThreads) { L.cnt[b] = 0; L.rnk[b] = 0; }
+      for (uint32_t b = tid; b < bs.nlocal; b += kThreads) L.cnt[b] = 0;
       // four candidate records per lane, their k-mer counts, inclusive scan over the block
       SkRec<W> rr[kSkPerLane];
       uint32_t ll[kSkPerLane];
@@ -418,16 +418,17 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(Super
           const uint32_t G = r ^ mix_g(region_mix<W>(qq), lbq);
           const uint32_t local = G & ((1u << isink.t.lb1) - 1u);
           tk[j] = tuple_pack<W>(qq, e);
-          tle[j] = local << 8;
           vmask |= 1u << j;
-          atomicAdd(&L.cnt[local], 1u);
+          // (the counting atomic returns the tuple's arrival index in its bin: with the bin's offset that is its
+          // sorted position -- no second atomic per tuple, as in k_stream_bin)
+          tle[j] = (local << 8) | (atomicAdd(&L.cnt[local], 1u) << 19);
         }
       }
       BinRes<NB> res;
       bin_reserve<LDS, NB>(L, bs, out, ob0, res);   // (its first barrier also ends the reads of s_rec / s_map)
 #pragma unroll
       for (int j = 0; j < kPosPerLane; j++)
-        if (j < nj && (vmask & (1u << j))) tle[j] |= bin_rank<LDS>(L, (tle[j] >> 8) & 0x7ffu) << 19;
+        if (j < nj && (vmask & (1u << j))) tle[j] += L.off[(tle[j] >> 8) & 0x7ffu] << 19;
       bin_commit<LDS, NB>(L, bs, out, ob0, res);
       for (int round = 0; round < kRounds; round++) {
         if ((uint32_t)round * kStage < T) {  // uniform
