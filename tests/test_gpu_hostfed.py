@@ -68,3 +68,12 @@ def test_idle_flushes_that_start_on_a_nearly_full_workspace():
     host, dev = _run(env, defer=400_000_000)   # 3 x 240 M occurrences through a 400 M workspace
     assert host[:4] == dev[:4]
     assert host[2] > 700_000_000
+
+
+def test_host_entry_without_the_one_pass_packer():
+    """Hosts without AVX-512 VBMI2 assemble 16 KiB blocks of the stream as ASCII and pack those (MCX_FUSED_PACK=0 forces
+    that path; the SWAR packer with MCX_NO_AVX2=1): same graph as the device-resident build."""
+    for extra in ({"MCX_FUSED_PACK": "0"}, {"MCX_NO_AVX2": "1"}):
+        env = dict(os.environ, MCX_STAGE_BYTES=str(32 << 20), **extra)
+        host, dev = _run(env)
+        assert host[:4] == dev[:4], extra
