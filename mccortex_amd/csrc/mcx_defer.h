@@ -904,36 +904,46 @@ __device__ __forceinline__ bool lds_apply(unsigned long long *lds, const Kmer<W>
   const unsigned long long want = key.w[0] | kFlag;
   uint32_t steps = 0;
   if constexpr (W == 1) {
+    // A whole bucket per step (both 16-byte halves of its keys, as in lds_try).  Until round 4 this loop looked at two
+    // slots per step: at high load factors (hashtest: 800 M keys into 2^30 slots; C2-stress) the general loop is where
+    // the insert spends its time -- 66 % / 49 % of a sub-table visit -- and every step is a dependent LDS round trip.
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef MCX_LDS_AS const volatile u64x2 lds_cv;  // (volatile: re-read on every step)
-    uint32_t s = bucket * kBucket;                  // logical slot of the pair being examined
+    uint32_t b = bucket;
     for (;;) {
-      const uint32_t p = lds_phys1(s);
-      const u64x2 kk = *(lds_cv *)(lds + p);
-      int hit = -1, empty = -1;
-      if (kk.y == 0) empty = 1;
-      if (kk.x == 0) empty = 0;
-      if (kk.y == want) hit = 1;
-      if (kk.x == want) hit = 0;
-      if (hit >= 0) {
-        unsigned long long *val = lds + kLdsVal1 + p + hit;
+      const uint32_t sw = (b >> 3) & 1u;
+      unsigned long long *b0 = lds + b * kBucket;
+      unsigned long long *h0 = b0 + 2 * sw, *h1 = b0 + 2 * (sw ^ 1u);  // logical slots 0-1, 2-3
+      const u64x2 lo = *(lds_cv *)h0;
+      const u64x2 hi = *(lds_cv *)h1;
+      unsigned long long *hit = nullptr, *emp = nullptr;
+      if (hi.y == 0) emp = h1 + 1;
+      if (hi.x == 0) emp = h1;
+      if (lo.y == 0) emp = h0 + 1;
+      if (lo.x == 0) emp = h0;  // (the first empty slot in probe order)
+      if (hi.y == want) hit = h1 + 1;
+      if (hi.x == want) hit = h1;
+      if (lo.y == want) hit = h0 + 1;
+      if (lo.x == want) hit = h0;
+      if (hit) {
+        unsigned long long *val = hit + kLdsVal1;
         const unsigned long long old = atomicAdd(val, 256ULL);
         if (e & ~(uint32_t)old) atomicOr(val, (unsigned long long)e);
         return true;
       }
-      if (empty >= 0) {
-        if (atomicCAS(lds + p + empty, 0ULL, want) == 0) {
-          unsigned long long *val = lds + kLdsVal1 + p + empty;
+      if (emp) {
+        if (atomicCAS(emp, 0ULL, want) == 0) {
+          unsigned long long *val = emp + kLdsVal1;
           n_novel++;
           atomicAdd(val, 256ULL);
           if (e) atomicOr(val, (unsigned long long)e);
           return true;
         }
         if (++steps > (1u << 22)) { full = 1; return true; }
-        continue;  // somebody took the slot: look at the pair again
+        continue;  // somebody took the slot: look at the bucket again
       }
-      s = (s + 2) & (uint32_t)(Sub<W>::kSlots - 1);
-      if (s == bucket * kBucket) return false;  // a full sub-table: every slot seen without a hit or a free one
+      b = (b + 1) & (uint32_t)(Sub<W>::kBuckets - 1);
+      if (b == bucket) return false;  // a full sub-table: every slot seen without a hit or a free one
     }
   } else {
     // slot j of bucket b: first key word at sp(j), the second kK1 words further on, the value kV

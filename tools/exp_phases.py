@@ -41,6 +41,24 @@ def main():
     dev = torch.device("cuda", 0)
     L = mcx.lib()
     L.mcx_debug_phases.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    if os.environ.get("PHASES_CFG") == "hashtest":  # the reference's hashtest: 800 M integer keys into 2^30 slots
+        n = 800_000_000
+        keys = torch.arange(n, dtype=torch.int64, device=dev)
+        edges = torch.zeros(n, dtype=torch.uint8, device=dev)
+        g = mcx.Graph(31, 1, 1 << 30)
+        g.configure("flush_overlap", 0)
+        g.insert_tuples_dev(0, keys[:65536], edges[:65536], 65536)
+        g.sync(); g.reset(); g.sync()
+        L.mcx_debug_phases(None, 1)
+        g.configure("profile", 1)
+        for lo in range(0, n, 100_000_000):
+            g.insert_tuples_dev(0, keys[lo:lo + 100_000_000], edges[lo:lo + 100_000_000], 100_000_000)
+        g.sync()
+        prof = g.profile()
+        print("nkmers", g.nkmers)
+        g.close()
+        report(L, "hashtest: %s" % "  ".join("%s %.2f ms (%d)" % (a, t, c) for a, (c, t) in prof.items()))
+        return
     stress = os.environ.get("PHASES_CFG") == "stress"  # C2-stress: iid reads (every k-mer novel), 2^33 slots
     if stress:
         batches = [bench.make_batch_iid(bench.BATCH_READS, seed=7000 + i, device=dev) for i in range(10)]
