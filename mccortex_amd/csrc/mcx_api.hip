@@ -556,7 +556,9 @@ static void launch_bin_stream_pk(mcx_graph *g, const StreamArgs &a, uint64_t nt,
       using GeoW = Geo<512, 512 * kPosPerLane>;
       static bool once_w[64] = {false};
       if (!once_w[g->device & 63]) { allow_lds(k_stream_bin<W, ONECOL, 512, FULL, SH, PK, 512>, sizeof(BinLds<W, 512, FULL, GeoW>)); once_w[g->device & 63] = true; }
-      const dim3 gridw((unsigned)std::min<uint64_t>((nt + 1) / 2, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid / 2)));
+      // (8 blocks per CU for 2 resident: 22.2-22.3 ms per 6 G occurrences at C2 against 22.8 with 4 and 23.5 with 2 --
+      // a finer tail; 64 K blocks: 26.0)
+      const dim3 gridw((unsigned)std::min<uint64_t>((nt + 1) / 2, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid)));
       hipLaunchKernelGGL((k_stream_bin<W, ONECOL, 512, FULL, SH, PK, 512>), gridw, dim3(512), sizeof(BinLds<W, 512, FULL, GeoW>), g->stream, a, bs, out, is);
       return;
     }
