@@ -647,15 +647,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     import torch.distributed as dist
+    from mccortex_amd import shard
+    # (MCX_DIST_BACKEND=gloo + MCX_DIST_ONE_DEVICE=0: shard.py's test transport -- several ranks on the one GPU of a
+    # test box, collectives staged through host memory; the driver's runs never set them)
+    local_rank = shard.local_device(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # MCX_BENCH_FORCE_SHARD=1: run the partition -> all-to-all -> insert path even at N=1
     # (validation of the N>1 code on a 1-GPU box; never used for the reported N=1 number)
     force_shard = os.environ.get("MCX_BENCH_FORCE_SHARD") == "1"
     if world > 1 or force_shard:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        shard.init_process_group(device, rank, world)
 
     import __graft_entry__
     if rank == 0:
@@ -663,7 +666,6 @@ def main():
     if world > 1:
         dist.barrier()
     import mccortex_amd as mcx
-    from mccortex_amd import shard
 
     B = args.batch_reads
     nsteps, nwarm = args.steps, args.warmup
@@ -762,6 +764,8 @@ def main():
     graph.reset()
     fence()
 
+    if sharded:
+        inserter.reset_stats()
     graph.configure("profile", 1)  # HIP events around every kernel launch on the handle's stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -770,6 +774,7 @@ def main():
     fence()
     ev1.record(ext)
     dt = time.perf_counter() - t0
+    dt_local = dt
     torch.cuda.synchronize()
 
     st = graph.device_stats()
@@ -799,18 +804,38 @@ def main():
         graph.configure("flush_overlap", 1)
     ident = torch.tensor([cs_local & 0xFFFFFFFF, cs_local >> 32, nodes_local], dtype=torch.int64, device=device)
     if world > 1:
-        dist.all_reduce(ident, op=dist.ReduceOp.SUM)   # 32-bit halves: the sums cannot overflow
+        shard.all_reduce(ident, op=dist.ReduceOp.SUM)   # 32-bit halves: the sums cannot overflow
     cs_total = (int(ident[0].item()) + (int(ident[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
     nodes_total = int(ident[2].item())
     tot = torch.tensor([float(kmers_local), dt], dtype=torch.float64, device=device)
     if world > 1:
         k_all = tot[:1].clone()
-        dist.all_reduce(k_all, op=dist.ReduceOp.SUM)
+        shard.all_reduce(k_all, op=dist.ReduceOp.SUM)
         t_all = tot[1:].clone()
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        shard.all_reduce(t_all, op=dist.ReduceOp.MAX)
         kmers_total, dt = float(k_all.item()), float(t_all.item())
     else:
         kmers_total = float(kmers_local)
+    # N > 1 diagnostics: what every rank spent per stage (HIP-event spans on its own streams) and put on the links
+    per_rank = None
+    if sharded:
+        stage_of = {"k_stream_superk": "sender", "k_stream_bin": "sender", "k_superk_bin": "owner", "k_tuples_bin": "split",
+                    "k_lds_insert": "insert", "k_insert_tuples": "owner_overflow"}
+        mine = {"rank": rank, "device": local_rank, "wall_s": dt_local,
+                "kmers_kmerised": int(kmers_local), "distinct_kmers_owned": int(nodes_local),
+                "stage_ms": {}, "exchange_ms": round(inserter.stats["exchange_ms"], 3), "exchange_steps": inserter.stats["steps"],
+                "link_bytes_sent": inserter.stats["link_bytes_sent"], "stream_bytes": inserter.stats["stream_bytes"]}
+        for kn, (c, t) in prof.items():
+            st_name = stage_of.get(kn, kn)
+            e = mine["stage_ms"].setdefault(st_name, {"kernel": kn, "launches": 0, "total_ms": 0.0})
+            e["launches"] += c
+            e["total_ms"] = round(e["total_ms"] + t, 3)
+        mine["link_bytes_per_occurrence"] = mine["link_bytes_sent"] / max(1, kmers_local)
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
 
     if rank == 0:
         value = kmers_total / dt
@@ -847,6 +872,14 @@ def main():
         if (world == 1 or strong) and not args.iid and B == BATCH_READS and args.genome == GENOME_PER_GPU and args.err == 0.001 \
                 and READ_LEN == 150 and nsteps in N1_CHECKSUMS:
             out["config"]["checksum_matches_n1"] = ("%016x" % cs_total) == N1_CHECKSUMS[nsteps]
+        if per_rank is not None:
+            out["multi_gpu"] = {"transport": shard.dist_backend() + (" (TEST transport: host-staged collectives, all ranks on one device)"
+                                                                     if shard.dist_backend() != "nccl" else " (RCCL)"),
+                                "exchange_format": "v3" if use_v3 else "v2",
+                                "what": "per rank: HIP-event spans per stage on the graph's stream (sender = k-merise own reads into per-owner bins, owner = k-merise "
+                                        "received super-k-mers into region bins, split = region -> sub-table bins, insert = LDS insert), the exchange's span on torch's "
+                                        "stream, and the bytes the rank sent to OTHER ranks",
+                                "per_rank": per_rank}
         gpu_ms = ev0.elapsed_time(ev1)
         kprof = prof_iso if prof_iso is not None else prof  # isolated durations where they exist
         dom = max(kprof, key=lambda n: kprof[n][1])

@@ -79,14 +79,15 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.path.exists(args.out) and not args.force:   # every rank sees the same file system: all leave
         raise SystemExit("File already exists: %s" % args.out)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
-
     import mccortex_amd as mcx
     from mccortex_amd import seqstream, shard
+
+    # (MCX_DIST_BACKEND=gloo + MCX_DIST_ONE_DEVICE: the test transport of shard.py, several ranks on one GPU)
+    local_rank = shard.local_device(local_rank)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_PORT", "29541")
+    shard.init_process_group(device, rank, world)
 
     k, ncols = args.kmer, len(names)
     # v3 (super-k-mer records, minimizer ownership: every rank holds an ordinary table) when k
@@ -107,7 +108,7 @@ def main(argv=None):
         fmt = seqstream.detect_format(path)
         mine = seqstream.plan_steps(path, fmt, rank, world, args.step_bytes)
         nsteps = torch.tensor([len(mine)], dtype=torch.int64, device=device)
-        dist.all_reduce(nsteps, op=dist.ReduceOp.MAX)       # every rank runs the same number of exchanges
+        shard.all_reduce(nsteps, op=dist.ReduceOp.MAX)       # every rank runs the same number of exchanges
         nsteps = int(nsteps.item())
         for g0 in range(0, nsteps, GROUP):
             steps = []
@@ -124,7 +125,7 @@ def main(argv=None):
         cur = graph.device_stats()
         d = torch.tensor([cur.total_bases_loaded - prev.total_bases_loaded, cur.contigs_parsed - prev.contigs_parsed,
                           cur.num_kmers_loaded - prev.num_kmers_loaded], dtype=torch.int64, device=device)
-        dist.all_reduce(d)
+        shard.all_reduce(d)
         prev = cur
         hdr.update_stats(colour, int(d[0].item()), int(d[1].item()))
         if rank == 0:
@@ -136,7 +137,7 @@ def main(argv=None):
     with open(part, "wb") as f:
         f.write(body)
     nk = torch.tensor([graph.nkmers], dtype=torch.int64, device=device)
-    dist.all_reduce(nk)
+    shard.all_reduce(nk)
     dist.barrier()
     if rank == 0:
         rs = 8 * graph.W + 5 * ncols

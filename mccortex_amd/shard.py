@@ -3,6 +3,8 @@
 The data path is exchange-only: every rank bins its per-occurrence tuples by owner and one
 all-to-all moves each bin to the rank that owns it.  `exchange()` is backend-agnostic host logic;
 the device kernels are reached through the Graph handle (mccortex_amd/graph.py)."""
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -10,12 +12,68 @@ import torch.distributed as dist
 MAX_ROUND = 1 << 24  # tuples per peer per all-to-all round (128 MiB of keys at W=1)
 
 
+# ---- transport ---------------------------------------------------------------------------------
+# The product transport is RCCL ("nccl" backend: device buffers straight onto xGMI).  RCCL refuses two
+# ranks on one device, so a box with ONE GPU can never run rank 1 -- MCX_DIST_BACKEND=gloo is the
+# test-only transport for that box: every collective below stages device tensors through host tensors
+# (device -> host copy, gloo collective over TCP loopback, host -> device copy, all in the order of
+# torch's current stream), and MCX_DIST_ONE_DEVICE=<d> puts every rank on device d.  Everything else --
+# sender / owner kernels, buffer rotation, events, rank-dependent slicing -- is the code RCCL runs with.
+
+def dist_backend():
+    return os.environ.get("MCX_DIST_BACKEND", "nccl")
+
+
+def local_device(local_rank):
+    """device index of this rank: LOCAL_RANK, or MCX_DIST_ONE_DEVICE for all ranks (test transport only)"""
+    one = os.environ.get("MCX_DIST_ONE_DEVICE")
+    if one is not None:
+        if dist_backend() == "nccl":
+            raise SystemExit("MCX_DIST_ONE_DEVICE needs MCX_DIST_BACKEND=gloo (RCCL refuses two ranks on one GPU)")
+        return int(one)
+    return local_rank
+
+
+def init_process_group(device, rank, world):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if dist_backend() == "nccl":
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+    else:
+        dist.init_process_group(dist_backend(), rank=rank, world_size=world)
+
+
+def _staged(t, group):
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def barrier(group=None):
+    dist.barrier(group=group)
+
+
+def all_to_all_single(dst, src, output_split_sizes=None, input_split_sizes=None, group=None):
+    if _staged(src, group):
+        hs, hd = src.contiguous().cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+        dist.all_to_all_single(hd, hs, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+        dst.copy_(hd)
+    else:
+        dist.all_to_all_single(dst, src, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+
+
 def exchange(send_keys, send_edges, counts, group=None):
     """send_keys [world, cap, W] int64, send_edges [world, cap] uint8, counts [world] int64 (same
     device).  Returns (recv_keys [n, W], recv_edges [n], recv_counts list) for this rank."""
     world = dist.get_world_size(group)
     recv_counts = torch.empty_like(counts)
-    dist.all_to_all_single(recv_counts, counts, group=group)
+    all_to_all_single(recv_counts, counts, group=group)
     sc, rc = counts.tolist(), recv_counts.tolist()
     ro = np.concatenate([[0], np.cumsum(rc)]).astype(np.int64)
     W = send_keys.shape[2]
@@ -27,7 +85,7 @@ def exchange(send_keys, send_edges, counts, group=None):
     # (tools/dbg_shard3.py), and bounded rounds also bound the staging RCCL needs.
     # every rank must run the same number of rounds: agree on the largest per-peer message
     gmax = torch.tensor([max(max(sc), max(rc), 1)], dtype=torch.int64, device=counts.device)
-    dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
     for r0 in range(0, int(gmax.item()), MAX_ROUND):
         s_lo = [min(c, r0) for c in sc]
         s_hi = [min(c, r0 + MAX_ROUND) for c in sc]
@@ -48,8 +106,8 @@ def exchange(send_keys, send_edges, counts, group=None):
             outs = [r_hi[p] - r_lo[p] for p in range(world)]
             tk = torch.empty((sum(outs), W), dtype=send_keys.dtype, device=send_keys.device)
             te = torch.empty((sum(outs),), dtype=send_edges.dtype, device=send_edges.device)
-            dist.all_to_all_single(tk, pk, output_split_sizes=outs, input_split_sizes=ins, group=group)
-            dist.all_to_all_single(te, pe, output_split_sizes=outs, input_split_sizes=ins, group=group)
+            all_to_all_single(tk, pk, output_split_sizes=outs, input_split_sizes=ins, group=group)
+            all_to_all_single(te, pe, output_split_sizes=outs, input_split_sizes=ins, group=group)
             o = 0
             for p in range(world):
                 recv_keys[ro[p] + r_lo[p]:ro[p] + r_hi[p]] = tk[o:o + outs[p]]
@@ -73,12 +131,12 @@ def _a2a_rows(dst, src, group):
     for r0 in range(0, rows, step):
         r1 = min(rows, r0 + step)
         if r0 == 0 and r1 == rows:
-            dist.all_to_all_single(dst, src, group=group)
+            all_to_all_single(dst, src, group=group)
         elif nccl:
             dist.all_to_all([dst[p, r0:r1] for p in range(world)], [src[p, r0:r1] for p in range(world)], group=group)
         else:
             tmp = torch.empty_like(src[:, r0:r1].contiguous())
-            dist.all_to_all_single(tmp, src[:, r0:r1].contiguous(), group=group)
+            all_to_all_single(tmp, src[:, r0:r1].contiguous(), group=group)
             dst[:, r0:r1] = tmp
 
 
@@ -114,6 +172,9 @@ class BlockExchange:
         _a2a_rows(recv.keys, self.keys, group)
         _a2a_rows(recv.ov_keys.view(self.world, 1, -1), self.ov_keys.view(self.world, 1, -1), group)
         _a2a_rows(recv.ov_edges.view(self.world, 1, -1), self.ov_edges.view(self.world, 1, -1), group)
+        # whole blocks travel whatever their fill: bytes this rank puts on the links (to the other ranks)
+        per_peer = sum(t[0].numel() * t.element_size() for t in (self.keys, self.counts, self.ov_keys, self.ov_edges, self.ov_counts))
+        return None, per_peer * (self.world - 1)
 
     def consume(self, graph, colour, ntuples):
         """owner: hand received blocks (this object is a receive set) to the graph"""
@@ -150,7 +211,7 @@ class SuperkExchange:
         """recv.recs[p][s][:n] <- rank p's recs[my rank][s][:n]; returns the records received"""
         world = self.world
         mine = self.fills.t().contiguous()                           # [owner][segment]
-        dist.all_to_all_single(recv.counts, mine, group=group)
+        all_to_all_single(recv.counts, mine, group=group)
         sc = torch.clamp(mine, max=self.seg_cap).tolist()             # host read: this step's fills
         rc = torch.clamp(recv.counts, max=self.seg_cap).tolist()
         nccl = dist.get_backend(group) == "nccl"
@@ -163,12 +224,14 @@ class SuperkExchange:
                 outs = [rc[p][s_] for p in range(world)]
                 pk = torch.cat([self.recs[p, s_, :ins[p]] for p in range(world)])
                 tk = torch.empty((sum(outs), self.rec_words), dtype=self.recs.dtype, device=self.recs.device)
-                dist.all_to_all_single(tk, pk, output_split_sizes=outs, input_split_sizes=ins, group=group)
+                all_to_all_single(tk, pk, output_split_sizes=outs, input_split_sizes=ins, group=group)
                 o = 0
                 for p in range(world):
                     recv.recs[p, s_, :outs[p]] = tk[o:o + outs[p]]
                     o += outs[p]
-        return sum(sum(r) for r in rc)
+        me = dist.get_rank(group)
+        sent = sum(sum(sc[p]) for p in range(world) if p != me) * self.rec_words * 8 + (world - 1) * self.segs * 8
+        return sum(sum(r) for r in rc), sent
 
     def consume(self, graph, colour, nrecords):
         """owner: k-merise the received segments (this object is a receive set)"""
@@ -213,6 +276,12 @@ class ShardedInserter:
         self.sent = [torch.cuda.Event() for _ in range(2)]       # send[b] -> recv[b] exchanged   (torch)
         self.consumed = [torch.cuda.Event() for _ in range(2)]   # recv[b] split by the owner     (ext)
         self.used = [False, False]                               # send[b] has been exchanged before
+        # diagnostics (bench.py --gpus N prints them per rank): the exchange's span on torch's stream per
+        # step (HIP events, read after the closing synchronize) and the bytes this rank put on the links
+        self.reset_stats()
+
+    def reset_stats(self):
+        self.stats = {"steps": 0, "exchange_ms": 0.0, "link_bytes_sent": 0, "stream_bytes": 0}
 
     def _partition(self, stream, nbytes, buf):
         if nbytes > self.max_stream_bytes:
@@ -231,6 +300,7 @@ class ShardedInserter:
         if not steps:
             return
         cur = torch.cuda.current_stream()
+        spans = []
         self._partition(steps[0][0], steps[0][1], 0)
         for n, (stream, nbytes) in enumerate(steps):
             buf = n % 2
@@ -239,7 +309,14 @@ class ShardedInserter:
             cur.wait_event(self.filled[buf])
             if self.used[buf]:
                 cur.wait_event(self.consumed[buf])       # recv[buf] is free again
-            got = self.send[buf].exchange_into(self.recv[buf], group=self.group)
+            x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            x0.record(cur)
+            got, sent_bytes = self.send[buf].exchange_into(self.recv[buf], group=self.group)
+            x1.record(cur)
+            spans.append((x0, x1))
+            self.stats["steps"] += 1
+            self.stats["link_bytes_sent"] += int(sent_bytes)
+            self.stats["stream_bytes"] += int(nbytes)
             self.sent[buf].record(cur)
             self.used[buf] = True
             self.ext.wait_event(self.sent[buf])
@@ -247,6 +324,7 @@ class ShardedInserter:
             self.consumed[buf].record(self.ext)
         self.ext.synchronize()
         cur.synchronize()
+        self.stats["exchange_ms"] += sum(a.elapsed_time(b) for a, b in spans)
         for b in self.send:
             if b.overflowed():
                 raise RuntimeError("an exchange bin overflowed (occurrences lost): raise its capacity")

@@ -1,5 +1,8 @@
-"""The multi-GPU build tool end to end on the one GPU of the test box (world size 1, RCCL backend):
-reads -> per-owner bins -> all-to-all -> owners insert -> shards -> one .ctx, byte-identical to the oracle."""
+"""The multi-GPU build tool end to end on the one GPU of the test box:
+reads -> per-owner bins -> all-to-all -> owners insert -> shards -> one .ctx, byte-identical to the oracle.
+World size 1 runs under the RCCL backend; world size 2 / 4 -- rank 1 exists: read slicing, step-count agreement,
+per-rank statistics, shard merge, header-once -- runs as N processes sharing cuda:0 through shard.py's test
+transport (MCX_DIST_BACKEND=gloo: RCCL refuses two ranks on one device), with the real kernels on every rank."""
 import os
 import subprocess
 import sys
@@ -14,17 +17,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, port, env=None):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "mccortex_amd.mgpu_build"] + args
+ONE_GPU = {"MCX_DIST_BACKEND": "gloo", "MCX_DIST_ONE_DEVICE": "0"}
+
+
+def _launch(world, port, tail, env=None, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + tail
     e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    if world > 1:
+        e.update(ONE_GPU)
     e.update(env or {})
-    p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    return p.returncode, p.stderr.decode(errors="replace")
+    p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
 
 
-@pytest.mark.parametrize("k,exchange", [(31, "v3"), (31, "v2"), (21, "v2"), (63, "v2")])
-def test_tool_matches_oracle(mcx, orc, tmp_path, k, exchange):
+def _run(args, port, env=None, world=1):
+    rc, _, err = _launch(world, port, ["-m", "mccortex_amd.mgpu_build"] + args, env)
+    return rc, err
+
+
+@pytest.mark.parametrize("k,exchange,world", [(31, "v3", 1), (31, "v2", 1), (21, "v2", 1), (63, "v2", 1),
+                                              (31, "v3", 2), (31, "v2", 2), (63, "v3", 2), (63, "v2", 2), (21, "v2", 2), (31, "v3", 4)])
+def test_tool_matches_oracle(mcx, orc, tmp_path, k, exchange, world):
     g = synth.genome(30000, 7)
     sets = []
     for i, (fmt, width) in enumerate([("fasta", 23), ("fastq", 0), ("plain", 0)]):
@@ -38,7 +52,7 @@ def test_tool_matches_oracle(mcx, orc, tmp_path, k, exchange):
     out = str(tmp_path / "out.ctx")
     args = ["-k", str(k), "-n", "1M", "--sort", "--step-bytes", "100K", "--sample", "alice", "--seq", sets[0][0], "--seq", sets[1][0],
             "--sample", "bob", "--seq2", sets[2][0] + ":" + sets[0][0], out]
-    rc, err = _run(args, 29600 + k, env={"MCX_EXCHANGE": exchange})
+    rc, err = _run(args, 29600 + k + 100 * world, env={"MCX_EXCHANGE": exchange}, world=world)
     assert rc == 0, err[-3000:]
     og = orc.Graph(k, 2, 1 << 20)
     og.set_sample(0, "alice"); og.set_sample(1, "bob")
@@ -51,8 +65,33 @@ def test_tool_matches_oracle(mcx, orc, tmp_path, k, exchange):
     assert len(got) == len(want) and got == want
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]
     # refuses to overwrite without -f
-    rc, err = _run(args, 29700 + k)
+    rc, err = _run(args, 29700 + k, world=world)
     assert rc != 0 and "already exists" in err
+
+
+def test_bench_two_ranks_strong_reproduces_the_single_gpu_graph(mcx, tmp_path):
+    """bench.py --gpus 2 (strong scaling = BASELINE config C3: the N = 1 reads dealt out to the ranks, the N = 1 table
+    split 2 ways) as two processes on cuda:0: the sum of the ranks' graph checksums and node counts must be what the
+    N = 1 run of the same steps reports, and the line must carry the per-rank stage table."""
+    import json
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batch-reads", "1000000"]
+    e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    one = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    for exchange in ("v3", "v2"):
+        rc, out, err = _launch(2, 29851 + (exchange == "v2"), ["bench.py", "--gpus", "2", "--scaling", "strong"] + common, env={"MCX_EXCHANGE": exchange})
+        assert rc == 0, err[-3000:]
+        two = json.loads(out.strip().splitlines()[-1])
+        assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+        assert two["config"]["graph_checksum"] == one["config"]["graph_checksum"], exchange
+        assert two["config"]["distinct_kmers_total"] == one["config"]["distinct_kmers_total"]
+        assert two["config"]["kmers_inserted"] == one["config"]["kmers_inserted"]
+        ranks = two["multi_gpu"]["per_rank"]
+        assert [r["rank"] for r in ranks] == [0, 1] and two["multi_gpu"]["exchange_format"] == exchange
+        assert sum(r["kmers_kmerised"] for r in ranks) == one["config"]["kmers_inserted"]
+        for r in ranks:
+            assert r["link_bytes_sent"] > 0 and r["exchange_steps"] == 1 and {"sender", "insert"} <= set(r["stage_ms"])
 
 
 @pytest.mark.parametrize("use_v3", [True, False])

@@ -132,7 +132,8 @@ def _superk_worker(rank, world, port, rec_words=2):
     recv = shard.SuperkExchange(world, segs, seg_cap, "cpu", rec_words=rec_words)
     for p in range(world):
         send.fills[:, p], send.recs[p] = stamp(rank, p)
-    n = send.exchange_into(recv)
+    n, sent = send.exchange_into(recv)
+    assert sent == sum(int(stamp(rank, p)[0].sum()) for p in range(world) if p != rank) * rec_words * 8 + (world - 1) * segs * 8
     tot = 0
     for p in range(world):
         cnt, recs = stamp(p, rank)
