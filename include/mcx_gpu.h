@@ -362,6 +362,26 @@ int mcx_graph_nkmers(mcx_graph *g, uint64_t *n);
 /* Contig/k-mer counters accumulated by the device since create/reset. */
 int mcx_graph_device_stats(mcx_graph *g, mcx_load_stats *out);
 
+/* How the inserts went: the slow-but-correct paths ("cliffs") of the partitioned build, made visible.  The
+ * reference prints its own insert diagnostics, the collision histogram of hash_table_print_stats
+ * (src/graph/hash_table.c:301-333); these are the ones this table has.  All zero on well-spread input (bench
+ * C2: asserted in tests/test_gpu_fullsize.py); printed by `mccortex<K> build` under MCX_TIMING=1.
+ *   fallback_inserts  occurrences that did not fit their partition bin (hot k-mers, an owner far above its share)
+ *                     and took the per-occurrence lock-free insert in HBM instead of the LDS insert
+ *   foreign_inserts   occurrences whose key another shard owns, handed to this shard through an entry that does
+ *                     not route (mcx_graph_add_reads on a shard handle): inserted on the spot
+ *   spilled           multi-GPU table: occurrences (exchange v2) / super-k-mer records (v3) that did not fit a
+ *                     send segment and went through the sender's spill area, routed by the host
+ *   flushes           passes over the table made by the partitioned insert (per colour with buffered tuples)
+ * Implies a sync; a multi-GPU handle reports sums over its shards. */
+typedef struct {
+  uint64_t fallback_inserts;
+  uint64_t foreign_inserts;
+  uint64_t spilled;
+  uint64_t flushes;
+} mcx_insert_stats;
+int mcx_graph_insert_stats(mcx_graph *g, mcx_insert_stats *out);
+
 /* HIP stream the handle submits on (hipStream_t as void*), so callers can
  * bracket it with their own events. */
 void *mcx_graph_stream(mcx_graph *g);

@@ -204,15 +204,19 @@ struct mcx_graph {
   // -- a whole table pass -- came that much too early).  After every such launch the device's k-mer counter is
   // copied to a pinned ring slot behind the kernel; when the copy has landed (event query, never a wait) the
   // launches up to it are "settled": what they really yielded is known, and the difference is taken off `pending`.
+  // Round 5: every entry is one launch -- its reservation `ub`, the bin set that took it and which counter it feeds
+  // (0: `kmers`, stream launches; 1: `binned`, the owner side of exchange v3, whose reservation is an upper bound of what
+  // the received records hold) -- so graphs with several colours (bin sets) and the shards of a multi-GPU table settle
+  // too: yield = counter behind the launch - counter behind the previous snapped point (a launch that found the ring
+  // full is not snapped: its yield is then charged to the next entry, which only makes the books more cautious).
   static constexpr uint32_t kSnap = 32;
-  struct Snap { uint64_t cum_ub; bool is_base; hipEvent_t ev; };
-  unsigned long long *h_snap = nullptr;  // pinned [kSnap]: the counter as of slot i
+  struct Snap { uint64_t ub; int set; int which; bool is_base; hipEvent_t ev; };
+  Counters *h_snap = nullptr;  // pinned [kSnap]: the counters as of slot i
   Snap snap[kSnap] = {};
   uint32_t snap_head = 0, snap_tail = 0;  // ring: [tail, head) in flight
-  uint64_t snap_base = 0;                 // the counter when the L1 bins were last empty
+  uint64_t snap_last[2] = {0, 0};         // the two counters at the last settled point
   bool snap_base_known = true;            // (a new graph: counters and bins are zero)
-  uint64_t snap_cum_ub = 0;               // start positions handed to stream launches since then
-  uint64_t snap_slack = 0;                // of those, known not to have yielded a tuple (already taken off `pending`)
+  uint64_t n_flushes = 0;                 // flushes of the partition bins since create / reset (each = a table pass per colour)
   // ---- build --intersect (ctx_build.c:341-363,384-413) ----
   int hidden = -1;              // colour that holds the intersection graphs' edges, or -1
   int ncols_vis = 0;            // colours that are exported / scanned (ncols, or ncols - 1)
@@ -233,6 +237,8 @@ struct mcx_graph {
 };
 
 // how the kernels that walk records / reads on every shard tell their own keys (mcx_kernels.h: OwnerSpec)
+static uint8_t *touch_base(const mcx_graph *g) { return reinterpret_cast<uint8_t *>(g->t.touch) - kTouchHdr; }
+
 static OwnerSpec owner_spec(const mcx_graph *g)
 {
   if (g->own_lbo) return OwnerSpec{2u, g->own_lbo, (uint32_t)g->gidx, g->k};
@@ -242,6 +248,7 @@ static OwnerSpec owner_spec(const mcx_graph *g)
 static int flush_deferred(mcx_graph *g);
 static void free_defer(mcx_graph *g);
 static void snap_push(mcx_graph *g, bool is_base);
+static void snap_push(mcx_graph *g, bool is_base, uint64_t ub, int set, int which);
 static void sets_release(mcx_graph *g)
 {
   std::fill(g->set_colour.begin(), g->set_colour.end(), -1);
@@ -267,6 +274,7 @@ static int grp_export(mcx_group *G, mcx_graph *f, int sorted, mcx_sink_fn sink, 
 static int grp_part_of_pointer(mcx_group *G, const void *d_ptr, mcx_graph **part);
 static mcx_graph *grp_part(mcx_group *G, int i);
 static int grp_n(mcx_group *G);
+static uint64_t grp_spilled(mcx_group *G);
 #define NO_GROUP(g, what) do { if ((g) && (g)->as_group) return fail(MCX_ERR_ARG, what " takes a shard, not the multi-GPU handle"); } while (0)
 
 extern "C" const char *mcx_last_error(void) { return g_err; }
@@ -395,9 +403,13 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   CREATE_TRY(hipMalloc((void **)&g->d_ctr, sizeof(Counters)));
   CREATE_TRY(hipHostMalloc((void **)&g->h_ctr, sizeof(Counters), hipHostMallocDefault));
   g->touch_bytes = (1 + ((g->t.nmain >> sub_shift_for_words(g->W)) + 31) / 32) * 4;
-  CREATE_TRY(hipMalloc((void **)&g->t.touch, g->touch_bytes));
+  {  // (kTouchHdr bytes of slow-path counters in front of the flags: TableView::touch)
+    uint8_t *tb = nullptr;
+    CREATE_TRY(hipMalloc((void **)&tb, kTouchHdr + g->touch_bytes));
+    g->t.touch = reinterpret_cast<uint32_t *>(tb + kTouchHdr);
+  }
   CREATE_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
-  CREATE_TRY(hipMemsetAsync(g->t.touch, 0, g->touch_bytes, g->stream));
+  CREATE_TRY(hipMemsetAsync(touch_base(g), 0, kTouchHdr + g->touch_bytes, g->stream));
   CREATE_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
   CREATE_TRY(hipStreamSynchronize(g->stream));
 #undef CREATE_TRY
@@ -423,7 +435,7 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
   free_defer(g);
   for (auto &sp : g->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (g->t.rec) (void)hipFree(g->t.rec);
-  if (g->t.touch) (void)hipFree(g->t.touch);
+  if (g->t.touch) (void)hipFree(touch_base(g));
   if (g->stream2) {
     (void)hipStreamDestroy(g->stream2);
     for (int i = 0; i < 2; i++) { (void)hipEventDestroy(g->ev_split[i]); (void)hipEventDestroy(g->ev_ins[i]); }
@@ -449,8 +461,9 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   if (!g) return fail(MCX_ERR_ARG, "null graph");
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipMemsetAsync(g->t.rec, 0, g->table_bytes, g->stream));
-  HIP_TRY(hipMemsetAsync(g->t.touch, 0, g->touch_bytes, g->stream));
+  HIP_TRY(hipMemsetAsync(touch_base(g), 0, kTouchHdr + g->touch_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
+  g->n_flushes = 0;
   if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->nsets * g->b1 * g->rep1 * 8, g->stream));
   if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->l2_regions * g->subs_per_bin * 8, g->stream));
   if (g->d_readstrt) HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
@@ -809,6 +822,10 @@ static int flush_deferred(mcx_graph *g)
     // request larger than a set (accepted only for a FREE set) found neither room nor a free set after "the flush"
     // ("internal: no L1 bin set after a flush": seed 210 of the round-4 soak).
     sets_release(g);
+    if (!g->idle_mark.empty()) {  // idle flushes have emptied every region group: the books start afresh, as after a whole flush
+      g->idle_next = 0; g->idle_base = 0; g->idle_mark.clear();
+      snap_push(g, true);
+    }
     return MCX_OK;
   }
   HIP_TRY(hipSetDevice(g->device));
@@ -884,6 +901,7 @@ static int flush_deferred(mcx_graph *g)
   if (g->pending) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->nsets * g->b1 * g->rep1 * 8, g->stream));
   g->pending = 0;
   g->pending_l2 = 0;
+  g->n_flushes++;
   g->idle_next = 0; g->idle_base = 0; g->idle_mark.clear();
   sets_release(g);
   snap_push(g, true);
@@ -894,52 +912,58 @@ static int flush_deferred(mcx_graph *g)
 // that is bound to the colour and has room, else a free set, else a flush (which frees them all).
 // `ub` beyond a set's capacity is accepted for an EMPTY set (callers that only know an upper bound
 // of what a device-side fill holds): a segment that overflows falls back to the direct insert.
-// settled launches (mcx_graph::snap_*): record the k-mer counter behind what has been enqueued so far
-static void snap_push(mcx_graph *g, bool is_base)
+// settled launches (mcx_graph::snap_*): record the counters behind what has been enqueued so far
+static void snap_push(mcx_graph *g, bool is_base, uint64_t ub, int set, int which)
 {
-  if (g->group || g->nsets != 1) return;
   if (!g->h_snap) {
-    if (hipHostMalloc((void **)&g->h_snap, sizeof(unsigned long long) * mcx_graph::kSnap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g->h_snap = nullptr; return; }
+    if (hipHostMalloc((void **)&g->h_snap, sizeof(Counters) * mcx_graph::kSnap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g->h_snap = nullptr; return; }
     for (uint32_t i = 0; i < mcx_graph::kSnap; i++)
-      if (hipEventCreateWithFlags(&g->snap[i].ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(g->h_snap); g->h_snap = nullptr; return; }
+      if (hipEventCreateWithFlags(&g->snap[i].ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        for (uint32_t j = 0; j < i; j++) { (void)hipEventDestroy(g->snap[j].ev); g->snap[j].ev = nullptr; }
+        (void)hipHostFree(g->h_snap);
+        g->h_snap = nullptr;
+        return;
+      }
   }
   if (is_base) {  // the bins are empty: what is in flight describes launches that no longer count
     g->snap_tail = g->snap_head;
     g->snap_base_known = false;
-    g->snap_cum_ub = 0;
-    g->snap_slack = 0;
   }
-  if (g->snap_head - g->snap_tail >= mcx_graph::kSnap) return;  // ring full: this launch settles with a later one
+  if (g->snap_head - g->snap_tail >= mcx_graph::kSnap) return;  // ring full: this launch's yield is charged to the next entry
   const uint32_t i = g->snap_head % mcx_graph::kSnap;
-  if (hipMemcpyAsync(&g->h_snap[i], &g->d_ctr->kmers, sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+  if (hipMemcpyAsync(&g->h_snap[i], g->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
       hipEventRecord(g->snap[i].ev, g->stream) != hipSuccess) { (void)hipGetLastError(); return; }
-  g->snap[i].cum_ub = g->snap_cum_ub;
+  g->snap[i].ub = ub;
+  g->snap[i].set = set;
+  g->snap[i].which = which;
   g->snap[i].is_base = is_base;
   g->snap_head++;
 }
+static void snap_push(mcx_graph *g, bool is_base) { snap_push(g, is_base, 0, 0, 0); }
 
 // ... and take what the settled launches did not yield off the books (never waits)
 static void snap_poll(mcx_graph *g)
 {
-  if (!g->h_snap || g->group || g->nsets != 1) return;
+  if (!g->h_snap) return;
   while (g->snap_tail != g->snap_head) {
     const uint32_t i = g->snap_tail % mcx_graph::kSnap;
     if (hipEventQuery(g->snap[i].ev) != hipSuccess) { (void)hipGetLastError(); break; }
-    const uint64_t v = g->h_snap[i];
-    if (g->snap[i].is_base) {
-      g->snap_base = v;
+    const uint64_t v[2] = {g->h_snap[i].kmers, g->h_snap[i].binned};
+    const mcx_graph::Snap &e = g->snap[i];
+    if (e.is_base) {
       g->snap_base_known = true;
-    } else if (g->snap_base_known && g->idle_mark.empty() && !g->set_pending.empty()) {
+    } else if (g->snap_base_known && g->idle_mark.empty() && (size_t)e.set < g->set_pending.size()) {
       // (once an idle flush has marked a region group the books are kept in its units: flush_if_device_idle)
-      const uint64_t yielded = std::min<uint64_t>(g->snap[i].cum_ub, v - g->snap_base);  // (other entries count k-mers too: still an upper bound)
-      const uint64_t slack = g->snap[i].cum_ub - yielded;
-      if (slack > g->snap_slack) {
-        const uint64_t d = slack - g->snap_slack;
-        g->snap_slack = slack;
-        g->pending -= std::min(g->pending, d);
-        g->set_pending[0] -= std::min(g->set_pending[0], d);
-      }
+      // (other entries feed the counters too -- the direct path, launches the full ring did not snap: the yield is an
+      // upper bound, the slack a lower one)
+      const uint64_t yielded = std::min<uint64_t>(e.ub, v[e.which] - g->snap_last[e.which]);
+      const uint64_t d = e.ub - yielded;
+      g->pending -= std::min(g->pending, d);
+      g->set_pending[e.set] -= std::min(g->set_pending[e.set], d);
     }
+    g->snap_last[0] = v[0];
+    g->snap_last[1] = v[1];
     g->snap_tail++;
   }
 }
@@ -1013,8 +1037,7 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
     BinOut out = l1_out(g, set);
     DISPATCH_WC(g, launch_bin_region_stream, g, P, colour, bs, out);
     HIP_TRY(hipGetLastError());
-    g->snap_cum_ub += hi - lo;
-    snap_push(g, false);
+    snap_push(g, false, hi - lo, set, 0);
     lo = hi;
   }
   return MCX_OK;
@@ -1450,13 +1473,17 @@ extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_
   if (rc != MCX_OK) return rc;
   if (!g->defer) return fail(MCX_ERR_ARG, "super-k-mer records need the deferred insert path (table too small or defer=0)");
   int set = 0;
-  rc = defer_reserve(g, colour, std::min(kmers_upper_bound, g->set_cap), &set);
+  const uint64_t ub = std::min(kmers_upper_bound, g->set_cap);
+  rc = defer_reserve(g, colour, ub, &set);
   if (rc != MCX_OK) return rc;
   SuperkIn in{d_recs, (const unsigned long long *)d_counts, seg_cap, nseg};
   BinSpec bs{BIN_GROUP, 0, g->b1, g->rep1, g->b1, 1, 0, 0};
   BinOut out = l1_out(g, set);
   DISPATCH_WC(g, launch_superk_bin, g, in, colour, bs, out);
   HIP_TRY(hipGetLastError());
+  // the caller's bound is 16 k-mers per record slot; what the records really held (Counters::binned) comes off the
+  // books when this launch has settled
+  snap_push(g, false, ub, set, 1);
   return MCX_OK;
 }
 
@@ -2489,6 +2516,31 @@ extern "C" int mcx_graph_device_stats(mcx_graph *g, mcx_load_stats *out)
   return rc;
 }
 
+extern "C" int mcx_graph_insert_stats(mcx_graph *g, mcx_insert_stats *out)
+{
+  if (!g || !out) return fail(MCX_ERR_ARG, "null argument");
+  memset(out, 0, sizeof(*out));
+  if (g->as_group) {
+    int rc = grp_drain(g->as_group), first = MCX_OK;
+    if (rc != MCX_OK) return rc;
+    for (int i = 0; i < grp_n(g->as_group); i++) {
+      mcx_insert_stats s;
+      rc = mcx_graph_insert_stats(grp_part(g->as_group, i), &s);
+      if (rc != MCX_OK && first == MCX_OK) first = rc;
+      out->fallback_inserts += s.fallback_inserts; out->foreign_inserts += s.foreign_inserts; out->flushes += s.flushes;
+    }
+    out->spilled = grp_spilled(g->as_group);
+    return first;
+  }
+  int rc = fetch_counters(g);  // (flushes what is buffered: the counters are final)
+  unsigned long long h[2] = {0, 0};
+  HIP_TRY(hipMemcpy(h, touch_base(g), sizeof(h), hipMemcpyDeviceToHost));
+  out->fallback_inserts = h[0];
+  out->foreign_inserts = h[1];
+  out->flushes = g->n_flushes;
+  return rc;
+}
+
 // ---------------------------------------------------------------------------
 // bulk load of .ctx records (build --graph; graph_load, src/graph/graphs_load.c:86-214)
 // ---------------------------------------------------------------------------
@@ -3062,6 +3114,7 @@ extern "C" uint32_t mcx_kmer_hash(const uint64_t *key, int k, uint32_t initval)
 
 static mcx_graph *grp_part(mcx_group *G, int i) { return G->part[i]; }
 static int grp_n(mcx_group *G) { return G->n; }
+static uint64_t grp_spilled(mcx_group *G) { return G->spilled; }
 // the shard on whose device `d_ptr` lives (shards that share a device take turns)
 static int grp_part_of_pointer(mcx_group *G, const void *d_ptr, mcx_graph **part)
 {

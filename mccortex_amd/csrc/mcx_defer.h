@@ -320,6 +320,7 @@ __device__ __forceinline__ void bin_writeout(LDS &L, int round, const BinSpec &b
         }
       } else {                      // ... lock-free insert into the HBM table
         table_mark_written(isink.t);
+        table_count_fallback(isink.t);
         const uint32_t region = bs.mode == BIN_GROUP ? b : region_of_seg;
         const Kmer<W> key = key_unquot<W>(qq, lbq, r_of<W>(isink.t, region, qq));
         const uint64_t slot = key_slot<W>(isink.t, key);
@@ -383,6 +384,7 @@ __device__ __noinline__ void foreign_insert(const InsertSink<W, ONECOL> &isink, 
                                             uint32_t &novel, uint32_t &full)
 {
   table_mark_written(isink.t);
+  table_count_foreign(isink.t);
   const uint64_t slot = key_slot<W>(isink.t, key);
   const uint64_t cur = *key_ptr_t<W, ONECOL>(isink.t, slot);
   probe_insert<W, ONECOL>(isink.t, key, slot, cur, 0, e, isink.col, novel, full);

@@ -61,12 +61,26 @@ struct TableView {
   // since the table was zeroed; touch[1 + s / 32] bit s % 32: the LDS insert has written sub-table
   // s.  While touch[0] == 0, a sub-table whose bit is clear still holds only zeros and the LDS
   // insert does not read it (the first flush of a build reads none of the table).
+  // In front of touch[0] sit kTouchHdr bytes of slow-path counters (the allocation starts there): occurrences that
+  // took the per-tuple direct insert because their partition bin was full (`fallback`), and keys of other shards
+  // inserted on the spot (`foreign`).  Correct but slow paths -- "cliffs" -- that would otherwise be silent
+  // (mcx_graph_insert_stats; the reference prints its collision histogram, hash_table.c:301-333).  They live here
+  // because the slow paths already hold this pointer: the hot kernels pay no register for them.
   uint32_t *touch;
 };
+constexpr int kTouchHdr = 32;  // bytes
 // Called by every kernel that writes hash-addressed slots outside the LDS insert.
 __device__ __forceinline__ void table_mark_written(const TableView &t)
 {
   if (t.touch) t.touch[0] = 1u;
+}
+__device__ __forceinline__ void table_count_fallback(const TableView &t)
+{
+  if (t.touch) atomicAdd(reinterpret_cast<unsigned long long *>(t.touch) - 4, 1ULL);
+}
+__device__ __forceinline__ void table_count_foreign(const TableView &t)
+{
+  if (t.touch) atomicAdd(reinterpret_cast<unsigned long long *>(t.touch) - 3, 1ULL);
 }
 __device__ __forceinline__ uint64_t *key_ptr(const TableView &t, uint64_t slot) { return t.rec + slot * t.KS; }
 __device__ __forceinline__ uint64_t *val_ptr(const TableView &t, uint64_t slot, uint32_t col)
@@ -259,6 +273,8 @@ struct Counters {  // device-resident, 64-bit each
   unsigned long long bin_over;  // != 0: a partition bin overflowed
   unsigned long long good_reads, bad_reads;
   unsigned long long absent;    // must-exist mode: k-mer occurrences whose k-mer is not in the graph (not "loaded", build_graph.c:175-177)
+  unsigned long long binned;    // occurrences the owner side of exchange v3 (k_superk_bin) put into the region bins: what a
+                                // reservation made with an upper bound really used (settled launches, mcx_api.hip snap_*)
 };
 
 // Add a per-thread tally to a device counter with ONE global atomic per block: all blocks hit

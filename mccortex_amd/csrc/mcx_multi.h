@@ -73,6 +73,7 @@ struct mcx_group {
   std::vector<int> cur;
   std::vector<std::array<bool, 2>> used;
   bool buffers = false;
+  uint64_t spilled = 0;  // occurrences (v2) / records (v3) that went through a sender's spill area (mcx_graph_insert_stats)
   bool peer_ok = true;  // every pair of distinct devices can map each other's memory (kernels may write to a peer)
 };
 
@@ -119,13 +120,14 @@ static int group_ensure_buffers(mcx_group *G)
   if (const char *e = getenv("MCX_MULTI_PIECE")) G->max_pos = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));  // tests
   if (G->v3) {
     // ~2.3 records per 16 positions on random reads; room for 3: what does not fit a segment goes to the
-    // sender's spill area and is routed by the host.  The spill takes 4 records per 16 positions more: low-
-    // complexity input makes LONG runs (one minimizer), i.e. few records; only an input that changes owner
-    // at nearly every k-mer of a whole piece could exceed 7 records per 16 positions (reported: MCX_ERR_FULL)
+    // sender's spill area and is routed by the host.  A record is a run of >= 1 k-mers, so a piece yields at most
+    // one record per start position: a spill area of max_pos records cannot overflow WHATEVER the input is -- one
+    // owner taking everything, or an owner change at every k-mer (512 MiB per send set at k <= 31; until round 5 it
+    // held 4 records per 16 positions and an input beyond that ended in MCX_ERR_FULL where one GPU succeeds).
     const uint64_t recb = 16ull * W;
     G->sk_segs = kSuperkRep;
     G->sk_cap = G->max_pos * 3 / 16 / ((uint64_t)N * G->sk_segs) + 4096;
-    G->sp_cap = G->max_pos / 4 + 4096;
+    G->sp_cap = G->max_pos + 16;
     if (const char *e = getenv("MCX_MULTI_SKCAP")) G->sk_cap = std::max<uint64_t>(16, strtoull(e, nullptr, 10));  // tests: force the spill path
     G->send.resize(N);
     G->recv.assign(N, std::vector<std::array<XBuf, 2>>(N));
@@ -162,6 +164,11 @@ static int group_ensure_buffers(mcx_group *G)
   G->seg_cap = ((uint64_t)(mean + 8.0 * sqrt(mean + 1.0)) + 64 + 1) & ~1ull;
   G->ov_cap = (std::max<uint64_t>(1u << 16, G->max_pos / (uint64_t)N / 16) + 15) & ~15ull;  // (16-byte aligned edge-byte rows: k_copy_filled)
   G->sp_cap = G->max_pos;
+  // k_copy_filled addresses segment js at js * ceil(cap * item_bytes / 16) 16-byte units: that is the real stride
+  // only when a segment is a whole number of units
+  if ((G->seg_cap * 8 * W) % 16 || (G->ov_cap * 8 * W) % 16 || G->ov_cap % 16)
+    return fail(MCX_ERR_ARG, "internal: exchange segment stride is not a multiple of 16 bytes (seg_cap %llu, ov_cap %llu)",
+                (unsigned long long)G->seg_cap, (unsigned long long)G->ov_cap);
   G->send.resize(N);
   G->h_spill.assign(N, {nullptr, nullptr});
   G->spill_colour.assign(N, {0, 0});
@@ -219,6 +226,7 @@ static int group_route_spill(mcx_group *G, int idx, int b)
   const uint64_t n = std::min<uint64_t>(*G->h_spill[idx][b], G->sp_cap);
   if (!n) return MCX_OK;
   *G->h_spill[idx][b] = 0;
+  G->spilled += n;
   const int N = G->n, W = me->W, colour = G->spill_colour[idx][b];
   const XBuf &s = G->send[idx][b];
   if (G->v3) {  // records: every shard picks its own out of the spill and k-merises them
@@ -240,8 +248,9 @@ static int group_route_spill(mcx_group *G, int idx, int b)
       else hipLaunchKernelGGL(k_superk_pick<2>, dim3(blocks), dim3(256), 0, own->stream, (const void *)r.p, (const uint8_t *)o.p, n, (uint32_t)j, (void *)d.p, cnt.p);
       GRP_TRY(hipGetLastError());
       int rc = mcx_graph_add_superk_dev(own, colour, d.p, cnt.p, 1, n, n * 16);
-      (void)hipStreamSynchronize(own->stream);  // the buffers are released when this scope ends
+      const hipError_t se = hipStreamSynchronize(own->stream);  // the buffers are released when this scope ends
       if (rc != MCX_OK) return rc;
+      GRP_TRY(se);  // (an asynchronous fault of the pick / the owner kernel is reported here, at the piece that caused it)
     }
     GRP_TRY(hipSetDevice(me->device));
     return MCX_OK;
@@ -258,8 +267,9 @@ static int group_route_spill(mcx_group *G, int idx, int b)
     GRP_TRY(hipMemcpyPeerAsync(e.p, own->device, s.ov_edges + at, me->device, n, own->stream));
     DISPATCH_WC(own, launch_insert_tuples_t, own, colour, (const uint64_t *)k.p, (const uint8_t *)e.p, n, 1u);
     const hipError_t le = hipGetLastError();
-    (void)hipStreamSynchronize(own->stream);  // the buffers are released when this scope ends
+    const hipError_t se = hipStreamSynchronize(own->stream);  // the buffers are released when this scope ends
     GRP_TRY(le);
+    GRP_TRY(se);
   }
   GRP_TRY(hipSetDevice(me->device));
   return MCX_OK;
@@ -324,8 +334,11 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
         GRP_TRY(hipEventRecord(G->arrived[j][idx][b], G->cs[idx]));
       }
       GRP_TRY(hipEventRecord(G->sent[idx][b], G->cs[idx]));
-      // 3. owners: k-merise what arrived into their region bins
-      const uint64_t share = (hi - lo) / (uint64_t)N + (hi - lo) / (uint64_t)(4 * N) + 4096;  // estimate for the flush clock
+      // 3. owners: k-merise what arrived into their region bins.  The reservation is a true upper bound -- every start
+      // position of the piece may belong to one owner -- and what the records really held comes off the owner's books
+      // when the launch has settled (Counters::binned, snap_*).  (Until round 5 it was an estimate, 1.25 x piece / N:
+      // an owner far above its share overflowed its bins into the per-occurrence insert without anyone noticing.)
+      const uint64_t share = hi - lo;
       for (int j = 0; j < N; j++) {
         mcx_graph *own = G->part[j];
         XBuf &r = G->recv[j][idx][b];
@@ -397,8 +410,9 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
       GRP_TRY(hipEventRecord(G->arrived[j][idx][b], G->cs[idx]));
     }
     GRP_TRY(hipEventRecord(G->sent[idx][b], G->cs[idx]));
-    // 3. owners: split by sub-table; the overflow bins take the full-tuple path
-    const uint64_t share = (hi - lo) / (uint64_t)N + (hi - lo) / (uint64_t)(4 * N) + 4096;  // estimate for the flush clock
+    // 3. owners: split by sub-table; the overflow bins take the full-tuple path.  Booked with a true upper bound:
+    // an owner's block holds at most `blk` tuples, and a piece at most hi - lo.
+    const uint64_t share = hi - lo;
     for (int j = 0; j < N; j++) {
       mcx_graph *own = G->part[j];
       XBuf &r = G->recv[j][idx][b];

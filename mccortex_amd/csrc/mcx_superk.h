@@ -314,6 +314,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(Super
   __shared__ uint32_t s_T, s_nl;
   const int tid = threadIdx.x;
   uint32_t n_novel = 0, full = 0;
+  unsigned long long n_binned = 0;  // (uniform: every tile's T)
   const uint32_t ob0 = (blockIdx.x % bs.rep) * bs.nout;
   const uint64_t chunks_per_seg = (in.seg_cap + kSkChunk - 1) / kSkChunk;
   const uint64_t nunits = chunks_per_seg * in.nseg;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(Super
       __syncthreads();
       const uint32_t T = s_T;
       pos += (uint64_t)kSkPerLane * s_nl;
+      n_binned += T;
 
       Kmer<W> tk[kPosPerLane];
       uint32_t tle[kPosPerLane];
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(kThreads, (W == 1 ? 4 : 3)) void k_superk_bin(Super
     }
   }
   block_add(&ctr->novel, n_novel);
+  if (tid == 0 && n_binned) atomicAdd(&ctr->binned, n_binned);
   if (full == 1) ctr->full = 1;
   if (full == 2) ctr->bin_over = 1;
 }

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
     "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash", "mcx_pack_bases", "mcx_pack_reads_host", "mcx_pack_stream_dev", "mcx_graph_add_packed_dev",
-    "mcx_ubench_stream", "mcx_ubench_random_rmw",
+    "mcx_ubench_stream", "mcx_ubench_random_rmw", "mcx_graph_insert_stats",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
     L.mcx_graph_insert_tuple_segments_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32, C.c_uint64]
     L.mcx_graph_add_records.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_int, C.c_uint32, C.POINTER(RecordStats)]
     L.mcx_graph_kmer_covg.argtypes = [vp, u64p, u64p]
+    L.mcx_graph_insert_stats.argtypes = [vp, vp]
     L.mcx_graph_covg_histogram.argtypes = [vp, u64p, C.c_uint32]
     L.mcx_sort_records.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int]
     L.mcx_records_sorted.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
@@ -364,6 +365,12 @@ class Graph:
         st = LoadStats()
         _check(self.L.mcx_graph_device_stats(self.h, C.byref(st)))
         return st
+
+    def insert_stats(self):
+        """mcx_insert_stats as a dict: fallback_inserts, foreign_inserts, spilled, flushes (implies a sync)"""
+        st = (C.c_uint64 * 4)()
+        _check(self.L.mcx_graph_insert_stats(self.h, st))
+        return dict(zip(("fallback_inserts", "foreign_inserts", "spilled", "flushes"), (int(x) for x in st)))
 
     @property
     def stream(self):

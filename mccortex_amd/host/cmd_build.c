@@ -802,6 +802,12 @@ int ctx_build(int argc, char **argv)
   if (getenv("MCX_TIMING")) fprintf(stderr, "[timing] %8.1f ms  inside mcx_graph_add_reads (%lu calls)\n", submit_ms, submit_calls);
   mcx_check(mcx_graph_sync(g), "sync");
   stage_time("graph built (device idle)");
+  if (getenv("MCX_TIMING")) { /* the slow-but-correct insert paths, made visible (the reference: hash_table_print_stats) */
+    mcx_insert_stats is;
+    mcx_check(mcx_graph_insert_stats(g, &is), "insert stats");
+    fprintf(stderr, "[timing] insert paths: %lu table passes, %lu fallback inserts (bin overflow), %lu foreign inserts, %lu spilled between devices\n",
+            (unsigned long)is.flushes, (unsigned long)is.fallback_inserts, (unsigned long)is.foreign_inserts, (unsigned long)is.spilled);
+  }
 
   uint64_t nk = 0;
   mcx_check(mcx_graph_nkmers(g, &nk), "nkmers");

@@ -77,6 +77,9 @@ def _build(mcx, batches, k, ncols, slots, cfg, colours=None):
     cs, n = g.checksum()
     nk, sc = g.kmer_covg()
     hist = g.covg_histogram(64)
+    ist = g.insert_stats()
+    # no occurrence of these well-spread inputs may leave the fast path (bin overflow -> per-occurrence insert)
+    assert ist["fallback_inserts"] == 0 and ist["foreign_inserts"] == 0, ist
     out = dict(checksum=cs, nodes=n, nkmers=g.nkmers, loaded=st.num_kmers_loaded, contigs=st.contigs_parsed,
                covg_nodes=nk.tolist(), covg_sum=sc.tolist(), hist0=int(hist[0]), hist_total=int(hist.sum()))
     g.close()
@@ -119,6 +122,50 @@ def test_benchmark_geometry_matches_oracle(mcx, orc, c2_batches, k):
         assert got == want, (k, name)
         assert (ds.num_kmers_loaded, ds.contigs_parsed, ds.num_kmers_novel) == (st.num_kmers_loaded, st.contigs_parsed, st.num_kmers_novel), (k, name)
         assert (int(nk[0]), int(sc[0])) == (want[1], st.num_kmers_loaded), (k, name)
+
+
+def test_benchmark_geometry_four_colours_matches_oracle(mcx, orc, c2_batches):
+    """BASELINE config C5's shape at the benchmark's table geometry, against the ORACLE: one C2 step dealt to four
+    colours (sample c = reads [c n / 4, (c + 1) n / 4)), 2^30 slots, through the partition + LDS insert (a pool of bin
+    sets, one table pass per colour), the direct path and eight in-process shards (C5 names 8 GPUs)."""
+    import bench
+    k, ncols, SLOTS = 31, 4, 1 << 30
+    b = c2_batches[0]
+    n = bench.BATCH_READS
+    rows = b.reshape(n, bench.READ_LEN + 1)
+    host = rows[:, :bench.READ_LEN].contiguous().cpu().numpy()
+    nt = min(32, os.cpu_count() or 1)
+    og = orc.Graph(k, ncols, 1 << 29)
+    og.tune(nt)
+    loaded = 0
+    cut = [n * c // ncols for c in range(ncols + 1)]
+    for c in range(ncols):
+        part = host[cut[c]:cut[c + 1]].reshape(-1)
+        offs = np.arange(cut[c + 1] - cut[c] + 1, dtype=np.uint64) * bench.READ_LEN
+        loaded += og.add_reads(c, part, offs, nthreads=nt).num_kmers_loaded
+    body = og.body_array(False)
+    want = (mcx.records_checksum(body, k, ncols), og.nkmers)
+    del body, og
+    streams = [rows[cut[c]:cut[c + 1]].reshape(-1).clone() for c in range(ncols)]
+    for name, kw, cfg in (("deferred", {}, {}), ("direct", {}, {"defer": 0}), ("8 in-process shards", {"devices": [0] * 8}, {})):
+        g = mcx.Graph(k, ncols, SLOTS, **kw)
+        for key, v in cfg.items():
+            g.configure(key, v)
+        for rep in range(2):            # the samples alternate: 0 1 2 3 0 1 2 3 (halves of every quarter)
+            for c in range(ncols):
+                s = streams[c]
+                half = (s.numel() // (bench.READ_LEN + 1) // 2) * (bench.READ_LEN + 1)
+                piece = (s[:half] if rep == 0 else s[half:]).clone()
+                g.add_stream_dev(c, piece, piece.numel())
+        g.sync()
+        ds = g.device_stats()
+        got = g.checksum()
+        nk, sc = g.kmer_covg()
+        ist = g.insert_stats()
+        g.close()
+        assert got == want, name
+        assert ds.num_kmers_loaded == loaded and int(sum(int(x) for x in sc)) == loaded, name
+        assert ist["fallback_inserts"] == 0, (name, ist)
 
 
 def test_huge_table_geometry_matches_oracle(mcx, orc):
@@ -279,6 +326,8 @@ def test_c2_full_size_in_process_multi(mcx, c2_batches):
         st = g.device_stats()
         cs, n = g.checksum()
         nk, sc = g.kmer_covg()
+        ist = g.insert_stats()
         g.close()
+        assert ist["fallback_inserts"] == 0 and ist["foreign_inserts"] == 0 and ist["spilled"] == 0, (xch, devs, ist)
         assert (cs, n, st.num_kmers_loaded, st.contigs_parsed) == (ref["checksum"], ref["nodes"], ref["loaded"], ref["contigs"]), (xch, devs)
         assert int(nk[0]) == ref["nodes"] and int(sc[0]) == ref["loaded"]

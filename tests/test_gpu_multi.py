@@ -225,3 +225,96 @@ def test_multi_v3_record_segments_spill(mcx, orc, k, monkeypatch):
     assert st.num_kmers_loaded == ost.num_kmers_loaded and st.contigs_parsed == ost.contigs_parsed
     assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
     g.close()
+
+
+def _owner_of_read_kmers(mcx, read, k, nparts):
+    owners = set()
+    for i in range(len(read) - k + 1):
+        key, _ = mcx.kmer_canonical(mcx.kmer_from_str(read[i:i + k], k), k)
+        owners.add(mcx.superk_owner(key, k, nparts))
+    return owners
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_multi_v3_every_record_spills_and_one_owner_takes_all(mcx, orc, k, monkeypatch):
+    """The two ends of exchange v3's record budget (round 5: no input can end in MCX_ERR_FULL where one GPU succeeds).
+    (a) Reads of k .. k + 2 bases: every record holds 1-3 k-mers -- the most records per k-mer an input makes -- with
+    segments of 16 records (MCX_MULTI_SKCAP), so nearly all of them go through the sender's spill area, which now
+    holds one record per start position of a piece (a record is a run of >= 1 k-mers: it cannot overflow).
+    (b) Reads chosen so that ONE shard owns every k-mer (by the product's own minimizer-owner function): the owner
+    side books a true upper bound and settles it, nothing falls back to the per-occurrence insert, and the other
+    shards stay empty."""
+    monkeypatch.setenv("MCX_MULTI_EXCHANGE", "v3")
+    rng = np.random.default_rng(k)
+    gen = synth.genome(40000, 5)
+    # (a)
+    monkeypatch.setenv("MCX_MULTI_PIECE", "400000")
+    monkeypatch.setenv("MCX_MULTI_SKCAP", "16")
+    reads = []
+    for _ in range(12000):
+        n = int(rng.integers(k, k + 3))
+        p = int(rng.integers(0, len(gen) - n))
+        reads.append(bytes(gen[p:p + n]))
+    bases, offs = orc.pack_reads(reads)
+    og = orc.Graph(k, 1, 1 << 20)
+    ost = og.add_reads(0, bases, offs)
+    g = _multi(mcx, k, 1, [0] * 8)
+    g.add_reads(0, bases, offs)
+    g.sync()
+    st = g.device_stats()
+    assert st.num_kmers_loaded == ost.num_kmers_loaded and st.contigs_parsed == ost.contigs_parsed
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    ist = g.insert_stats()
+    assert ist["spilled"] > len(reads) // 2, ist   # (a read is at least one record; 8 x 8 x 16 segment slots per piece)
+    g.close()
+    monkeypatch.delenv("MCX_MULTI_SKCAP")
+    monkeypatch.setenv("MCX_MULTI_PIECE", "30000")
+    # (b)
+    nparts = 4
+    mine = []
+    while len(mine) < 1500:
+        n = int(rng.integers(k, k + 4))
+        p = int(rng.integers(0, len(gen) - n))
+        r = bytes(gen[p:p + n])
+        if _owner_of_read_kmers(mcx, r.decode(), k, nparts) == {2}:
+            mine.append(r)
+    bases, offs = orc.pack_reads(mine)
+    og = orc.Graph(k, 1, 1 << 20)
+    g = _multi(mcx, k, 1, [0] * nparts)
+    for _ in range(3):
+        g.add_reads(0, bases, offs)
+        og.add_reads(0, bases, offs)
+    g.sync()
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    ist = g.insert_stats()
+    assert ist["fallback_inserts"] == 0 and ist["foreign_inserts"] == 0, ist
+    g.close()
+
+
+def test_insert_stats_make_the_slow_paths_visible(mcx, orc):
+    """mcx_graph_insert_stats: zero on well-spread input; hot k-mers (thousands of occurrences of one key in a batch)
+    overflow their partition bin and are counted as fallback inserts; keys of another shard handed to a shard handle
+    are counted as foreign inserts -- both correct, both slow, neither silent any more."""
+    k = 31
+    bases, offs = synth.reads(20000, 150, genome_len=300000, seed=9)
+    g = mcx.Graph(k, 1, 1 << 22)
+    g.add_reads(0, bases, offs)
+    ist = g.insert_stats()
+    assert ist["fallback_inserts"] == 0 and ist["foreign_inserts"] == 0 and ist["spilled"] == 0 and ist["flushes"] >= 1, ist
+    g.close()
+    hot, hoffs = orc.pack_reads(["A" * 150] * 200000)
+    g = mcx.Graph(k, 1, 1 << 22)
+    og = orc.Graph(k, 1, 1 << 22)
+    g.add_reads(0, hot, hoffs)
+    og.add_reads(0, hot, hoffs)
+    ist = g.insert_stats()
+    assert ist["fallback_inserts"] > 0, ist
+    assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
+    g.reset()
+    assert g.insert_stats()["fallback_inserts"] == 0
+    g.close()
+    sh = mcx.Graph(k, 1, 1 << 22, nparts=2, part=0)
+    sh.add_reads(0, bases, offs)
+    ist = sh.insert_stats()
+    assert ist["foreign_inserts"] > 0, ist
+    sh.close()

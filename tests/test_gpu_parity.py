@@ -625,3 +625,41 @@ def test_batch_without_kmers_then_another_colour(mcx, orc, monkeypatch):
     g.sync()
     assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
     g.close()
+
+
+@pytest.mark.parametrize("k", [31, 63])
+@pytest.mark.parametrize("how", ["deferred", "direct", "2 shards v3", "2 shards v2"])
+def test_coverage_saturates_through_the_read_path(mcx, orc, k, how, monkeypatch):
+    """db_node_increment_coverage (src/graph/db_node.c:139-144) stops at UINT32_MAX.  A node is loaded from a
+    record with coverage 0xFFFFFFFE (0xFFFFFFFD, 0xFFFFFFFF) and reads then hit it three times -- through the
+    partition + LDS insert, the direct HBM atomics and two shards in either exchange format: the exported
+    coverage is 0xFFFFFFFF, never a wrapped count, and everything else counts on."""
+    import struct
+    read = "ACGGTCATTGACCGATTACGGCATCGGATTCAGCTTAGGCATCGATTGCAGCTAGCTAGGCTTAACGGCTAGCATCGGATCATTC"
+    W = (2 * k + 63) // 64
+    nk = len(read) - k + 1
+    keys = [mcx.kmer_canonical(mcx.kmer_from_str(read[i:i + k], k), k)[0] for i in range(nk)]
+    near = [0xFFFFFFFE, 0xFFFFFFFD, 0xFFFFFFFF, 0xFFFFFFFC, 5]
+    rec = b"".join(struct.pack("<%dQIB" % W, *(key + [near[i % len(near)], 0x10 if i % 2 else 0x00])) for i, key in enumerate(keys))
+    other, ooffs = synth.reads(3000, 100, genome_len=20000, seed=k)
+    rb, ro = orc.pack_reads([read] * 3 + [read[5:]])
+    og = orc.Graph(k, 1, 1 << 20)
+    if how.startswith("2 shards"):
+        monkeypatch.setenv("MCX_MULTI_EXCHANGE", how[-2:])
+        g = mcx.Graph(k, 1, 1 << 20, devices=[0, 0])
+    else:
+        g = mcx.Graph(k, 1, 1 << 20)
+        if how == "direct":
+            g.configure("defer", 0)
+    og.add_reads(0, other, ooffs); g.add_reads(0, other, ooffs)
+    for i, key in enumerate(keys):
+        og.add_record(key, [near[i % len(near)]], [0x10 if i % 2 else 0x00])
+    g.add_records(rec, 1, [(0, 0)])
+    og.add_reads(0, rb, ro); g.add_reads(0, rb, ro)
+    body = g.export(True)
+    assert body == og.body_bytes(True)
+    rs = 8 * W + 5
+    recs = {bytes(body[i:i + 8 * W]): struct.unpack_from("<I", body, i + 8 * W)[0] for i in range(0, len(body), rs)}
+    sat = [recs[struct.pack("<%dQ" % W, *key)] for i, key in enumerate(keys) if near[i % len(near)] >= 0xFFFFFFFC and i >= 5]
+    assert sat and all(c == 0xFFFFFFFF for c in sat)   # (the first 5 k-mers got 3 hits, the rest 4)
+    g.close()
