@@ -146,17 +146,18 @@ def test_benchmark_geometry_four_colours_matches_oracle(mcx, orc, c2_batches):
     body = og.body_array(False)
     want = (mcx.records_checksum(body, k, ncols), og.nkmers)
     del body, og
-    streams = [rows[cut[c]:cut[c + 1]].reshape(-1).clone() for c in range(ncols)]
-    for name, kw, cfg in (("deferred", {}, {}), ("direct", {}, {"defer": 0}), ("8 in-process shards", {"devices": [0] * 8}, {})):
+    # (pieces stay alive until the graph has consumed them: add_stream_dev is asynchronous on the graph's own stream)
+    pieces = []
+    for c in range(ncols):
+        mid = (cut[c] + cut[c + 1]) // 2
+        pieces.append((rows[cut[c]:mid].reshape(-1).clone(), rows[mid:cut[c + 1]].reshape(-1).clone()))
+    for name, kw, cfg in (("deferred", {}, {}), ("direct", {}, {"defer": 0}), ("8 in-process shards", {"devices": [0] * 8}, {"defer_tuples": 125_000_000})):   # (all eight share the one device's HBM here)
         g = mcx.Graph(k, ncols, SLOTS, **kw)
         for key, v in cfg.items():
             g.configure(key, v)
         for rep in range(2):            # the samples alternate: 0 1 2 3 0 1 2 3 (halves of every quarter)
             for c in range(ncols):
-                s = streams[c]
-                half = (s.numel() // (bench.READ_LEN + 1) // 2) * (bench.READ_LEN + 1)
-                piece = (s[:half] if rep == 0 else s[half:]).clone()
-                g.add_stream_dev(c, piece, piece.numel())
+                g.add_stream_dev(c, pieces[c][rep], pieces[c][rep].numel())
         g.sync()
         ds = g.device_stats()
         got = g.checksum()

@@ -28,6 +28,10 @@ def _launch(world, port, tail, env=None, timeout=900):
         e.update(ONE_GPU)
     e.update(env or {})
     p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    if p.returncode != 0:   # the whole log of a failed launch, for the builder (gpurun_out/ is scratch)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "failed_launch_%d.log" % port), "wb") as f:
+            f.write(p.stdout + b"\n---- stderr ----\n" + p.stderr)
     return p.returncode, p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
 
 
@@ -74,7 +78,8 @@ def test_bench_two_ranks_strong_reproduces_the_single_gpu_graph(mcx, tmp_path):
     split 2 ways) as two processes on cuda:0: the sum of the ranks' graph checksums and node counts must be what the
     N = 1 run of the same steps reports, and the line must carry the per-rank stage table."""
     import json
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batch-reads", "1000000"]
+    # (--defer-tuples: two ranks and this pytest process share the one device's HBM here)
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batch-reads", "1000000", "--defer-tuples", "1000000000"]
     e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]

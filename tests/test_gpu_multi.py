@@ -265,7 +265,7 @@ def test_multi_v3_every_record_spills_and_one_owner_takes_all(mcx, orc, k, monke
     assert st.num_kmers_loaded == ost.num_kmers_loaded and st.contigs_parsed == ost.contigs_parsed
     assert g.export(True) == og.ctx_bytes(True)[og.header_size():]
     ist = g.insert_stats()
-    assert ist["spilled"] > len(reads) // 2, ist   # (a read is at least one record; 8 x 8 x 16 segment slots per piece)
+    assert ist["spilled"] > len(reads) // 4, ist   # (a read is at least one record; 8 x 8 x 16 segment slots per piece)
     g.close()
     monkeypatch.delenv("MCX_MULTI_SKCAP")
     monkeypatch.setenv("MCX_MULTI_PIECE", "30000")
