@@ -115,6 +115,14 @@ def csrc_digest():
     for n in ("mcx_defer.h", "mcx_kernels.h", "mcx_kmer.h"):
         h.update(n.encode())
         h.update(open(os.path.join(d, n), "rb").read())
+    # ... and their launch geometry (grids, block sizes, LDS sizes, variant choice): the launch functions of mcx_api.hip
+    # (round 4's last change -- 8 blocks per CU for the 512-thread k-merising kernel -- lived there and escaped the digest)
+    api = open(os.path.join(d, "mcx_api.hip"), "rb").read()
+    lo, hi = api.find(b"static void launch_bin_stream_pk"), api.find(b"static void free_defer")
+    if lo < 0 or hi < lo:
+        raise RuntimeError("csrc_digest: launch functions not found in mcx_api.hip")
+    h.update(b"launch-geometry")
+    h.update(api[lo:hi])
     return h.hexdigest()[:16]
 
 
@@ -270,8 +278,10 @@ def kernel_table(prof, kmers, W=1, bases_per_kmer=1.25):
     return out
 
 
-def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packed=None, cfg=None, checksum=False):
-    """one device-resident build of `batches` (fresh graph; `packed`: their packed form) -> record"""
+def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packed=None, cfg=None, checksum=False, isolated=False):
+    """one device-resident build of `batches` (fresh graph; `packed`: their packed form) -> record.
+    isolated: a second pass over the same input with the flush overlap off (one kernel at a time on one stream) gives
+    per-kernel durations that mean something; `value` is the first pass (overlap on, the default)."""
     import torch
     g = mcx.Graph(k, ncols, table_slots)
     if defer_tuples:
@@ -280,33 +290,56 @@ def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packe
         g.configure(key, v)
     g.add_stream_dev(0, batches[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
     g.sync(); g.reset(); g.sync()
-    g.configure("profile", 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if packed is not None:
-        for c, (code, inv, n) in zip(colours, packed):
-            g.add_packed_dev(c, code, inv, n)
-    else:
-        for c, b in zip(colours, batches):
-            g.add_stream_dev(c, b, b.numel())
-    g.sync()
-    dt = time.perf_counter() - t0
+
+    def one_pass():
+        g.configure("profile", 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if packed is not None:
+            for c, (code, inv, n) in zip(colours, packed):
+                g.add_packed_dev(c, code, inv, n)
+        else:
+            for c, b in zip(colours, batches):
+                g.add_stream_dev(c, b, b.numel())
+        g.sync()
+        return time.perf_counter() - t0
+
+    dt = one_pass()
     st = g.device_stats()
     prof = g.profile()
-    cs = g.checksum() if checksum else None
+    cs = g.checksum() if (checksum or isolated) else None
+    ist = g.insert_stats()
+    prof_iso, dt_iso = None, None
+    if isolated:
+        g.reset()
+        g.configure("flush_overlap", 0)
+        g.sync()
+        dt_iso = one_pass()
+        prof_iso = g.profile()
+        if g.checksum() != cs:
+            raise RuntimeError("the non-overlapped pass built another graph")
     g.close()
     torch.cuda.empty_cache()
     W = (2 * k + 63) // 64
-    kt = kernel_table(prof, st.num_kmers_loaded, W, (0.375 if packed is not None else 1.0) * (READ_LEN + 1) / (READ_LEN - k + 1.0))
+    bpk = (0.375 if packed is not None else 1.0) * (READ_LEN + 1) / (READ_LEN - k + 1.0)
+    kt = kernel_table(prof_iso if prof_iso is not None else prof, st.num_kmers_loaded, W, bpk)
     dom = max(kt, key=lambda n: kt[n]["total_ms"])
     alg = (ALG_BYTES_PER_KMER if W == 1 else 29.70) * st.num_kmers_loaded + 8.0 * W * st.num_kmers_novel
     out = {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(batches), "steps": len(batches),
            "kmers_inserted": int(st.num_kmers_loaded), "distinct_kmers": int(st.num_kmers_novel),
            "roofline_frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
-           "dominant_kernel": dom, "dominant_frac": kt[dom]["frac"], "kernels": kt,
-           "kernels_note": "HIP-event spans on the handle's streams; with the flush overlap on (default) the spans of k_tuples_bin and "
-                           "k_lds_insert include each other's interference (isolated durations: roofline.kernels of the headline)"}
-    if cs is not None:
+           "table_passes": ist["flushes"], "fallback_inserts": ist["fallback_inserts"]}
+    if prof_iso is not None:
+        out.update({"dominant_kernel": dom, "dominant_frac": kt[dom]["frac"], "kernels": kt,
+                    "kernels_note": "ISOLATED durations: a second pass over the same input with the flush overlap off (one kernel at a time, HIP events around "
+                                    "every launch, same graph checksum); dominant_frac = that kernel's own design bytes over its isolated time, against 8 TB/s",
+                    "isolated_pass_ms_per_step": round(1e3 * dt_iso / len(batches), 3),
+                    "spans_overlapped": {n: {"launches": c, "total_ms": round(t, 3)} for n, (c, t) in prof.items()}})
+    else:
+        out.update({"spans_overlapped": {n: {"launches": c, "total_ms": round(t, 3)} for n, (c, t) in prof.items()},
+                    "kernels_note": "HIP-event SPANS of the timed pass: with the flush overlap on (the default) the spans of k_tuples_bin and k_lds_insert contain "
+                                    "each other, so no per-kernel fraction is derived from them (isolated figures: the headline, C4_k63, C2_stress, hashtest)"})
+    if cs is not None and checksum:
         out["graph_checksum"], out["nodes"] = "%016x" % cs[0], int(cs[1])
     return out
 
@@ -338,18 +371,25 @@ def hashtest(mcx, device, table_slots, nkeys=800_000_000):
     g = mcx.Graph(K, 1, table_slots)
     g.insert_tuples_dev(0, keys[:65536], edges[:65536], 65536)
     g.sync(); g.reset(); g.sync()
-    g.configure("profile", 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    chunk = 100_000_000
-    for lo in range(0, nkeys, chunk):
-        n = min(chunk, nkeys - lo)
-        g.insert_tuples_dev(0, keys[lo:lo + n], edges[lo:lo + n], n)
-    g.sync()
-    dt = time.perf_counter() - t0
+
+    def one_pass():
+        g.configure("profile", 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        chunk = 100_000_000
+        for lo in range(0, nkeys, chunk):
+            n = min(chunk, nkeys - lo)
+            g.insert_tuples_dev(0, keys[lo:lo + n], edges[lo:lo + n], n)
+        g.sync()
+        return time.perf_counter() - t0
+
+    dt = one_pass()
     nk = g.nkmers
-    prof = g.profile()
+    spans = g.profile()
     nkc, sc = g.kmer_covg()
+    g.reset(); g.configure("flush_overlap", 0); g.sync()   # isolated per-kernel durations: a second pass, one kernel at a time
+    dt_iso = one_pass()
+    prof = g.profile()
     g.close()
     del keys, edges
     torch.cuda.empty_cache()
@@ -362,6 +402,9 @@ def hashtest(mcx, device, table_slots, nkeys=800_000_000):
                                     "source": "results/hash_table_benchmark/results20150409thurs.linux.txt:10"},
             "vs_reference_published": nkeys / dt / 5.9e6,
             "kernels": {n: {"launches": c, "total_ms": round(t, 3)} for n, (c, t) in prof.items()},
+            "kernels_note": "ISOLATED durations (second pass, flush overlap off); spans of the timed pass: spans_overlapped",
+            "isolated_pass_seconds": round(dt_iso, 4),
+            "spans_overlapped": {n: {"launches": c, "total_ms": round(t, 3)} for n, (c, t) in spans.items()},
             "what": "mccortex31 hashtest -k 31 -n 1G 800000000: integer keys 0..N-1, device-resident, mcx_graph_insert_tuples_dev in chunks of 100 M + sync"}
 
 
@@ -373,7 +416,7 @@ def c2_stress(mcx, device, nsteps, batch_reads, slots=1 << 33):
     try:
         # (flush size: the stream positions of all steps, as for C4 -- a device-resident launch is booked with the positions
         # it covers until it has settled -- so that the build really makes ONE table pass: 2 M sub-table visits, not 4 M)
-        r = run_config(mcx, steps, K, 1, [0] * nsteps, slots, nsteps * batch_reads * (READ_LEN + 1) + (1 << 26))
+        r = run_config(mcx, steps, K, 1, [0] * nsteps, slots, nsteps * batch_reads * (READ_LEN + 1) + (1 << 26), isolated=True)
     finally:
         del steps
         torch.cuda.empty_cache()
@@ -439,7 +482,7 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
     # (e) C4: k = 63 (two-word keys); C5-like: 4 colours on one GPU
     # (flush size: the stream positions of all steps -- the library books a device-resident stream launch with the
     # positions it covers, 1.7x the k-mers it yields at k = 63 -- so that the build makes ONE table pass like C2's)
-    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, max(5_000_000_000, len(steps) * B * (READ_LEN + 1) + (1 << 26)), pk)
+    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, max(5_000_000_000, len(steps) * B * (READ_LEN + 1) + (1 << 26)), pk, isolated=True)
     r["workload"] = "C4: k=63 (2-word BinaryKmer), 1 colour, %d reads x %d bp per step, table %d slots, 1 GPU" % (B, READ_LEN, table_slots)
     out["other_configs"] = {"C4_k63": r}
     # (4 colours: the L1 workspace is a pool of bin sets shared by the colours, sized here to hold all 20 steps,
@@ -617,7 +660,7 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the device-resident figure (profiling passes)")
-    ap.add_argument("--oracle-steps", type=int, default=2,
+    ap.add_argument("--oracle-steps", type=int, default=5,
                     help="steps of the workload the CPU oracle builds into the same -n table (timed = cpu_baseline.value; its records' checksum "
                          "is compared with the GPU graph of the same steps).  About 20 s of 32 host threads per step; 10 = the whole 50M-read set")
     ap.add_argument("--no-full-e2e", action="store_true", help="skip e2e_full (the CLI on the whole 50M-read FASTQ: a 15 GB scratch file)")
@@ -778,6 +821,7 @@ def main():
     torch.cuda.synchronize()
 
     st = graph.device_stats()
+    ist = graph.insert_stats()  # slow-path counters: must be zero on this workload
     kmers_local = st.num_kmers_loaded  # k-mer occurrences this rank k-merised (== inserted job-wide)
     prof = graph.profile()  # {kernel: (launches, total ms)} of the timed region, measured live with HIP events
     cs_local, nodes_local = graph.checksum()   # order-independent checksum of this rank's k-mers
@@ -865,8 +909,11 @@ def main():
                        "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel),
-                       "distinct_kmers_total": nodes_total, "graph_checksum": "%016x" % cs_total},
+                       "distinct_kmers_total": nodes_total, "graph_checksum": "%016x" % cs_total,
+                       "table_passes_rank0": ist["flushes"], "fallback_inserts_rank0": ist["fallback_inserts"], "foreign_inserts_rank0": ist["foreign_inserts"]},
         }
+        # the figures a reader looks for first, ahead of the long objects (a truncated log still shows them); filled in below
+        out["summary"] = {}
         # the same reads must give the same graph whatever N is (strong scaling and N = 1): the sum of the
         # ranks' order-independent checksums against what N = 1 runs of this file report for `steps` steps
         if (world == 1 or strong) and not args.iid and B == BATCH_READS and args.genome == GENOME_PER_GPU and args.err == 0.001 \
@@ -956,6 +1003,34 @@ def main():
         if ex.get("_tmpdir"):
             import shutil
             shutil.rmtree(ex["_tmpdir"], ignore_errors=True)
+        sm = out["summary"]
+        sm["value_gkmers_per_s"] = round(value / 1e9, 2)
+        sm["roofline_frac"] = round(out["roofline"]["frac"], 4)
+        for key in ("checksum_matches_oracle", "checksum_matches_n1"):
+            if key in out["config"]:
+                sm[key] = out["config"][key]
+        def _g(d, *path):
+            for p_ in path:
+                d = d.get(p_) if isinstance(d, dict) else None
+            return d
+        for name, path, scale in (("host_fed_gkmers_per_s", ("host_fed", "value"), 1e-9), ("e2e_seconds_10M_reads", ("e2e", "seconds"), 1),
+                                  ("e2e_full_seconds_50M_reads", ("e2e_full", "seconds"), 1), ("default_defer_gkmers_per_s", ("default_defer", "value"), 1e-9),
+                                  ("packed_resident_gkmers_per_s", ("packed_resident", "value"), 1e-9), ("ascii_resident_gkmers_per_s", ("ascii_resident", "value"), 1e-9),
+                                  ("C4_k63_gkmers_per_s", ("other_configs", "C4_k63", "value"), 1e-9), ("C4_k63_roofline_frac", ("other_configs", "C4_k63", "roofline_frac"), 1),
+                                  ("C5_like_gkmers_per_s", ("other_configs", "C5_like_4_colours_1gpu", "value"), 1e-9),
+                                  ("C5_interleaved_gkmers_per_s", ("other_configs", "C5_like_interleaved_colours_1gpu", "value"), 1e-9),
+                                  ("C2_stress_gkmers_per_s", ("other_configs", "C2_stress", "value"), 1e-9), ("hashtest_ginserts_per_s", ("other_configs", "hashtest", "value"), 1e-9),
+                                  ("inprocess_2_shards_1gpu_gkmers_per_s", ("inprocess_2_shards_1gpu", "value"), 1e-9),
+                                  ("inprocess_8_shards_1gpu_gkmers_per_s", ("inprocess_8_shards_1gpu", "value"), 1e-9),
+                                  ("cpu_baseline_mkmers_per_s_port", ("cpu_baseline", "value"), 1e-6)):
+            v = _g(out, *path)
+            if isinstance(v, (int, float)):
+                sm[name] = round(v * scale, 3)
+        v = _g(out, "e2e_full", "checksum_matches_device_resident_build")
+        if v is not None:
+            sm["e2e_full_checksum_matches_device_resident_build"] = v
+        if "cpu_baseline" in out:
+            sm["gpu_over_cpu_port"] = round(value / max(1.0, out["cpu_baseline"]["value"]), 1)
     if world > 1 or force_shard:
         dist.barrier()
         dist.destroy_process_group()

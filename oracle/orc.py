@@ -135,6 +135,9 @@ def ref_revcmp(W):
         R.ref_revcmp.restype = None
         R.ref_revcmp.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         assert R.ref_revcmp_words() == W
+        if hasattr(R, "ref_bklk3_hashlittle"):   # src/kmer/kmer_hash.h compiled in as well (round 5)
+            R.ref_bklk3_hashlittle.restype = C.c_uint32
+            R.ref_bklk3_hashlittle.argtypes = [C.c_void_p, C.c_uint32]
         _REVCMP[W] = R
     return _REVCMP[W]
 

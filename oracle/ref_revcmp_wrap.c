@@ -31,3 +31,23 @@ void ref_revcmp(int method, const uint64_t *in, size_t kmer_size, uint64_t *out)
   }
   for(i = 0; i < NUM_BKMER_WORDS; i++) out[i] = y.b[i];
 }
+
+/*
+ * The reference's own fixed-length hash of a BinaryKmer, src/kmer/kmer_hash.h:162-211 (bklk3_hashlittle), compiled
+ * from where it lies.  It needs <string.h>, the BinaryKmer typedef (revcmp.c brings it, above) and BKMER_BYTES as a
+ * number the preprocessor can compare: revcmp.c spells it with sizeof, which #if cannot evaluate -- the reference's
+ * src/graph/binary_kmer.h:17-18 keeps that spelling commented out for the same reason and uses the line below.
+ * That one macro value is the only thing written here; no header is stood in for.
+ */
+#include <string.h>
+#undef BKMER_BYTES
+#define BKMER_BYTES (NUM_BKMER_WORDS * 8) /* src/graph/binary_kmer.h:18 */
+#include "src/kmer/kmer_hash.h"
+
+uint32_t ref_bklk3_hashlittle(const uint64_t *in, uint32_t initval)
+{
+  BinaryKmer x;
+  size_t i;
+  for(i = 0; i < NUM_BKMER_WORDS; i++) x.b[i] = in[i];
+  return bklk3_hashlittle(x, initval);
+}

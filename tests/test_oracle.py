@@ -55,6 +55,28 @@ def test_hash_matches_reference_lookup3(orc):
             assert L.orc_kmer_hash(x, k, iv) == R.ref_lk3_hashlittle(a.ctypes.data, 8 * W, iv)
 
 
+@pytest.mark.parametrize("k", [3, 15, 29, 31, 33, 47, 63])
+def test_hash_matches_reference_kmer_hash_h(orc, mcx, k):
+    """The reference's own BinaryKmer hash -- bklk3_hashlittle, src/kmer/kmer_hash.h:162-211, compiled unmodified
+    into oracle/_ref with NUM_BKMER_WORDS = 1 and 2 -- against the oracle's orc_kmer_hash and the product's host
+    template mcx_kmer_hash (the device uses the same template: mcx_kmer.h kmer_hash<W>), on canonical keys and
+    arbitrary seeds (hash_table.c:132-145 rehashes with seed + i)."""
+    L = orc.lib()
+    W = L.orc_words_for_k(k)
+    R = orc.ref_revcmp(W)
+    if R is None or not hasattr(R, "ref_bklk3_hashlittle"):
+        pytest.skip("oracle/_ref/librevcmp%d.so with kmer_hash.h not built (needs /root/reference at build time)" % W)
+    rng = np.random.default_rng(500 + k)
+    for s in [_rand_kmer(rng, k) for _ in range(300)] + ["A" * k, "T" * k, "ACG" * (k // 3) + "A" * (k % 3)]:
+        x = L.orc_kmer_from_str(s.encode(), k)
+        key = L.orc_kmer_get_key(x, k)
+        a = np.array(_words(key, W), dtype=np.uint64)
+        for iv in (0, 1, 7, int(rng.integers(0, 2**32))):
+            want = R.ref_bklk3_hashlittle(a.ctypes.data, iv)
+            assert L.orc_kmer_hash(key, k, iv) == want
+            assert mcx.kmer_hash([int(w) for w in a], k, iv) == want
+
+
 @pytest.mark.parametrize("k", list(range(3, 64, 2)))
 def test_revcomp_matches_reference_revcmp(orc, mcx, k):
     """orc_kmer_revcomp / orc_kmer_get_key and the product's host template mcx_kmer_canonical against
