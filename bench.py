@@ -118,7 +118,7 @@ def csrc_digest():
     # ... and their launch geometry (grids, block sizes, LDS sizes, variant choice): the launch functions of mcx_api.hip
     # (round 4's last change -- 8 blocks per CU for the 512-thread k-merising kernel -- lived there and escaped the digest)
     api = open(os.path.join(d, "mcx_api.hip"), "rb").read()
-    lo, hi = api.find(b"static void launch_bin_stream_pk"), api.find(b"static void free_defer")
+    lo, hi = api.find(b"static void launch_bin_stream_pk"), api.find(b"static void free_defer(mcx_graph *g)\n{")
     if lo < 0 or hi < lo:
         raise RuntimeError("csrc_digest: launch functions not found in mcx_api.hip")
     h.update(b"launch-geometry")
