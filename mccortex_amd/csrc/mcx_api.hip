@@ -576,24 +576,6 @@ static void launch_bin_stream_pk(mcx_graph *g, const StreamArgs &a, uint64_t nt,
       return;
     }
   }
-  // region bins of an unsharded two-word table: 8 positions per lane x 512 threads (k_stream_bin8; MCX_STREAM_P=16: the old kernel)
-  if constexpr (W == 2 && !FULL && SH == 0) {
-    static const bool p8 = [] { const char *e = getenv("MCX_STREAM_P"); return !e || atoi(e) == 8; }();
-    if (p8 && bs.nlocal <= 1024) {
-      static bool once_8[64] = {false};
-      if (!once_8[g->device & 63]) {
-        allow_lds(k_stream_bin8<ONECOL, 512, PK>, sizeof(BinLds<2, 512, false, Geo8>));
-        allow_lds(k_stream_bin8<ONECOL, 1024, PK>, sizeof(BinLds<2, 1024, false, Geo8>));
-        once_8[g->device & 63] = true;
-      }
-      const dim3 grid8((unsigned)std::min<uint64_t>(nt, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid)));
-      if (bs.nlocal <= 512)
-        hipLaunchKernelGGL((k_stream_bin8<ONECOL, 512, PK>), grid8, dim3(kT8), sizeof(BinLds<2, 512, false, Geo8>), g->stream, a, bs, out, is);
-      else
-        hipLaunchKernelGGL((k_stream_bin8<ONECOL, 1024, PK>), grid8, dim3(kT8), sizeof(BinLds<2, 1024, false, Geo8>), g->stream, a, bs, out, is);
-      return;
-    }
-  }
   const dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid)));
   // the histogram capacity sets the LDS footprint and with it the blocks per CU: 512 and 1024 bins
   // leave room for 4 blocks (W=1), 2048 for 2

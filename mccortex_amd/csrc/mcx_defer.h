@@ -653,171 +653,6 @@ __global__ __launch_bounds__(T, (W == 1 ? 4 : 3)) void k_stream_bin(StreamArgs a
 }
 
 // ---------------------------------------------------------------------------
-// 1b. reads -> region bins, TWO-WORD keys, 8 positions per lane x 512 threads (round 5).
-//     k_stream_bin<W = 2> keeps a lane's 16 packed tuples in registers -- 64 VGPRs of tuple words plus 16 of tags: 168
-//     registers, 3 waves per SIMD, 33 ms for C4's 4.38 G occurrences against 14.6 ms of bytes.  Here a lane takes 8
-//     positions (32 + 8 registers of tuples), a tile of 4096 positions is k-merised by 512 threads, and two such blocks
-//     (4 waves per SIMD) fit a CU.  The price is the per-lane set-up (validity masks by doubling, the window loads), paid
-//     for 8 positions instead of 16.  Region bins of an unsharded table only (SH 0, packed tuples): the sharded and the
-//     owner-bin variants stay with k_stream_bin.
-// ---------------------------------------------------------------------------
-constexpr int kT8 = 512, kP8 = 8;
-using Geo8 = Geo<kT8, kTile>;
-template <bool ONECOL, int NB, bool PK>
-__global__ __launch_bounds__(kT8, 4) void k_stream_bin8(StreamArgs a_arg, BinSpec bs, BinOut out_arg, InsertSink<2, ONECOL> isink_arg)
-{
-  constexpr int W = 2;
-  static_assert(kT8 * kP8 == kTile, "one tile per block iteration");
-  __shared__ uint32_t s_code[kChunks + 4];
-  __shared__ uint32_t s_inv[kChunks / 2 + 4];
-  struct Cold { StreamArgs a; InsertSink<W, ONECOL> isink; };   // (as in k_stream_bin: rarely read arguments live in LDS)
-  __shared__ Cold cold;
-  if (threadIdx.x == 0) { cold.a = a_arg; cold.isink = isink_arg; }
-  __syncthreads();
-  const StreamArgs &a = cold.a;
-  const BinOut &out = out_arg;
-  const InsertSink<W, ONECOL> &isink = cold.isink;
-  const uint64_t a_tile0 = a_arg.tile0, a_ntiles = a_arg.ntiles;
-  const uint32_t t_lbq = isink_arg.t.lb1 + isink_arg.t.lbo;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  using LDS = BinLds<W, NB, false, Geo8>;
-  LDS &L = *reinterpret_cast<LDS *>(dyn_lds);
-
-  const int k = a_arg.k;
-  uint32_t n_kmers = 0, n_contigs = 0, n_novel = 0, full = 0;
-  const uint64_t top_mask = ~0ULL >> (128 - 2 * k);
-  const int first_shift = 2 * k - 66;
-  const uint32_t ob0 = (blockIdx.x % bs.rep) * bs.nout;
-
-  // the 272 chunks of a tile: one per thread (threads 0..271); the NEXT tile's chunk waits in registers
-  uint4 pre = make_uint4(0, 0, 0, 0);
-  auto fetch = [&](uint64_t tile, int t) {
-    if (t >= kChunks) return;
-    if (PK) {
-      const int64_t c = (int64_t)(tile * (kTile / 16)) - 1 + t, nch = (int64_t)((a_arg.nbytes + 15) / 16);
-      const bool in = c >= 0 && c < nch;
-      pre.x = in ? a_arg.code[c] : 0u;
-      pre.y = in ? (uint32_t)a_arg.inv[c] : 0xFFFFu;
-    } else {
-      pre = load_chunk(a_arg.stream, a_arg.nbytes, (int64_t)(tile * kTile) - 16 + 16 * (int64_t)t);
-    }
-  };
-  {
-    const uint64_t t0 = a_tile0 + blockIdx.x;
-    if (t0 < a_ntiles) fetch(t0, (int)threadIdx.x);
-  }
-  for (uint64_t tile = a_tile0 + blockIdx.x; tile < a_ntiles; tile += gridDim.x) {
-    const int tid = (int)tid_now();
-    if (tid < kChunks) {
-      uint32_t code, inv;
-      if (PK) { code = pre.x; inv = pre.y; } else encode_words(pre, code, inv);
-      s_code[tid] = code;
-      reinterpret_cast<uint16_t *>(s_inv)[tid ^ 1] = (uint16_t)inv;
-    }
-    for (uint32_t b = tid; b < bs.nlocal + 64; b += kT8) { L.cnt[b] = 0; L.rnk[b] = 0; }
-    if (tid < 4) { s_code[kChunks + tid] = 0; s_inv[kChunks / 2 + tid] = 0xFFFFFFFFu; }
-    {
-      const uint64_t tn = tile + gridDim.x;
-      if (tn < a_ntiles) fetch(tn, tid);
-    }
-    __syncthreads();
-
-    const uint32_t pl = 16u + (uint32_t)kP8 * (uint32_t)tid;  // the lane's first position in region coordinates (the halo chunk is 0..15)
-    const uint64_t Vh = inv_win64(s_inv, pl);
-    const uint64_t Vl = inv_win64(s_inv, pl + 64);
-    const uint32_t prev_inv = (s_inv[(pl - 1) >> 5] >> (31 - ((pl - 1) & 31))) & 1u;
-    uint32_t range = 0xFF00u;  // positions 0..7 of the lane at bits 15..8
-    {
-      const uint64_t plo = a.pos_lo, phi = a.pos_hi, T0 = tile * kTile;
-      if (T0 < plo || T0 + kTile > phi) {
-        const uint64_t P0 = T0 + (uint64_t)kP8 * (uint64_t)tid;
-        const int j_lo = plo > P0 ? (int)min((uint64_t)kP8, plo - P0) : 0;
-        const int j_hi = phi > P0 ? (int)min((uint64_t)kP8, phi - P0) : 0;
-        range = ((0x10000u >> j_lo) - 1u) & ~((0x10000u >> j_hi) - 1u);
-      }
-    }
-    uint32_t ok16, nok16, pok16;  // as in k_stream_bin; only bits 15..8 are looked at
-    {
-      uint64_t Mh = Vh, Ml = Vl;
-      for (int c = 1; c < k;) {  // uniform
-        const int s = min(c, k - c);
-        Mh |= (Mh << s) | (Ml >> (64 - s));
-        Ml |= Ml << s;
-        c += s;
-      }
-      ok16 = ~(uint32_t)(Mh >> 48) & range;
-      const int sh = 112 - k;  // 49..79
-      const uint64_t nx = sh >= 64 ? (Vh >> (sh - 64)) : ((Vh << (64 - sh)) | (Vl >> sh));
-      nok16 = ~(uint32_t)nx & 0xFFFFu;
-      pok16 = ~((prev_inv << 15) | (uint32_t)(Vh >> 49)) & 0xFFFFu;
-    }
-    Kmer<W> tk[kP8];
-    uint32_t tle[kP8];
-    const uint32_t trash = bs.nlocal + 1u + ((uint32_t)tid & 31u);
-    n_kmers += __popc(ok16);
-    n_contigs += __popc(ok16 & ~pok16);
-    {
-      const uint64_t hi = code_win64(s_code, pl), lo = code_win64(s_code, pl + 32);
-      const uint32_t own = (uint32_t)(hi >> 32);  // the lane's positions 0..15, first base on top
-      const uint32_t before = (s_code[(pl - 1) >> 4] >> (2u * (15u - ((pl - 1) & 15u)))) & 3u;
-      const uint32_t lbq = t_lbq;
-      Kmer<W> fw, rc;
-      const int s = 128 - 2 * k;
-      fw.w[0] = hi >> s;
-      fw.w[W - 1] = (lo >> s) | (hi << (64 - s));
-      rc = revcomp<W>(fw, k);
-      const uint32_t feed32 = (uint32_t)(code_win64(s_code, pl + (uint32_t)k) >> 32);  // the bases after the lane's k-mers
-      uint32_t arr_prev = 0;
-#pragma unroll
-      for (int j = 0; j < kP8; j++) {
-        const uint32_t prev_nuc = j == 0 ? before : ((own >> (32 - 2 * j)) & 3u);
-        const uint32_t nuc_next = (feed32 >> (30 - 2 * j)) & 3u;
-        const uint32_t valid = 0u - ((ok16 >> (15 - j)) & 1u);
-        const uint32_t nb = (nok16 >> (15 - j)) & 1u, pb = (pok16 >> (15 - j)) & 1u;
-        uint32_t o, r;
-        const Kmer<W> key = canonical<W>(fw, rc, o);
-        const uint32_t o4 = o << 2;
-        const uint32_t e = (nb << (nuc_next | o4)) | (pb << ((prev_nuc ^ 7u) ^ o4));
-        const Kmer<W> q = key_quot<W>(key, lbq, r);
-        const uint32_t G = r ^ mix_g(region_mix<W>(q), lbq);
-        tk[j] = tuple_pack<W>(q, e);
-        const uint32_t local = (G & valid) | (trash & ~valid);
-        tle[j] = local;
-        const uint32_t arr_now = atomicAdd(&L.cnt[local], 1u);
-        if (j > 0) { tle[j - 1] |= arr_prev << 12; asm volatile("" : "+v"(tle[j - 1])); }
-        arr_prev = arr_now;
-        if (j == kP8 - 1) tle[j] |= arr_now << 12;
-        asm volatile("" : "+v"(tle[j]), "+v"(tk[j].w[0]), "+v"(tk[j].w[W - 1]));
-        fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask;
-        fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc_next;
-        rc.w[W - 1] = (rc.w[W - 1] >> 2) | (rc.w[0] << 62);
-        rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << first_shift);
-      }
-    }
-    BinRes<NB, kT8> res;
-    bin_reserve<LDS, NB>(L, bs, out, ob0, res, true);
-#pragma unroll
-    for (int j = 0; j < kP8; j++) {
-      tle[j] += L.off[tle[j] & 0xfffu] << 12;  // arrival index -> sorted position
-      if ((j & 3) == 3) asm volatile("" : "+v"(tle[j - 3]), "+v"(tle[j - 2]), "+v"(tle[j - 1]), "+v"(tle[j]));
-    }
-    bin_commit<LDS, NB>(L, bs, out, ob0, res);
-    for (int round = 0; round < kRounds; round++) {
-#pragma unroll
-      for (int j = 0; j < kP8; j++)
-        bin_place<W, false, LDS>(L, round, tle[j] >> 12, tle[j] & 0xfffu, tk[j], 0);
-      bin_writeout<W, ONECOL, false, 0, LDS>(L, round, bs, out, ob0, 0, isink, n_novel, full);
-    }
-  }
-  block_add(&a.ctr->kmers, n_kmers);
-  block_add(&a.ctr->contigs, n_contigs);
-  block_add(&a.ctr->novel, n_novel);
-  if (full == 1) a.ctr->full = 1;
-  if (full == 2) a.ctr->bin_over = 1;
-  if (a.flag && n_contigs) *a.flag = 1;
-}
-
-// ---------------------------------------------------------------------------
 // 2. tuples -> bins.
 //    IN_FULL  (tuples received from other GPUs: keys + edge bytes) -> region bins, BIN_GROUP
 //    !IN_FULL (packed tuples of the region bins)                    -> sub-table bins, BIN_SUBLOCAL
