@@ -66,9 +66,13 @@ template <class T> struct DevBuf {
 class StagePool {
  public:
   static StagePool &get() { static StagePool *p = new StagePool(); return *p; }  // (never destroyed: its threads sleep until the process ends)
+  // The pool's turn (call_mu_) is held from begin() to finish(): a run() or begin() reached on the SAME thread in
+  // between would wait for itself.  No such path exists (submit() of add_reads_packed never packs), and owner_
+  // turns one into an abort with a message instead of a hang.
   void run(int T, const std::function<void(int)> &fn)
   {
     if (T <= 1) { fn(0); return; }
+    check_not_owner();
     std::lock_guard<std::mutex> turn(call_mu_);
     {
       std::unique_lock<std::mutex> lk(mu_);
@@ -86,7 +90,9 @@ class StagePool {
   // (both from the same thread).  `fn` must stay alive until finish().
   void begin(int T, const std::function<void(int)> &fn)
   {
+    check_not_owner();
     call_mu_.lock();
+    owner_.store(std::this_thread::get_id());
     {
       std::unique_lock<std::mutex> lk(mu_);
       while ((int)th_.size() < T) th_.emplace_back([this] { worker(); }), th_.back().detach();
@@ -101,9 +107,18 @@ class StagePool {
       cv_done_.wait(lk, [&] { return pending_ == 0; });
       fn_ = nullptr; T_ = 0; next_ = 0;
     }
+    owner_.store(std::thread::id());
     call_mu_.unlock();
   }
  private:
+  void check_not_owner() const
+  {
+    if (owner_.load() == std::this_thread::get_id()) {
+      fprintf(stderr, "mcx: internal error: the staging pool was re-entered between begin() and finish()\n");
+      abort();
+    }
+  }
+  std::atomic<std::thread::id> owner_{std::thread::id()};
   void worker()
   {
     std::unique_lock<std::mutex> lk(mu_);
@@ -1824,15 +1839,15 @@ static int ensure_stage(mcx_graph *g)
   // staged in a second region sized for reads of >= 15 bytes on average and the
   // filler stops a chunk when either region is full.
   const uint64_t bytes = kCarry + kStageBytes + 256 + (kStageBytes / 16 + 2) * sizeof(uint64_t);
-  for (int i = 0; i < mcx_graph::kStageBufs; i++) {
-    HIP_TRY(hipHostMalloc((void **)&g->h_stage[i], bytes, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&g->d_stage[i], bytes));
-    HIP_TRY(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&g->ev_copy[i], hipEventDisableTiming));
-    HIP_TRY(hipEventCreate(&g->ev_wait0[i]));
-    HIP_TRY(hipEventCreate(&g->ev_wait1[i]));
+  for (int i = 0; i < mcx_graph::kStageBufs; i++) {  // (per resource: a call that failed part-way is continued, not repeated)
+    if (!g->h_stage[i]) HIP_TRY(hipHostMalloc((void **)&g->h_stage[i], bytes, hipHostMallocDefault));
+    if (!g->d_stage[i]) HIP_TRY(hipMalloc((void **)&g->d_stage[i], bytes));
+    if (!g->ev[i]) HIP_TRY(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
+    if (!g->ev_copy[i]) HIP_TRY(hipEventCreateWithFlags(&g->ev_copy[i], hipEventDisableTiming));
+    if (!g->ev_wait0[i]) HIP_TRY(hipEventCreate(&g->ev_wait0[i]));
+    if (!g->ev_wait1[i]) HIP_TRY(hipEventCreate(&g->ev_wait1[i]));
   }
-  HIP_TRY(hipStreamCreateWithFlags(&g->cstream, hipStreamNonBlocking));
+  if (!g->cstream) HIP_TRY(hipStreamCreateWithFlags(&g->cstream, hipStreamNonBlocking));
   g->stage_alloc = bytes;
   return MCX_OK;
 }

@@ -82,6 +82,20 @@ __device__ __forceinline__ void table_count_foreign(const TableView &t)
 {
   if (t.touch) atomicAdd(reinterpret_cast<unsigned long long *>(t.touch) - 3, 1ULL);
 }
+// "Hash table is full", fail fast (round 5).  A key whose sub-table is full scans the overflow area linearly, the whole
+// of it (1 / 32 of the table) before it gives up -- and once that area is full EVERY further new key does: a build whose
+// -n is too small for its input (4.8 G distinct k-mers into 1.1 G slots) ground on for a quarter of an hour where the
+// reference dies at the first failed insert (hash_table.c:119-123).  The first scan that fails raises touch[-2]; an
+// insert that is about to enter the overflow area, or is in the middle of scanning it, gives up as soon as it sees the
+// flag (its occurrence is lost, but so is the build: mcx_graph_sync reports MCX_ERR_FULL).
+__device__ __forceinline__ bool table_full_flagged(const TableView &t)
+{
+  return t.touch && __hip_atomic_load(t.touch - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+__device__ __forceinline__ void table_flag_full(const TableView &t)
+{
+  if (t.touch) __hip_atomic_store(t.touch - 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint64_t *key_ptr(const TableView &t, uint64_t slot) { return t.rec + slot * t.KS; }
 __device__ __forceinline__ uint64_t *val_ptr(const TableView &t, uint64_t slot, uint32_t col)
 {
@@ -341,6 +355,7 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
   uint32_t probes = 0;
   uint64_t limit = ovf ? t.nslots - t.nmain : t.max_probe;
   bool fresh = !ovf;  // `cur`/`hint` were preloaded for this slot
+  if (ovf && table_full_flagged(t)) { full = 1; return; }
   for (;;) {
     uint64_t *r = key_ptr_t<W, ONECOL>(t, slot);
     uint64_t *v = val_ptr_t<W, ONECOL>(t, slot, col);
@@ -387,13 +402,15 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
       }
     }
     if (++probes >= limit) {
-      if (ovf || t.nslots == t.nmain) { full = 1; return; }
+      if (ovf || t.nslots == t.nmain) { full = 1; table_flag_full(t); return; }
       ovf = true;  // the whole sub-table was seen without a hit or a free slot
+      if (table_full_flagged(t)) { full = 1; return; }
       probes = 0;
       limit = t.nslots - t.nmain;
       slot = ovf_start<W>(t, key);
       continue;
     }
+    if (ovf && (probes & 4095u) == 0 && table_full_flagged(t)) { full = 1; return; }
     slot++;
     if (!ovf) { if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots; }  // wrap inside the sub-table
     else if (slot == t.nslots) slot = t.nmain;
@@ -441,13 +458,15 @@ __device__ __forceinline__ uint64_t find_or_insert_rec(const TableView &t, const
       if (__hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT) == key.w[W - 1]) return slot;
     }
     if (++probes >= limit) {  // sub-table full: the key is in the overflow area or nowhere (see ovf_start)
-      if (ovf || t.nslots == t.nmain) { if (!must_exist) full = 1; return kNoSlot; }
+      if (ovf || t.nslots == t.nmain) { if (!must_exist) { full = 1; table_flag_full(t); } return kNoSlot; }
       ovf = true;
+      if (!must_exist && table_full_flagged(t)) { full = 1; return kNoSlot; }
       probes = 0;
       limit = t.nslots - t.nmain;
       slot = ovf_start<W>(t, key);
       continue;
     }
+    if (ovf && !must_exist && (probes & 4095u) == 0 && table_full_flagged(t)) { full = 1; return kNoSlot; }
     slot++;
     if (!ovf) { if ((slot & (Sub<W>::kSlots - 1)) == 0) slot -= Sub<W>::kSlots; }
     else if (slot == t.nslots) slot = t.nmain;

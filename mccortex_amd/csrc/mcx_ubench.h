@@ -68,17 +68,20 @@ __global__ __launch_bounds__(256) void k_ubench_rmw(uint64_t *tab, uint64_t nrec
 
 template <class F> static int ubench_time(F launch, int reps, double *ms_out)
 {
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
-  launch();
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  (void)hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; r++) launch();
-  (void)hipEventRecord(e1, 0);
-  if (hipEventSynchronize(e1) != hipSuccess) return -1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess) return -1;
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return -1; }
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
+  bool ok = false;
+  launch();
+  if (hipDeviceSynchronize() == hipSuccess) {
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; r++) launch();
+    (void)hipEventRecord(e1, 0);
+    ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (!ok || !(ms > 0.f) || reps < 1) { (void)hipGetLastError(); return -1; }  // (a rate is about to be divided by this)
   *ms_out = ms / reps;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -20,7 +20,15 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
+
+static double now_ms(void)
+{
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
 
 typedef struct {
   const unsigned char *p, *end; /* byte range, starts at a record boundary */
@@ -197,6 +205,9 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
                void (*submit)(void *arg, read_batch *b, int fq_offset_guess), void (*started)(void *arg), void *arg)
 {
   if (nthreads < 2 || (fmt != SEQ_FMT_FASTA && fmt != SEQ_FMT_FASTQ && fmt != SEQ_FMT_PLAIN)) return 1;
+  const bool timing = getenv("MCX_TIMING") != NULL;
+  const double t_start = now_ms();
+  double t_submit = 0;
   int fd = open(path, O_RDONLY);
   if (fd < 0) return 1;
   struct stat st;
@@ -247,6 +258,7 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
     }
     prev = next;
   }
+  const double t_setup = now_ms();
   for (int t = 0; t < nthreads; t++) pthread_create(&c.w[t].th, NULL, worker_main, &c.w[t]);
   if (started) started(arg); /* the first batches are tens of milliseconds away */
 
@@ -260,7 +272,9 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
         const int idx = w->ready;
         pthread_mutex_unlock(&c.mu);
         int guess = w->rp.qmax ? (w->rp.qmin >= 59 ? 64 : 33) : 0;
+        const double ts = timing ? now_ms() : 0;
         submit(arg, &w->batch[idx], guess);
+        if (timing) t_submit += now_ms() - ts;
         pthread_mutex_lock(&c.mu);
         w->ready = -1;
         pthread_cond_broadcast(&c.cv_free);
@@ -279,11 +293,15 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
     if (!progressed && live > 0) pthread_cond_wait(&c.cv_ready, &c.mu);
   }
   pthread_mutex_unlock(&c.mu);
+  const double t_parsed = now_ms();
   for (int t = 0; t < nthreads; t++) { read_batch_free(&c.w[t].batch[0]); read_batch_free(&c.w[t].batch[1]); }
   free(c.w);
   pthread_mutex_destroy(&c.mu);
   pthread_cond_destroy(&c.cv_ready);
   pthread_cond_destroy(&c.cv_free);
   munmap((void *)base, size);
+  if (timing)
+    fprintf(stderr, "[timing] par_ingest %s: %d threads, %.1f MB: set-up %.1f ms, parse + submit %.1f ms (of which inside submit %.1f), teardown %.1f ms\n",
+            path, nthreads, size / 1e6, t_setup - t_start, t_parsed - t_setup, t_submit, now_ms() - t_parsed);
   return rc;
 }

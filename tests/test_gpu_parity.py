@@ -663,3 +663,25 @@ def test_coverage_saturates_through_the_read_path(mcx, orc, k, how, monkeypatch)
     sat = [recs[struct.pack("<%dQ" % W, *key)] for i, key in enumerate(keys) if near[i % len(near)] >= 0xFFFFFFFC and i >= 5]
     assert sat and all(c == 0xFFFFFFFF for c in sat)   # (the first 5 k-mers got 3 hits, the rest 4)
     g.close()
+
+
+@pytest.mark.parametrize("defer", [1, 0])
+def test_overfull_table_fails_fast(mcx, defer):
+    """-n far too small for the input: the reference dies at the first insert that finds no slot ("Hash table is
+    full", hash_table.c:119-123).  Here every further new key used to scan the whole overflow area (1 / 32 of the
+    table) before giving up -- a build of 4.8 G distinct k-mers into 1.1 G slots did not finish in a quarter of an
+    hour.  The first failed scan now raises a flag that turns the later ones away: MCX_ERR_FULL within seconds."""
+    import time
+    rng = np.random.default_rng(4)
+    n, L = 300_000, 150
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * L)]       # iid: 36 M distinct k-mers
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    g = mcx.Graph(31, 1, 1 << 22)                                            # 4 M slots (+ 1 / 32 overflow area)
+    g.configure("defer", defer)
+    t0 = time.perf_counter()
+    with pytest.raises(mcx.McxError) as ei:
+        g.add_reads(0, bases, offs)
+        g.sync()
+    assert ei.value.code == mcx.MCX_ERR_FULL
+    assert time.perf_counter() - t0 < 30
+    g.close()
