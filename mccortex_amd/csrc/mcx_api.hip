@@ -826,6 +826,20 @@ static BinOut l1_out(const mcx_graph *g, int set)
   return BinOut{g->l1_keys + (uint64_t)set * segs * g->cap1 * g->W, nullptr, g->l1_cnt + (uint64_t)set * segs, g->cap1, nullptr, nullptr, nullptr, 0};
 }
 
+// The second stream of the flush overlap.  Creating a stream takes tens of milliseconds on this runtime (60 ms each in the
+// rocprofv3 HIP trace of a CLI build, round 5): "prepare" does it while the first batch is being parsed, so that the
+// closing flush of a host-fed build does not pay for it.
+static int ensure_flush_stream(mcx_graph *g)
+{
+  if (g->stream2) return MCX_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    if (!g->ev_split[i]) HIP_TRY(hipEventCreateWithFlags(&g->ev_split[i], hipEventDisableTiming));
+    if (!g->ev_ins[i]) HIP_TRY(hipEventCreateWithFlags(&g->ev_ins[i], hipEventDisableTiming));
+  }
+  return MCX_OK;
+}
+
 // Split the L1 bins by sub-table and let one workgroup per sub-table apply its tuples in LDS,
 // one group of regions at a time.
 static int flush_deferred(mcx_graph *g)
@@ -853,13 +867,8 @@ static int flush_deferred(mcx_graph *g)
   const bool overlap = flush_overlap(g) && g->pending && !g->pending_l2 && g->l2_regions >= 2 * G && G < g->b1;
   hipStream_t s1 = g->stream;
   if (overlap) {
-    if (!g->stream2) {
-      HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
-      for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipEventCreateWithFlags(&g->ev_split[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&g->ev_ins[i], hipEventDisableTiming));
-      }
-    }
+    int rc2 = ensure_flush_stream(g);
+    if (rc2 != MCX_OK) return rc2;
     HIP_TRY(hipEventRecord(g->ev_split[0], s1));  // the second stream starts behind everything queued so far
     HIP_TRY(hipStreamWaitEvent(g->stream2, g->ev_split[0], 0));
   }
@@ -1127,6 +1136,7 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
   if (!strcmp(key, "prepare")) {  // allocate now what the first mcx_graph_add_reads would: pinned staging, bins
     int rc = ensure_stage(g);
     if (rc == MCX_OK && g->defer && !g->must_exist) rc = ensure_defer(g);
+    if (rc == MCX_OK && g->defer && !g->must_exist && flush_overlap(g)) rc = ensure_flush_stream(g);
     return rc;
   }
   if (!strcmp(key, "grid_stream")) { g->grid_stream = (int)value; return MCX_OK; }
@@ -1814,8 +1824,8 @@ static int flush_if_device_idle(mcx_graph *g, int starved = -1 /* -1: ask the st
   HIP_TRY(hipGetLastError());
   DISPATCH_WC(g, launch_lds_insert_t, g, colour, r0 * g->subs_per_bin, ng * g->subs_per_bin);
   HIP_TRY(hipGetLastError());
-  for (uint32_t rep = 0; rep < g->rep1; rep++)  // the group's L1 bins are empty again
-    HIP_TRY(hipMemsetAsync(g->l1_cnt + (uint64_t)rep * g->b1 + r0, 0, (size_t)ng * 8, g->stream));
+  // the group's L1 bins are empty again: its counters in all replicas with one call (rows of ng counters, b1 apart)
+  HIP_TRY(hipMemset2DAsync(g->l1_cnt + r0, (size_t)g->b1 * 8, 0, (size_t)ng * 8, g->rep1, g->stream));
   // The bound on what is buffered.  A region group that has not been emptied since A_i occurrences had been
   // handed over holds its share of A - A_i; the flush trigger (defer_reserve) compares `pending` with the
   // capacity the segments were sized for, so `pending` must stay A - min_i(A_i): it only drops once the group
@@ -2485,9 +2495,15 @@ extern "C" int mcx_graph_add_reads_pcr(mcx_graph *g, int colour, const uint8_t *
 static int fetch_counters(mcx_graph *g)
 {
   HIP_TRY(hipSetDevice(g->device));
+  static const bool timing = getenv("MCX_TIMING") != nullptr;
+  const double t0 = timing ? now_s() : 0;
+  const uint64_t had = g->pending + g->pending_l2;
   { int rc = flush_deferred(g); if (rc != MCX_OK) return rc; }
+  const double t1 = timing ? now_s() : 0;
   HIP_TRY(hipMemcpyAsync(g->h_ctr, g->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
+  if (timing && had) fprintf(stderr, "[timing] closing flush: %.1f ms to enqueue (%llu occurrences booked), %.1f ms until the device was idle\n",
+                             (t1 - t0) * 1e3, (unsigned long long)had, (now_s() - t1) * 1e3);
   if (g->h_ctr->full) return fail(MCX_ERR_FULL, "Hash table is full");
   if (g->h_ctr->bin_over) return fail(MCX_ERR_FULL, "partition bin overflow");
   return MCX_OK;

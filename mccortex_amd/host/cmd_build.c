@@ -753,7 +753,15 @@ int ctx_build(int argc, char **argv)
     }
     else if (bt->remove_pcr) { load_task_pcr(g, bt); prc = 0; }
     else if (nthreads > 1 && strcmp(bt->path, "-") != 0)
-      prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, getenv("MCX_PAR_BATCH") ? (size_t)atol(getenv("MCX_PAR_BATCH")) : PAR_BATCH_BASES, submit_batch, t == 0 ? prepare_graph : NULL, &sc);
+    {
+      /* batch size of the range parsers: every batch costs its mcx_graph_add_reads call about half a millisecond of
+       * HIP calls whatever its size (rocprofv3 --hip-trace of a 12 GB build, round 5), so large files get 64 MB
+       * batches -- as long as the 2 x threads buffers stay a small part of the file */
+      size_t pb = PAR_BATCH_BASES;
+      if (file_size(bt->path) >= (off_t)4 * (off_t)nthreads * (off_t)(64u << 20)) pb = 64u << 20;
+      if (getenv("MCX_PAR_BATCH")) pb = (size_t)atol(getenv("MCX_PAR_BATCH"));
+      prc = par_ingest(bt->path, bt->fmt, (int)nthreads, sc.use_q, pb, submit_batch, t == 0 ? prepare_graph : NULL, &sc);
+    }
     if (prc == 2) {
       /* A record the range parsers do not handle (multi-line FASTQ) beyond the part of the file that was
        * probed: batches of this file are in the graph already.  When nothing else is (first input, no

@@ -198,6 +198,21 @@ static void *worker_main(void *arg)
   return NULL;
 }
 
+/* What is left to do when the last batch has been handed over: give back 2 x nthreads batch buffers (33 MB each, huge
+ * pages) and unmap the file.  For a 12 GB FASTQ that took 150-190 ms on the build's critical path (round 5,
+ * tools/exp_parse.sh: parse alone 80 ms, teardown 150 ms) -- a third of the whole ingest.  A detached thread does it
+ * while the caller goes on to flush, sort and write the graph. */
+typedef struct { worker *w; int nw; void *base; size_t size; } teardown_job;
+static void *teardown_main(void *arg)
+{
+  teardown_job *j = arg;
+  for (int t = 0; t < j->nw; t++) { read_batch_free(&j->w[t].batch[0]); read_batch_free(&j->w[t].batch[1]); }
+  free(j->w);
+  munmap(j->base, j->size);
+  free(j);
+  return NULL;
+}
+
 /* Parse `path` with nthreads threads, calling submit(batch) for every batch on the calling thread.
  * Returns 0 on success, 1 if the file is not suitable (caller uses the sequential parser; nothing
  * has been submitted), 2 if an irregular record was met after submission began. */
@@ -294,12 +309,20 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
   }
   pthread_mutex_unlock(&c.mu);
   const double t_parsed = now_ms();
-  for (int t = 0; t < nthreads; t++) { read_batch_free(&c.w[t].batch[0]); read_batch_free(&c.w[t].batch[1]); }
-  free(c.w);
   pthread_mutex_destroy(&c.mu);
   pthread_cond_destroy(&c.cv_ready);
   pthread_cond_destroy(&c.cv_free);
-  munmap((void *)base, size);
+  {
+    teardown_job *j = malloc(sizeof(*j));
+    pthread_t th;
+    pthread_attr_t at;
+    if (!j) die("Out of memory");
+    *j = (teardown_job){c.w, nthreads, (void *)base, size};
+    pthread_attr_init(&at);
+    pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+    if (getenv("MCX_SYNC_TEARDOWN") || pthread_create(&th, &at, teardown_main, j) != 0) teardown_main(j);
+    pthread_attr_destroy(&at);
+  }
   if (timing)
     fprintf(stderr, "[timing] par_ingest %s: %d threads, %.1f MB: set-up %.1f ms, parse + submit %.1f ms (of which inside submit %.1f), teardown %.1f ms\n",
             path, nthreads, size / 1e6, t_setup - t_start, t_parsed - t_setup, t_submit, now_ms() - t_parsed);
