@@ -1842,13 +1842,29 @@ static int flush_if_device_idle(mcx_graph *g, int starved = -1 /* -1: ask the st
   return MCX_OK;
 }
 
+// Layout of a staging buffer.  ASCII chunks (MCX_PACKED=0, the fallback): kCarry + kStageBytes stream bytes, then the
+// staged offsets.  Packed chunks (the default): code words, invalid flags, offsets back to back -- 112 MB instead of
+// 192 MB at the default chunk size, and three of them are page-locked on the first call (hipHostMalloc pins about
+// 4 GB/s: 60 of `prepare`'s 150-200 ms on the CLI's critical path before the first batch can be submitted; round 5).
+static bool stage_packed()
+{
+  static const bool packed = [] { const char *e = getenv("MCX_PACKED"); return !e || atoi(e) != 0; }();
+  return packed;
+}
+static uint64_t stage_inv_at() { return (((kCarry + kStageBytes + 64) / 16 * 4) + 63) & ~63ull; }  // packed: byte offset of the invalid flags
+static uint64_t stage_off_region()
+{
+  if (!stage_packed()) return kCarry + kStageBytes + 256;
+  return (stage_inv_at() + (kCarry + kStageBytes + 64) / 16 * 2 + 255) & ~255ull;
+}
+
 static int ensure_stage(mcx_graph *g)
 {
   if (g->stage_alloc) return MCX_OK;
   // stream bytes + worst-case one offset per 2 bytes would be silly; offsets are
   // staged in a second region sized for reads of >= 15 bytes on average and the
   // filler stops a chunk when either region is full.
-  const uint64_t bytes = kCarry + kStageBytes + 256 + (kStageBytes / 16 + 2) * sizeof(uint64_t);
+  const uint64_t bytes = stage_off_region() + (kStageBytes / 16 + 2) * sizeof(uint64_t);
   for (int i = 0; i < mcx_graph::kStageBufs; i++) {  // (per resource: a call that failed part-way is continued, not repeated)
     if (!g->h_stage[i]) HIP_TRY(hipHostMalloc((void **)&g->h_stage[i], bytes, hipHostMallocDefault));
     if (!g->d_stage[i]) HIP_TRY(hipMalloc((void **)&g->d_stage[i], bytes));
@@ -1876,10 +1892,10 @@ static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, 
 static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, const uint64_t *off, uint64_t nreads,
                             unsigned char *d_flags)
 {
-  const uint64_t off_region = kCarry + kStageBytes + 256;  // byte offset of the staged offsets (8-aligned), as in the ASCII layout
+  const uint64_t off_region = stage_off_region();           // byte offset of the staged offsets (8-aligned)
   const uint64_t max_offs = kStageBytes / 16;
   const uint64_t cap_pos = kCarry + kStageBytes + 64;       // positions a chunk may hold
-  const uint64_t inv_at = ((cap_pos / 16 * 4) + 63) & ~63ull;  // byte offset of the invalid flags inside a staging buffer
+  const uint64_t inv_at = stage_inv_at();                   // byte offset of the invalid flags inside a staging buffer
   uint32_t carry_code[kCarry / 16];
   uint16_t carry_inv[kCarry / 16];
   for (uint64_t i = 0; i < kCarry / 16; i++) { carry_code[i] = 0; carry_inv[i] = 0xFFFF; }
@@ -2124,7 +2140,7 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
   HIP_TRY(hipMallocAsync((void **)&d_flags, nreads, g->stream));
   HIP_TRY(hipMemsetAsync(d_flags, 0, nreads, g->stream));
 
-  static const bool packed = [] { const char *e = getenv("MCX_PACKED"); return !e || atoi(e) != 0; }();
+  const bool packed = stage_packed();
   if (packed) {
     rc = add_reads_packed(g, colour, bases, off, nreads, d_flags);
     if (rc != MCX_OK) return rc;
@@ -2134,7 +2150,7 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
     return MCX_OK;
   }
 
-  const uint64_t off_region = kCarry + kStageBytes + 256;  // byte offset of the staged offsets (8-aligned)
+  const uint64_t off_region = stage_off_region();  // byte offset of the staged offsets (8-aligned)
   const uint64_t max_offs = kStageBytes / 16;
   uint64_t r = 0, r_pos = 0;  // next read, bytes of it already staged
   uint8_t carry[kCarry];
@@ -2606,7 +2622,7 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
   HIP_TRY(hipMemcpyAsync(d_into, from_col, sizeof(int32_t) * (size_t)nmap, hipMemcpyHostToDevice, g->stream));
   HIP_TRY(hipMemcpyAsync(d_into.p + nmap, into_col, sizeof(int32_t) * (size_t)nmap, hipMemcpyHostToDevice, g->stream));
   HIP_TRY(hipMemcpyAsync(d_st, &h_st, sizeof(h_st), hipMemcpyHostToDevice, g->stream));
-  const uint64_t per_chunk = std::max<uint64_t>(1, kStageBytes / rec_bytes);
+  const uint64_t per_chunk = std::max<uint64_t>(1, std::min<uint64_t>(kStageBytes, g->stage_alloc) / rec_bytes);  // (a staging buffer holds stage_alloc bytes)
   int cur = 0;
   for (uint64_t r0 = 0; r0 < nrecs; r0 += per_chunk, cur ^= 1) {
     const uint64_t n = std::min(per_chunk, nrecs - r0);
