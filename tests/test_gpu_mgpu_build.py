@@ -28,7 +28,7 @@ def _launch(world, port, tail, env=None, timeout=900):
         e.update(ONE_GPU)
     e.update(env or {})
     p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
-    if p.returncode != 0:   # the whole log of a failed launch, for the builder (gpurun_out/ is scratch)
+    if p.returncode != 0 and b"already exists" not in p.stderr:   # the whole log of a failed launch, for the builder (gpurun_out/ is scratch)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "failed_launch_%d.log" % port), "wb") as f:
             f.write(p.stdout + b"\n---- stderr ----\n" + p.stderr)
