@@ -516,6 +516,7 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
         else:
             g.add_stream_dev(0, steps[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
         g.sync(); g.reset(); g.sync()
+        g.configure("profile", 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i, b in enumerate(steps):
@@ -526,11 +527,21 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
         g.sync()
         dt = time.perf_counter() - t0
         st = g.device_stats()
+        ist = g.insert_stats()
+        # HIP-event spans of every shard's kernels, summed over the shards (all of which share the ONE device here, so
+        # the spans of different shards overlap each other: a breakdown of where the launches go, not a time budget)
+        stage_of = {"k_stream_superk": "sender", "k_stream_bin": "sender", "k_superk_bin": "owner", "k_tuples_bin": "split", "k_lds_insert": "insert"}
+        stages = {}
+        for kn, (c, t) in g.profile().items():
+            e = stages.setdefault(stage_of.get(kn.split("@")[0], kn.split("@")[0]), {"launches": 0, "span_ms_summed_over_shards": 0.0})
+            e["launches"] += c
+            e["span_ms_summed_over_shards"] = round(e["span_ms_summed_over_shards"] + t, 2)
         cs, nk = g.checksum()
         g.close()
         torch.cuda.empty_cache()
         out["inprocess_%d_shards_1gpu" % nsh] = {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(steps),
                                           "distinct_kmers": int(st.num_kmers_novel), "graph_checksum": "%016x" % cs,
+                                          "stages": stages, "table_passes_all_shards": ist["flushes"], "fallback_inserts": ist["fallback_inserts"], "spilled": ist["spilled"],
                                           "what": "mcx_graph_create_multi with device 0 named %d times: %d shards on ONE GPU, exchange v3 (super-k-mer records, "
                                                   "minimizer owners), the filled parts copied by a kernel through peer-mapped pointers (device-local here); a "
                                                   "measure of the path's overhead, not of scaling; the graph checksum must equal config.graph_checksum" % (nsh, nsh)}

@@ -229,8 +229,8 @@ class Graph:
 
     def profile(self):
         """{kernel: (calls, total_ms)} for launches recorded since configure('profile', 1)."""
-        buf = C.create_string_buffer(4096)
-        _check(self.L.mcx_graph_profile(self.h, buf, 4096))
+        buf = C.create_string_buffer(16384)   # (a multi-GPU handle reports every shard's kernels: name@shard)
+        _check(self.L.mcx_graph_profile(self.h, buf, 16384))
         out = {}
         for line in buf.value.decode().splitlines():
             name, calls, ms = line.split()
