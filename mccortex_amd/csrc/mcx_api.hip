@@ -31,6 +31,7 @@
 using namespace mcx;
 
 static thread_local char g_err[512] = "";
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -1134,9 +1135,15 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     return MCX_OK;
   }
   if (!strcmp(key, "prepare")) {  // allocate now what the first mcx_graph_add_reads would: pinned staging, bins
+    const double t0 = now_s();
     int rc = ensure_stage(g);
+    const double t1 = now_s();
     if (rc == MCX_OK && g->defer && !g->must_exist) rc = ensure_defer(g);
+    const double t2 = now_s();
     if (rc == MCX_OK && g->defer && !g->must_exist && flush_overlap(g)) rc = ensure_flush_stream(g);
+    if (getenv("MCX_TIMING"))
+      fprintf(stderr, "[timing] prepare: pinned staging + copy stream %.1f ms, partition workspace (%.1f GB) %.1f ms, flush stream %.1f ms\n", (t1 - t0) * 1e3,
+              g->l1_keys ? (double)g->nsets * g->b1 * g->rep1 * g->cap1 * 8 * g->W / 1e9 : 0.0, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     return rc;
   }
   if (!strcmp(key, "grid_stream")) { g->grid_stream = (int)value; return MCX_OK; }
@@ -1783,7 +1790,6 @@ struct StageTiming {
                                           (unsigned long long)chunks, wait * 1e3, prep * 1e3, pack * 1e3, submit * 1e3, (unsigned long long)flushes); }
 };
 static StageTiming g_stage_timing;
-static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Host-fed builds: when the device has caught up with the host (nothing queued on the graph's stream
 // at the moment a packed chunk is about to be copied) the host is the bottleneck -- parsing, packing,
@@ -2719,11 +2725,16 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
     (void)hipFree(d_ks); (void)hipFree(d_ks2); (void)hipFree(d_tmp);
     d_k0 = d_k1 = d_slot = d_idx = d_idx2 = d_ks = d_ks2 = nullptr; d_tmp = nullptr;
   };
+  // The chunk buffers: the host entry's staging pairs when the graph has them (pinned host + device memory that sits
+  // idle once the reads are in: the device is idle here, fetch_counters has just returned) -- page-locking two fresh
+  // 64 MiB buffers took 23 ms on a good day and 263 ms on a bad one (`export ... buffers allocated`, round 5).
+  const bool borrow = g->stage_alloc >= chunk * recsz && g->h_stage[0] && g->h_stage[1] && g->d_stage[0] && g->d_stage[1];
   auto cleanup = [&]() {
     free_range();
     (void)hipFree(d_cursor);
     for (int i = 0; i < 2; i++) {
       if (done[i]) (void)hipEventDestroy(done[i]);
+      if (borrow) continue;
       (void)hipFree(d_rec2[i]);
       if (h_rec2[i]) (void)hipHostFree(h_rec2[i]);
     }
@@ -2741,8 +2752,13 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   // records are produced and copied to pinned memory in 64 MiB chunks, double buffered: while the
   // sink consumes chunk i on the host, the device emits and copies chunk i + 1
   for (int i = 0; i < 2; i++) {
-    EXP_TRY(hipMalloc((void **)&d_rec2[i], chunk * recsz));
-    EXP_TRY(hipHostMalloc((void **)&h_rec2[i], chunk * recsz, hipHostMallocDefault));
+    if (borrow) {
+      d_rec2[i] = g->d_stage[i];
+      h_rec2[i] = g->h_stage[i];
+    } else {
+      EXP_TRY(hipMalloc((void **)&d_rec2[i], chunk * recsz));
+      EXP_TRY(hipHostMalloc((void **)&h_rec2[i], chunk * recsz, hipHostMallocDefault));
+    }
     EXP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
   }
   export_clock("buffers allocated");

@@ -674,10 +674,17 @@ int ctx_build(int argc, char **argv)
   if (ndevices == 1) devices[0] = device;
   mcx_check(mcx_graph_create_multi(&g, (int)kmer_size, (int)dev_cols, kmers_in_hash, devices, ndevices), "Cannot allocate graph");
   if (ngisec > 0) mcx_check(mcx_graph_configure(g, "intersect", 1), "intersect mode");
-  /* The partition workspace is sized for the occurrences buffered per flush (by default as much as
-   * 30 % of the free HBM allows): when the inputs cannot hold that many, size it for the inputs. */
-  if (seq_bytes_known && ngisec == 0 && !getenv("MCX_DEFER_TUPLES"))
-    mcx_check(mcx_graph_configure(g, "defer_tuples", seq_bytes_est + (1u << 20) > (1ull << 33) ? (1ull << 33) : seq_bytes_est + (1u << 20)), "flush size");
+  /* The partition workspace is sized for the occurrences buffered per flush (the library's default: as much as
+   * 40 % of the free HBM allows, up to 8.6 G occurrences = 65 GB): when the inputs cannot hold that many, size it for
+   * the inputs -- and never beyond 2.1 G occurrences (18 GB) here: a build fed from files is bound by the host (the
+   * device is busy for 145 ms of a 1 s build, round 5), so the extra table passes of a smaller window run in time the
+   * device would otherwise idle, while a 65 GB hipMalloc costs 0.6-2.2 s whenever the device's memory was freed by
+   * another process moments before (the driver hands it over at ~30 GB/s then; 0.8 ms when it is clean). */
+  if (ngisec == 0 && !getenv("MCX_DEFER_TUPLES")) {
+    uint64_t window = 1ull << 31;
+    if (seq_bytes_known && seq_bytes_est + (1u << 20) < window) window = seq_bytes_est + (1u << 20);
+    mcx_check(mcx_graph_configure(g, "defer_tuples", window), "flush size");
+  }
   uint64_t slots = 0, tbytes = 0;
   mcx_graph_capacity(g, &slots, &tbytes);
   status("[hasht] Allocated table in HBM with %s entries, using %s", ulong_to_str(slots, s1), bytes_to_str(tbytes, 1, s2));
