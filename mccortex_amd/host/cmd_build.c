@@ -680,13 +680,15 @@ int ctx_build(int argc, char **argv)
    * device is busy for 145 ms of a 1 s build, round 5), so the extra table passes of a smaller window run in time the
    * device would otherwise idle, while a 65 GB hipMalloc costs 0.6-2.2 s whenever the device's memory was freed by
    * another process moments before (the driver hands it over at ~30 GB/s then; 0.8 ms when it is clean). */
+  uint64_t slots = 0, tbytes = 0;
+  mcx_graph_capacity(g, &slots, &tbytes);
   if (ngisec == 0 && !getenv("MCX_DEFER_TUPLES")) {
     uint64_t window = 1ull << 31;
+    const uint64_t by_table = 64 * (slots / (uint64_t)ndevices);  /* (the library's own rule: 64 occurrences per slot of a device's table) */
+    if (by_table < window) window = by_table;
     if (seq_bytes_known && seq_bytes_est + (1u << 20) < window) window = seq_bytes_est + (1u << 20);
     mcx_check(mcx_graph_configure(g, "defer_tuples", window), "flush size");
   }
-  uint64_t slots = 0, tbytes = 0;
-  mcx_graph_capacity(g, &slots, &tbytes);
   status("[hasht] Allocated table in HBM with %s entries, using %s", ulong_to_str(slots, s1), bytes_to_str(tbytes, 1, s2));
   stage_time("table allocated");
 
