@@ -578,6 +578,7 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
     try:
         ne = min(2, len(steps))
         write_fastq(fq, steps[:ne], fq_small)
+        os.sync()   # (input preparation ends here: the file's dirty pages are on disk before the command is timed)
         nthreads = min(32, os.cpu_count() or 1)
         cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-m", "%dG" % (table_slots * 21 // (1 << 30) + 2), "-t", str(nthreads),
                "--sort", "--sample", "bench", "--seq", fq, ctx]
@@ -630,6 +631,7 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
                     os.unlink(f_)
             t0 = time.perf_counter()
             write_fastq(fq, batches[:n_c2])
+            os.sync()   # (the 15 GB just written are dirty pages: without this their write-back competes with the command's own 4.4 GB of output)
             t_write = time.perf_counter() - t0
             nthreads = min(32, os.cpu_count() or 1)
             cmd = [exe, "build", "-f", "-k", str(K), "-n", str(table_slots), "-m", "%dG" % (table_slots * 21 // (1 << 30) + 2), "-t", str(nthreads),
