@@ -2725,13 +2725,19 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   // gigabytes each: 40 ms of an export on a good day, 200+ ms when the driver has to hand over memory another process
   // freed moments before (`export ... compacted / sorted`: 38 / 52 ms against 149 / 282 ms, round 5).  What does not
   // fit the pool is allocated as before.
-  uint8_t *pool = (g->l1_keys && !g->pending && !g->pending_l2) ? reinterpret_cast<uint8_t *>(g->l1_keys) : nullptr;
-  const uint64_t pool_bytes = pool ? (uint64_t)g->nsets * g->b1 * g->rep1 * g->cap1 * 8 * g->W : 0;
-  uint64_t pool_off = 0;
+  // (two pools: the region bins and the sub-table bins.  The command's 2.1 G-occurrence window gives 18.5 + 2.9 GB; C2's
+  // 337 M k-mers need 5 x 2.7 GB of arrays + 5.4 GB for the radix sort, and the one array that found no room made a
+  // hipMalloc of 150 ms inside the bench process)
+  const bool bins_idle = g->l1_keys && !g->pending && !g->pending_l2;
+  uint8_t *pool[2] = {bins_idle ? reinterpret_cast<uint8_t *>(g->l1_keys) : nullptr, bins_idle ? reinterpret_cast<uint8_t *>(g->l2_keys) : nullptr};
+  const uint64_t pool_bytes[2] = {pool[0] ? (uint64_t)g->nsets * g->b1 * g->rep1 * g->cap1 * 8 * g->W : 0,
+                                  pool[1] ? (uint64_t)g->l2_regions * g->subs_per_bin * g->cap2 * 8 * g->W : 0};
+  uint64_t pool_off[2] = {0, 0};
   std::vector<void *> owned;
   auto salloc = [&](void **p, size_t bytes) -> hipError_t {
     const uint64_t need = ((uint64_t)bytes + 255) & ~255ull;
-    if (pool && pool_off + need <= pool_bytes) { *p = pool + pool_off; pool_off += need; return hipSuccess; }
+    for (int i = 0; i < 2; i++)
+      if (pool[i] && pool_off[i] + need <= pool_bytes[i]) { *p = pool[i] + pool_off[i]; pool_off[i] += need; return hipSuccess; }
     const hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess) owned.push_back(*p);
     return e;
@@ -2739,7 +2745,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   auto free_range = [&]() {
     for (void *q : owned) (void)hipFree(q);
     owned.clear();
-    pool_off = 0;
+    pool_off[0] = pool_off[1] = 0;
     d_k0 = d_k1 = d_slot = d_idx = d_idx2 = d_ks = d_ks2 = nullptr; d_tmp = nullptr;
   };
   // The chunk buffers: the host entry's staging pairs when the graph has them (pinned host + device memory that sits
