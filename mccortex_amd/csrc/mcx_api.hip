@@ -2738,8 +2738,11 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
     const uint64_t need = ((uint64_t)bytes + 255) & ~255ull;
     for (int i = 0; i < 2; i++)
       if (pool[i] && pool_off[i] + need <= pool_bytes[i]) { *p = pool[i] + pool_off[i]; pool_off[i] += need; return hipSuccess; }
+    const double t0 = now_s();
     const hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess) owned.push_back(*p);
+    if (getenv("MCX_TIMING")) fprintf(stderr, "[timing]   export: %.2f GB of scratch found no room in the idle bins (%.1f + %.1f GB): hipMalloc %.1f ms\n", bytes / 1e9,
+                                      pool_bytes[0] / 1e9, pool_bytes[1] / 1e9, (now_s() - t0) * 1e3);
     return e;
   };
   auto free_range = [&]() {
@@ -2816,15 +2819,17 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
     export_clock("compacted");
     // permutation of the compacted entries: by key (sorted) or by slot (table order)
     size_t tmp_bytes = 0;
+    const uint64_t *first_key = sorted ? (W == 2 ? d_k1 : d_k0) : d_slot;
+    // (the sort's own temporary first: it is the largest block -- two more arrays of m words -- and the bump allocator
+    // fills the first pool in order; the smaller arrays find room in what is left or in the second pool)
+    EXP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, first_key, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, m, 0, 64, st));
+    EXP_TRY(salloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
     EXP_TRY(salloc((void **)&d_idx, m * 8));
     EXP_TRY(salloc((void **)&d_idx2, m * 8));
     EXP_TRY(salloc((void **)&d_ks, m * 8));
     if (sorted && W == 2) EXP_TRY(salloc((void **)&d_ks2, m * 8));
     const unsigned gb = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, m);
-    const uint64_t *first_key = sorted ? (W == 2 ? d_k1 : d_k0) : d_slot;
-    EXP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, first_key, d_ks, d_idx, d_idx2, m, 0, 64, st));
-    EXP_TRY(salloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
     EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, first_key, d_ks, d_idx, d_idx2, m, 0, 64, st));
     uint64_t *perm = d_idx2;
     if (sorted && W == 2) {  // LSD: stable second pass on the most significant word
