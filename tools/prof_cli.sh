@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 kernel + copy statistics of the whole CLI build on a 40 M-read FASTQ (round 5: where does the device's time go in the host-fed path?)
+# The whole CLI build on a synthetic FASTQ: four timed runs in a row (MCX_TIMING=1), or with PROF=1 one run under rocprofv3
+# (kernel, copy and HIP-API statistics + the device busy time over the build: profiles/r05i_cli_*).  Round 5.
 cd "$(dirname "$0")/.."
 T=${TMPDIR:-/tmp}/prof_cli; mkdir -p $T gpurun_out/prof_cli
 (cd $T && python /root/repo/tools/exp_parse_gen.py ${1:-40000000})
@@ -7,7 +8,12 @@ export MCX_TIMING=1
 mccortex_amd/bin/mccortex31 build -f -k 31 -n 1G -m 30G -t 32 --sort -s x --seq $T/reads.fq $T/out.ctx 2>&1 | grep "timing" | grep -v "export\|epoch" | tr '\n' ' '; echo
 rm -f $T/out.ctx; sleep 2
 cd /tmp && export TMPDIR=/tmp
-for i in 1 2 3; do rm -f $T/out.ctx; sleep 2; /root/repo/mccortex_amd/bin/mccortex31 build -f -k 31 -n 1G -m 30G -t 32 --sort -s x --seq $T/reads.fq $T/out.ctx 2>&1 | grep "timing" | grep -v "export  \|arguments\|insert paths\|add_reads" | tr "\n" " " | sed "s/\[timing\]//g"; echo; done
+if [ "${PROF:-0}" = "1" ]; then
+  # (MCX_KEEP_DESTROY=1: the command leaves through _exit() otherwise and rocprofv3 never gets to write its tables)
+  MCX_KEEP_DESTROY=1 rocprofv3 --kernel-trace --memory-copy-trace --hip-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_cli -o cli -- /root/repo/mccortex_amd/bin/mccortex31 build -f -k 31 -n 1G -m 30G -t 32 --sort -s x --seq $T/reads.fq $T/out.ctx > $T/rp.log 2>&1; grep -v "^\[2\|timing\]   export" $T/rp.log | tail -20 | cut -c1-300
+else
+  for i in 1 2 3; do rm -f $T/out.ctx; sleep 2; /root/repo/mccortex_amd/bin/mccortex31 build -f -k 31 -n 1G -m 30G -t 32 --sort -s x --seq $T/reads.fq $T/out.ctx 2>&1 | grep "timing" | grep -v "export  \|arguments\|insert paths\|add_reads" | tr "\n" " " | sed "s/\[timing\]//g"; echo; done
+fi
 cd /root/repo
 find gpurun_out/prof_cli -name "*stats*" | head
 for f in $(find gpurun_out/prof_cli -name "*kernel_stats.csv" -o -name "*memory_copy_stats.csv"); do echo "== $f"; head -14 $f | cut -c1-220; done
