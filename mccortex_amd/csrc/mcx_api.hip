@@ -165,6 +165,7 @@ struct mcx_graph {
   uint64_t touch_bytes = 0;  // TableView::touch
   Counters *d_ctr = nullptr;
   Counters *h_ctr = nullptr;  // pinned
+  uint32_t *h_full = nullptr;  // pinned: the table's "full" flag (TableView::touch[-2]) as of a recent chunk of the host entry
   // host staging (double buffered)
   // (three staging pairs since round 4: with two, the host waited 20 ms per 6 G occurrences for the device to release one)
   static constexpr int kStageBufs = 3;
@@ -418,6 +419,8 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   }
   CREATE_TRY(hipMalloc((void **)&g->d_ctr, sizeof(Counters)));
   CREATE_TRY(hipHostMalloc((void **)&g->h_ctr, sizeof(Counters), hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc((void **)&g->h_full, sizeof(uint32_t), hipHostMallocDefault));
+  *g->h_full = 0;
   g->touch_bytes = (1 + ((g->t.nmain >> sub_shift_for_words(g->W)) + 31) / 32) * 4;
   {  // (kTouchHdr bytes of slow-path counters in front of the flags: TableView::touch)
     uint8_t *tb = nullptr;
@@ -459,6 +462,7 @@ extern "C" void mcx_graph_destroy(mcx_graph *g)
   if (g->d_ctr) (void)hipFree(g->d_ctr);
   if (g->d_readstrt) (void)hipFree(g->d_readstrt);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
+  if (g->h_full) (void)hipHostFree(g->h_full);
   if (g->h_snap) {
     (void)hipHostFree(g->h_snap);
     for (uint32_t i = 0; i < mcx_graph::kSnap; i++) (void)hipEventDestroy(g->snap[i].ev);
@@ -480,6 +484,7 @@ extern "C" int mcx_graph_reset(mcx_graph *g)
   HIP_TRY(hipMemsetAsync(touch_base(g), 0, kTouchHdr + g->touch_bytes, g->stream));
   HIP_TRY(hipMemsetAsync(g->d_ctr, 0, sizeof(Counters), g->stream));
   g->n_flushes = 0;
+  if (g->h_full) { HIP_TRY(hipStreamSynchronize(g->stream)); *g->h_full = 0; }
   if (g->l1_cnt) HIP_TRY(hipMemsetAsync(g->l1_cnt, 0, (size_t)g->nsets * g->b1 * g->rep1 * 8, g->stream));
   if (g->l2_cnt) HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, (size_t)g->l2_regions * g->subs_per_bin * 8, g->stream));
   if (g->d_readstrt) HIP_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
@@ -2082,6 +2087,13 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
                          reinterpret_cast<const uint16_t *>(ds + inv_at), (const uint64_t *)(ds + off_region), J.nwhole, g->k, d_flags + J.r0);
       HIP_TRY(hipGetLastError());
     }
+    // "Hash table is full" while reads are still coming in: the flag of the device (raised by the first insert that finds
+    // neither its sub-table nor the overflow area free) follows every chunk to pinned memory; a later chunk that finds it
+    // set ends the call -- the reference dies at that insert (hash_table.c:119-123), this build within a few chunks of it.
+    if (g->h_full && g->t.touch) {
+      if (*g->h_full) return fail(MCX_ERR_FULL, "Hash table is full");
+      HIP_TRY(hipMemcpyAsync(g->h_full, g->t.touch - 2, sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+    }
     HIP_TRY(hipEventRecord(g->ev[b], g->stream));
     g_stage_timing.chunks++;
     return MCX_OK;
@@ -2149,7 +2161,7 @@ extern "C" int mcx_graph_add_reads(mcx_graph *g, int colour, const uint8_t *base
   const bool packed = stage_packed();
   if (packed) {
     rc = add_reads_packed(g, colour, bases, off, nreads, d_flags);
-    if (rc != MCX_OK) return rc;
+    if (rc != MCX_OK) { (void)hipFreeAsync(d_flags, g->stream); return rc; }  // (stream-ordered: behind the kernels that write the flags)
     hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, g->stream, (const unsigned char *)d_flags, nreads, g->d_ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipFreeAsync(d_flags, g->stream));
