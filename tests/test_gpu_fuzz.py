@@ -108,7 +108,7 @@ def test_superkmer_records_on_arbitrary_bytes(mcx, orc, seed):
             assert shard.merge_sorted_bodies(bodies, 8 * W + 5, 8 * W) == want, (n, k, nparts)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MCX_FUZZ_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MCX_FUZZ_SEED0", "0")), int(os.environ.get("MCX_FUZZ_SEED0", "0")) + int(os.environ.get("MCX_FUZZ_SEEDS", "6"))))
 def test_random_colours_devices_and_batches(mcx, orc, seed, monkeypatch):
     """Random k, colours, device count, exchange format, pool of L1 bin sets, flush size and batch cuts;
     samples in random order (colour switches at every batch); arbitrary bytes in some reads.  The graph
