@@ -25,7 +25,7 @@
 //      xGMI, a direct copy per pair (every pair of GPUs of a node is one hop)      [copy stream i]
 //   3. shard j splits what it received by sub-table (k_tuples_bin); its LDS insert applies it at
 //      the next flush                                                                   [stream j]
-// Send and receive sets are double buffered and the three steps are ordered with HIP events only,
+// Send and receive sets exist kSets (3) times and the three steps are ordered with HIP events only,
 // so the sender kernel of piece n + 1 overlaps with the copies of piece n and the owners' split of
 // piece n - 1.  Nothing here reads a table, so nothing flushes one.  The same device may be named
 // more than once (-D 0,0): the peer copy then is a device-local copy, which is how the path is
@@ -51,6 +51,12 @@ struct XBuf {  // one block set: packed tuples by (owner, region) + per-owner ov
 
 }  // namespace
 
+// Send / receive sets per (sender, owner): the sender kernel of piece n + 1 overlaps the copies of piece n and the owners'
+// kernels of piece n - 1, and the host may run one piece further ahead -- it reads a set's spill count (pinned memory,
+// written behind the sender kernel) when it REUSES the set, i.e. it waits for the sender kernel of kSets pieces ago.  With
+// two sets that capped the run-ahead at two pieces (round 4's advisor); three since round 5.
+constexpr int kSets = 3;
+
 struct mcx_group {
   int n = 0;
   std::vector<mcx_graph *> part;
@@ -61,17 +67,17 @@ struct mcx_group {
   uint32_t sk_segs = 0; // v3: replica segments per owner
   uint64_t sk_cap = 0;  // v3: records per segment
   uint64_t sp_cap = 0;  // spill area of a send set: every occurrence of a piece fits, so no input can overflow
-  std::vector<std::array<unsigned long long *, 2>> h_spill;  // [i][b] pinned: spill fill of the set's last piece
-  std::vector<std::array<int, 2>> spill_colour;               // colour of that piece
+  std::vector<std::array<unsigned long long *, kSets>> h_spill;  // [i][b] pinned: spill fill of the set's last piece
+  std::vector<std::array<int, kSets>> spill_colour;               // colour of that piece
   // send[i][b]: blocks for all owners on shard i's device; recv[j][i][b]: shard i's block on shard j's device
-  std::vector<std::array<XBuf, 2>> send;
-  std::vector<std::vector<std::array<XBuf, 2>>> recv;
+  std::vector<std::array<XBuf, kSets>> send;
+  std::vector<std::vector<std::array<XBuf, kSets>>> recv;
   std::vector<hipStream_t> cs;                                     // copy stream of sender i (its device)
-  std::vector<std::array<hipEvent_t, 2>> filled, sent;             // [i][b]
-  std::vector<std::vector<std::array<hipEvent_t, 2>>> arrived;     // [j][i][b], recorded on cs[i]
-  std::vector<std::vector<std::array<hipEvent_t, 2>>> consumed;    // [j][i][b], recorded on shard j's stream
+  std::vector<std::array<hipEvent_t, kSets>> filled, sent;             // [i][b]
+  std::vector<std::vector<std::array<hipEvent_t, kSets>>> arrived;     // [j][i][b], recorded on cs[i]
+  std::vector<std::vector<std::array<hipEvent_t, kSets>>> consumed;    // [j][i][b], recorded on shard j's stream
   std::vector<int> cur;
-  std::vector<std::array<bool, 2>> used;
+  std::vector<std::array<bool, kSets>> used;
   bool buffers = false;
   uint64_t spilled = 0;  // occurrences (v2) / records (v3) that went through a sender's spill area (mcx_graph_insert_stats)
   bool peer_ok = true;  // every pair of distinct devices can map each other's memory (kernels may write to a peer)
@@ -89,7 +95,7 @@ static void group_free_buffers(mcx_group *G)
 {
   for (int i = 0; i < G->n; i++) {
     (void)hipSetDevice(G->part[i]->device);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < kSets; b++) {
       if ((size_t)i < G->send.size()) {
         XBuf &x = G->send[i][b];
         (void)hipFree(x.keys); (void)hipFree(x.counts); (void)hipFree(x.ov_keys); (void)hipFree(x.ov_edges); (void)hipFree(x.ov_counts);
@@ -130,13 +136,13 @@ static int group_ensure_buffers(mcx_group *G)
     G->sp_cap = G->max_pos + 16;
     if (const char *e = getenv("MCX_MULTI_SKCAP")) G->sk_cap = std::max<uint64_t>(16, strtoull(e, nullptr, 10));  // tests: force the spill path
     G->send.resize(N);
-    G->recv.assign(N, std::vector<std::array<XBuf, 2>>(N));
-    G->h_spill.assign(N, {nullptr, nullptr});
-    G->spill_colour.assign(N, {0, 0});
+    G->recv.assign(N, std::vector<std::array<XBuf, kSets>>(N));
+    G->h_spill.assign(N, {});
+    G->spill_colour.assign(N, {});
     const uint64_t blk_recs = (uint64_t)G->sk_segs * G->sk_cap;
     for (int i = 0; i < N; i++) {
       GRP_TRY(hipSetDevice(G->part[i]->device));
-      for (int b = 0; b < 2; b++) {
+      for (int b = 0; b < kSets; b++) {
         XBuf &s = G->send[i][b];
         GRP_TRY(hipMalloc((void **)&s.recs, (uint64_t)N * blk_recs * recb));
         GRP_TRY(hipMalloc((void **)&s.fills_rm, (uint64_t)N * G->sk_segs * 8));
@@ -170,13 +176,13 @@ static int group_ensure_buffers(mcx_group *G)
     return fail(MCX_ERR_ARG, "internal: exchange segment stride is not a multiple of 16 bytes (seg_cap %llu, ov_cap %llu)",
                 (unsigned long long)G->seg_cap, (unsigned long long)G->ov_cap);
   G->send.resize(N);
-  G->h_spill.assign(N, {nullptr, nullptr});
-  G->spill_colour.assign(N, {0, 0});
-  G->recv.assign(N, std::vector<std::array<XBuf, 2>>(N));
+  G->h_spill.assign(N, {});
+  G->spill_colour.assign(N, {});
+  G->recv.assign(N, std::vector<std::array<XBuf, kSets>>(N));
   const uint64_t blk = (uint64_t)G->segs * G->seg_cap;  // tuples of one owner's block
   for (int i = 0; i < N; i++) {
     GRP_TRY(hipSetDevice(G->part[i]->device));
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < kSets; b++) {
       XBuf &s = G->send[i][b];
       GRP_TRY(hipMalloc((void **)&s.keys, (uint64_t)N * blk * 8 * W));
       GRP_TRY(hipMalloc((void **)&s.counts, (uint64_t)N * G->segs * 8));
@@ -291,7 +297,7 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
     for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
       const uint64_t hi = std::min(L.pos_hi, lo + G->max_pos);
       const int b = G->cur[idx];
-      G->cur[idx] ^= 1;
+      G->cur[idx] = (G->cur[idx] + 1) % kSets;
       XBuf &s = G->send[idx][b];
       rc = group_route_spill(G, idx, b);  // what this set's previous piece spilled (nearly always nothing)
       if (rc != MCX_OK) return rc;
@@ -358,7 +364,7 @@ static int group_submit_stream(mcx_group *G, int idx, const StreamLaunch &L, int
   for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
     const uint64_t hi = std::min(L.pos_hi, lo + G->max_pos);
     const int b = G->cur[idx];
-    G->cur[idx] ^= 1;
+    G->cur[idx] = (G->cur[idx] + 1) % kSets;
     XBuf &s = G->send[idx][b];
     rc = group_route_spill(G, idx, b);  // what this set's previous piece spilled (nearly always nothing)
     if (rc != MCX_OK) return rc;
@@ -445,13 +451,13 @@ static void group_destroy(mcx_group *G)
     if (!G->part[i]) continue;
     (void)hipSetDevice(G->part[i]->device);
     if ((size_t)i < G->cs.size() && G->cs[i]) (void)hipStreamDestroy(G->cs[i]);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < kSets; b++) {
       if ((size_t)i < G->filled.size() && G->filled[i][b]) (void)hipEventDestroy(G->filled[i][b]);
       if ((size_t)i < G->sent.size() && G->sent[i][b]) (void)hipEventDestroy(G->sent[i][b]);
     }
   }
-  for (auto &row : G->arrived) for (auto &e : row) for (int b = 0; b < 2; b++) if (e[b]) (void)hipEventDestroy(e[b]);
-  for (auto &row : G->consumed) for (auto &e : row) for (int b = 0; b < 2; b++) if (e[b]) (void)hipEventDestroy(e[b]);
+  for (auto &row : G->arrived) for (auto &e : row) for (int b = 0; b < kSets; b++) if (e[b]) (void)hipEventDestroy(e[b]);
+  for (auto &row : G->consumed) for (auto &e : row) for (int b = 0; b < kSets; b++) if (e[b]) (void)hipEventDestroy(e[b]);
   for (int j = 0; j < G->n; j++) {
     if (!G->part[j]) continue;
     G->part[j]->group = nullptr;
@@ -493,12 +499,12 @@ extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols,
     if (G->v3) G->part[i]->own_lbo = lbo;
   }
   G->cs.assign(ndevices, nullptr);
-  G->filled.assign(ndevices, {nullptr, nullptr});
-  G->sent.assign(ndevices, {nullptr, nullptr});
-  G->arrived.assign(ndevices, std::vector<std::array<hipEvent_t, 2>>(ndevices, {nullptr, nullptr}));
-  G->consumed.assign(ndevices, std::vector<std::array<hipEvent_t, 2>>(ndevices, {nullptr, nullptr}));
+  G->filled.assign(ndevices, {});
+  G->sent.assign(ndevices, {});
+  G->arrived.assign(ndevices, std::vector<std::array<hipEvent_t, kSets>>(ndevices, std::array<hipEvent_t, kSets>{}));
+  G->consumed.assign(ndevices, std::vector<std::array<hipEvent_t, kSets>>(ndevices, std::array<hipEvent_t, kSets>{}));
   G->cur.assign(ndevices, 0);
-  G->used.assign(ndevices, {false, false});
+  G->used.assign(ndevices, {});
 #define MK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc_ = fail(MCX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); group_destroy(G); return rc_; } } while (0)
   for (int i = 0; i < ndevices; i++) {
     MK_TRY(hipSetDevice(devices[i]));
@@ -513,7 +519,7 @@ extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols,
         }
       }
     MK_TRY(hipStreamCreateWithFlags(&G->cs[i], hipStreamNonBlocking));
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < kSets; b++) {
       MK_TRY(hipEventCreateWithFlags(&G->filled[i][b], hipEventDisableTiming));
       MK_TRY(hipEventCreateWithFlags(&G->sent[i][b], hipEventDisableTiming));
       for (int j = 0; j < ndevices; j++) MK_TRY(hipEventCreateWithFlags(&G->arrived[j][i][b], hipEventDisableTiming));
@@ -522,7 +528,7 @@ extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols,
   for (int j = 0; j < ndevices; j++) {
     MK_TRY(hipSetDevice(devices[j]));
     for (int i = 0; i < ndevices; i++)
-      for (int b = 0; b < 2; b++) MK_TRY(hipEventCreateWithFlags(&G->consumed[j][i][b], hipEventDisableTiming));
+      for (int b = 0; b < kSets; b++) MK_TRY(hipEventCreateWithFlags(&G->consumed[j][i][b], hipEventDisableTiming));
   }
 #undef MK_TRY
   mcx_graph *f = new mcx_graph();  // the facade: no device state of its own
@@ -541,7 +547,7 @@ static int grp_drain(mcx_group *G)
 {
   if (G->buffers)
     for (int i = 0; i < G->n; i++)
-      for (int b = 0; b < 2; b++) {
+      for (int b = 0; b < kSets; b++) {
         int rc = group_route_spill(G, i, b);
         if (rc != MCX_OK) return rc;
       }
