@@ -15,7 +15,7 @@ steps = [bench.make_batch(genome, B, 1000 + i, dev) for i in range(N)]
 del genome; torch.cuda.empty_cache()
 ns = int(os.environ.get("SHARDS", "8"))
 g = mcx.Graph(31, 1, 1 << 30, devices=[0] * ns)
-g.configure("defer_tuples", int(os.environ.get("DEFER", "3000000000")))
+g.configure("defer_tuples", int(os.environ.get("DEFER", str(8_000_000_000 // max(ns, 2)))))   # (all shards share the ONE device's HBM here)
 g.add_stream_dev(0, steps[0][:1024 * 151], 1024 * 151); g.sync(); g.reset(); g.sync()
 res = []
 for rep in range(2):
