@@ -166,6 +166,9 @@ void orc_kmer_to_str(orc_bkmer x, int k, char *out)
 }
 
 /* hash_mem.c:5-15 */
+int orc_rehash_limit(void) { return ORC_REHASH_LIMIT; }
+int orc_max_bucket_size(void) { return ORC_MAX_BUCKET; }
+
 uint64_t orc_hash_table_cap(uint64_t nkmers, uint64_t *nbuckets, uint8_t *bucket_size)
 {
   uint64_t nbits = 10;

@@ -40,6 +40,8 @@ orc_bkmer orc_kmer_revcomp(orc_bkmer x, int k);                    /* binary_kme
 orc_bkmer orc_kmer_get_key(orc_bkmer x, int k);                    /* binary_kmer.c:43-57 */
 uint32_t  orc_kmer_hash(orc_bkmer key, int k, uint32_t initval);   /* kmer_hash.h:162-211 */
 void      orc_kmer_to_str(orc_bkmer x, int k, char *out);          /* binary_kmer.c:190-.. */
+int       orc_rehash_limit(void);     /* REHASH_LIMIT, src/basic/hash_mem.h:4 */
+int       orc_max_bucket_size(void);  /* MAX_BUCKET_SIZE, src/basic/hash_mem.h:8 */
 uint64_t  orc_hash_table_cap(uint64_t nkmers, uint64_t *nbuckets, uint8_t *bucket_size); /* hash_mem.c:5-15 */
 
 /* contig splitting (row G): seq_reader.c:61-117 and :127-172 */

@@ -120,6 +120,25 @@ def ref_lookup3():
     return _REF
 
 
+_HASHMEM = None
+
+
+def ref_hashmem():
+    """The reference's self-contained src/basic/hash_mem.h (constants + ht_mem) compiled into oracle/_ref (or None)."""
+    global _HASHMEM
+    if _HASHMEM is None:
+        so = os.path.join(_HERE, "_ref", "libhashmemref.so")
+        if not os.path.exists(so):
+            return None
+        R = C.CDLL(so)
+        R.ref_ht_mem.restype = C.c_size_t
+        R.ref_ht_mem.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t]
+        R.ref_ideal_occupancy.restype = C.c_float
+        R.ref_warn_occupancy.restype = C.c_float
+        _HASHMEM = R
+    return _HASHMEM
+
+
 _REVCMP = {}
 
 

@@ -51,6 +51,31 @@ def test_capacity_kats_of_the_reference(host, orc):
         assert (nb.value, bs.value) == (nbuckets, bucket)
 
 
+def test_constants_and_memory_formula_of_the_reference_header(host, orc):
+    """src/basic/hash_mem.h compiled unmodified into oracle/_ref: REHASH_LIMIT and MAX_BUCKET_SIZE against the oracle's,
+    ht_mem() against the bytes the product's sizing reports, the occupancy thresholds `build` warns at
+    (cmd_mem.c:66, ctx_build.c) against the literals the host program uses."""
+    R = orc.ref_hashmem()
+    if R is None:
+        pytest.skip("oracle/_ref/libhashmemref.so not built (needs /root/reference at build time)")
+    L = orc.lib()
+    assert (R.ref_rehash_limit(), R.ref_max_bucket_size()) == (L.orc_rehash_limit(), L.orc_max_bucket_size()) == (20, 48)
+    assert (R.ref_ideal_occupancy(), R.ref_warn_occupancy()) == (0.75, C.c_float(0.9).value)
+    src = open(os.path.join(ROOT, "mccortex_amd", "host", "cmd_build.c")).read()
+    assert "#define IDEAL_OCCUPANCY 0.75f" in src and "#define WARN_OCCUPANCY 0.9f" in src
+    import random
+    rnd = random.Random(3)
+    for bits in (104, 168, 288):
+        for _ in range(200):
+            nk = rnd.randrange(1, 1 << rnd.randrange(4, 40))
+            p = host.table_plan_for_kmers(nk, bits)
+            assert 1 <= p.bucket_size <= R.ref_max_bucket_size() + 1   # (hash_mem.c:9-11: floor(n / buckets) <= 48, the bucket takes the ceiling)
+            assert p.bytes == R.ref_ht_mem(p.bucket_size, p.nbuckets, bits)
+        for mem in (1 << 20, 512 << 20, 70 << 30):
+            p = host.table_plan_for_memory(mem, bits)
+            assert p.bytes == R.ref_ht_mem(p.bucket_size, p.nbuckets, bits) <= mem
+
+
 def test_memory_limit_fills_but_never_exceeds(host):
     for bits in (104, 64 + 40 + 64, 128 + 40 * 4):        # k=31 1 colour; --sort; k=63 4 colours
         for mem in (1 << 20, 512 << 20, 3 * (1 << 30) + 12345, 70 * (1 << 30)):
