@@ -1,11 +1,14 @@
 /* ctx_file.c -- .ctx header writer and reader, colour filters and the per-colour GraphInfo
  * arithmetic (docs/file_formats/graph_file_format.txt; src/graph/graph_writer.c:11-110,
  * src/graph/graph_file_reader.c:78-340, src/basic/file_filter.c, src/basic/range.c,
- * src/basic/graph_info.c).  x86-64 only: the header stores `long double seq_err` as its 16
+ * src/basic/graph_info.c).  The reader is written from the format document: a table of header
+ * fields and one scanner for colour lists; the reference's checks and messages are kept.
+ * x86-64 only: the header stores `long double seq_err` as its 16
  * in-memory bytes (10-byte x87 value + padding). */
 #include "host.h"
 
 #include <errno.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -146,220 +149,226 @@ size_t ctx_write_header(FILE *fh, uint32_t kmer_size, uint32_t ncols, const col_
   return n;
 }
 
-/* ---- colour ranges (src/basic/range.c) ---- */
-static int range_parse(const char *str, size_t *start, size_t *end, size_t range_max)
+/* ---- colour lists: "3", "0-2", "4-1" (descending), "0,2-3,7"; the syntax of the CLI's
+ * "<into>:in.ctx:<from>" graph arguments (semantics of src/basic/range.c) ----
+ * One scanner over a (pointer, length) slice serves both the sizing pass (out == NULL) and the
+ * filling pass.  An empty slice stands for "every colour 0..max". */
+#define COL_LIST_CHARS "0123456789,-"
+
+typedef struct { const char *s; size_t n; } slice;
+
+static long long col_list_expand(slice txt, uint64_t max, uint32_t *out)
 {
-  char *endp;
-  if (*str == '*') { *start = 0; *end = range_max; return 1; }
-  unsigned long from = strtoul(str, &endp, 10), to = from;
-  if (endp == str) return -1;
-  if (*endp == '-') {
-    const char *s2 = endp + 1;
-    to = strtoul(s2, &endp, 10);
-    if (endp == s2) return -1;
+  if (txt.n == 0) { /* nothing named: all of them */
+    if (out) for (uint64_t c = 0; c <= max; c++) out[c] = (uint32_t)c;
+    return (long long)(max + 1);
   }
-  if (from > range_max || to > range_max) return -1;
-  *start = from; *end = to;
-  return (int)(endp - str);
-}
-
-static int range_get_num(const char *str, size_t range_max)
-{
-  size_t start, end, num = 0;
-  int bytes;
-  for (const char *p = str; *p;) {
-    if ((bytes = range_parse(p, &start, &end, range_max)) == -1) return -1;
-    p += bytes;
-    num += (start > end ? start - end : end - start) + 1;
-    if (*p == ',') p++;
+  long long count = 0;
+  uint64_t num[2] = {0, 0};  /* the item being read: num[0], or num[0]-num[1] */
+  int which = 0, digits = 0; /* which number of the item, digits seen in it */
+  for (size_t i = 0; i <= txt.n; i++) {
+    const char ch = i < txt.n ? txt.s[i] : ','; /* the end of the text closes the last item */
+    if (ch >= '0' && ch <= '9') {
+      num[which] = num[which] * 10 + (uint64_t)(ch - '0');
+      if (num[which] > max) return -1;
+      digits++;
+    } else if (ch == '-') {
+      if (which == 1 || digits == 0) return -1;
+      which = 1; digits = 0;
+    } else if (ch == ',') {
+      if (digits == 0) return -1; /* empty item, ",," or a comma at either end */
+      const uint64_t first = num[0], last = which ? num[1] : num[0];
+      const uint64_t span = (first <= last ? last - first : first - last) + 1;
+      if (out)
+        for (uint64_t j = 0; j < span; j++) out[count + (long long)j] = (uint32_t)(first <= last ? first + j : first - j);
+      count += (long long)span;
+      num[0] = num[1] = 0; which = 0; digits = 0;
+    } else return -1;
   }
-  return num == 0 ? (int)(range_max + 1) : (int)num;
+  return count;
 }
 
-static int range_parse_array(const char *str, size_t *arr, size_t range_max)
+/* ---- graph argument "<into>:path:<from>" (semantics of src/basic/file_filter.c:7-143) ----
+ * <into> is a leading colour list closed by ':', <from> a trailing one opened by ':'; the path
+ * between them keeps at least one character. */
+typedef struct { slice into, path, from; bool has_into, has_from; } graph_arg;
+
+static graph_arg graph_arg_split(const char *arg)
 {
-  size_t num = 0, start, end;
-  int bytes;
-  const char *p = str;
-  while (*p) {
-    if ((bytes = range_parse(p, &start, &end, range_max)) == -1) return -1;
-    p += bytes;
-    if (*p == ',') p++;
-    if (start <= end) for (size_t j = start; j <= end; j++) arr[num++] = j;
-    /* descending range a-b = a, a-1, .. b.  (The reference's loop, range.c:71-72, has no lower
-     * bound: it runs on to 0 and past the array range_get_num() sized.) */
-    else for (size_t j = start; j <= start; j--) { arr[num++] = j; if (j == end) break; }
+  graph_arg ga;
+  memset(&ga, 0, sizeof(ga));
+  const size_t len = strlen(arg);
+  size_t lo = 0, hi = len;
+  const size_t lead = strspn(arg, COL_LIST_CHARS);
+  if (lead > 0 && arg[lead] == ':') {
+    ga.has_into = true; ga.into = (slice){arg, lead};
+    lo = lead + 1;
   }
-  if (p > str && *(p - 1) == ',') return -1;
-  if (num == 0) for (num = 0; num <= range_max; num++) arr[num] = num;
-  return (int)num;
-}
-
-static int range_parse_array_fill(const char *str, size_t *arr, size_t range_max, size_t num_entries)
-{
-  const int r = range_parse_array(str, arr, range_max);
-  if (r < 0) return -1;
-  if (r == 0) for (size_t i = 0; i < num_entries; i++) arr[i] = i;
-  else if (r == 1) for (size_t i = 1; i < num_entries; i++) arr[i] = arr[0];
-  else if ((size_t)r != num_entries) return -1;
-  return (int)num_entries;
-}
-
-/* ---- colour filter "<into>:path:<from>" (src/basic/file_filter.c:7-143) ---- */
-static int is_range_char(char c) { return (c >= '0' && c <= '9') || c == '-' || c == ','; }
-
-static void deconstruct_path(const char *path, const char **start, const char **end)
-{
-  const char *p = path;
-  *start = path;
-  while (is_range_char(*p)) p++;
-  if (p > path && *p == ':') { p++; *start = p; }
-  p = *end = path + strlen(path);
-  while (p > (*start) + 1) {
-    p--;
-    if (*p == ':') { *end = p; break; }
-    else if (!is_range_char(*p)) break;
+  size_t t = len;
+  while (t > lo + 1 && memchr(COL_LIST_CHARS, arg[t - 1], sizeof(COL_LIST_CHARS) - 1)) t--;
+  if (t > lo + 1 && arg[t - 1] == ':') {
+    ga.has_from = true; ga.from = (slice){arg + t, len - t};
+    hi = t - 1;
   }
+  ga.path = (slice){arg + lo, hi - lo};
+  return ga;
 }
 
-static int cmp_into(const void *a, const void *b)
+static int filter_order(const void *a, const void *b)
 {
   const col_filter *x = a, *y = b;
-  if (x->into != y->into) return x->into < y->into ? -1 : 1;
-  return x->from < y->from ? -1 : (x->from > y->from);
+  const uint64_t kx = (uint64_t)x->into << 32 | x->from, ky = (uint64_t)y->into << 32 | y->from;
+  return (kx > ky) - (kx < ky);
 }
 
-/* file_filter_set_cols */
-static void filter_set_cols(ctx_reader *r, size_t srcncols, size_t into_offset)
+/* Colours of the file (`from`) and where they go in the graph (`into`).  Without <from>: every colour
+ * of the file; without <into>: into_offset, into_offset + 1, ...; one <into> colour takes them all. */
+static void reader_set_filter(ctx_reader *r, size_t into_offset)
 {
-  const char *ps, *pe;
-  deconstruct_path(r->input, &ps, &pe);
-  char *path_start = r->input + (ps - r->input), *path_end = r->input + (pe - r->input);
-  char *from_fltr = (*path_end == ':' ? path_end + 1 : NULL);
-  char *into_fltr = (path_start > r->input ? r->input : NULL);
-  size_t ncols;
-  if (from_fltr) {
-    int s = range_get_num(from_fltr, srcncols - 1);
-    if (s < 0) die("Invalid filter path: %s (from size: %zu)", r->input, srcncols);
-    ncols = (size_t)s;
-  } else ncols = srcncols;
-  if (into_fltr) {
-    *(path_start - 1) = '\0';
-    int s = range_get_num(into_fltr, SIZE_MAX - 1);
-    *(path_start - 1) = ':';
-    if (s < 0 || (s != 1 && (size_t)s != ncols)) die("Invalid filter path: %s (s:%i ncols:%zu)", r->input, s, ncols);
-  }
-  r->filter = calloc(ncols ? ncols : 1, sizeof(col_filter));
-  r->nfilter = ncols;
-  /* a range may name up to range_max+1 entries; ranges are bounded by the checks above */
-  size_t *tmp = calloc((ncols > srcncols ? ncols : srcncols) + 1, sizeof(size_t));
-  if (from_fltr) {
-    if (range_parse_array(from_fltr, tmp, srcncols - 1) == -1) die("Invalid filter path: %s", r->input);
-    for (size_t i = 0; i < ncols; i++) r->filter[i].from = (uint32_t)tmp[i];
-  } else for (size_t i = 0; i < ncols; i++) r->filter[i].from = (uint32_t)i;
-  if (into_fltr) {
-    *(path_start - 1) = '\0';
-    int s = range_parse_array_fill(into_fltr, tmp, SIZE_MAX - 1, ncols);
-    *(path_start - 1) = ':';
-    if (s < 0 || (size_t)s != ncols) die("Invalid filter path: %s (s:%i ncols:%zu)", r->input, s, ncols);
-    for (size_t i = 0; i < ncols; i++) r->filter[i].into = (uint32_t)tmp[i];
-  } else for (size_t i = 0; i < ncols; i++) r->filter[i].into = (uint32_t)(into_offset + i);
-  free(tmp);
-  qsort(r->filter, r->nfilter, sizeof(col_filter), cmp_into);
+  const graph_arg ga = graph_arg_split(r->input);
+  const uint64_t file_max = (uint64_t)r->num_cols - 1, into_max = UINT32_MAX - 1;
+
+  long long nfrom = ga.has_from ? col_list_expand(ga.from, file_max, NULL) : (long long)r->num_cols;
+  if (nfrom < 0) die("Invalid filter path: %s (from size: %zu)", r->input, (size_t)r->num_cols);
+  long long ninto = ga.has_into ? col_list_expand(ga.into, into_max, NULL) : nfrom;
+  if (ninto < 0 || (ninto != 1 && ninto != nfrom))
+    die("Invalid filter path: %s (s:%i ncols:%zu)", r->input, (int)ninto, (size_t)nfrom);
+
+  const size_t n = (size_t)nfrom;
+  uint32_t *from = calloc(n + 1, sizeof(uint32_t)), *into = calloc(n + 1, sizeof(uint32_t));
+  r->filter = calloc(n + 1, sizeof(col_filter));
+  if (!from || !into || !r->filter) die("Out of memory");
+  col_list_expand(ga.has_from ? ga.from : (slice){NULL, 0}, file_max, from);
+  if (ga.has_into) {
+    col_list_expand(ga.into, into_max, into);
+    if (ninto == 1) for (size_t i = 1; i < n; i++) into[i] = into[0];
+  } else for (size_t i = 0; i < n; i++) into[i] = (uint32_t)(into_offset + i);
+
+  r->nfilter = n;
   r->into_ncols = 0;
-  for (size_t i = 0; i < r->nfilter; i++)
-    if ((size_t)r->filter[i].into + 1 > r->into_ncols) r->into_ncols = (size_t)r->filter[i].into + 1;
+  for (size_t i = 0; i < n; i++) {
+    r->filter[i] = (col_filter){from[i], into[i]};
+    if ((size_t)into[i] + 1 > r->into_ncols) r->into_ncols = (size_t)into[i] + 1;
+  }
+  qsort(r->filter, n, sizeof(col_filter), filter_order);
+  free(from); free(into);
 }
 
-/* ---- header reader (graph_file_read_header: graph_file_reader.c:78-260) ---- */
-static void gfread(ctx_reader *r, void *ptr, size_t n, const char *entry)
+/* ---- header reader, driven by a description of docs/file_formats/graph_file_format.txt
+ * (checks and messages of graph_file_read_header: graph_file_reader.c:78-260) ---- */
+typedef enum { FT_U8, FT_U32, FT_U64, FT_LDBL, FT_TEXT } field_type;
+typedef struct {
+  const char *what;   /* how a short read names the field */
+  field_type type;
+  size_t offset;      /* in the record the section fills */
+  uint32_t since;     /* first format version that has it */
+} hdr_field;
+
+static const hdr_field hdr_dims[] = { /* into ctx_reader */
+  {"graph version", FT_U32, offsetof(ctx_reader, version), 4},
+  {"kmer size", FT_U32, offsetof(ctx_reader, kmer_size), 4},
+  {"num of bitfields", FT_U32, offsetof(ctx_reader, num_words), 4},
+  {"number of colours", FT_U32, offsetof(ctx_reader, num_cols), 4},
+};
+/* one array of <cols> entries each, in this order; into col_info */
+static const hdr_field hdr_colour_arrays[] = {
+  {"mean read length for each colour", FT_U32, offsetof(col_info, mean_read_length), 4},
+  {"total sequence loaded for each colour", FT_U64, offsetof(col_info, total_sequence), 4},
+  {"sample name", FT_TEXT, offsetof(col_info, name), 6},
+  {"seq error rates", FT_LDBL, offsetof(col_info, seq_err), 6},
+};
+/* one block per colour; into err_cleaning */
+static const hdr_field hdr_cleaning[] = {
+  {"tip cleaning", FT_U8, offsetof(err_cleaning, cleaned_tips), 6},
+  {"remove low covg unitig", FT_U8, offsetof(err_cleaning, cleaned_unitigs), 6},
+  {"remove low covg kmers", FT_U8, offsetof(err_cleaning, cleaned_kmers), 6},
+  {"cleaned against graph", FT_U8, offsetof(err_cleaning, is_graph_intersection), 6},
+  {"remove low covg unitig threshold", FT_U32, offsetof(err_cleaning, clean_unitigs_thresh), 6},
+  {"remove low covg kmer threshold", FT_U32, offsetof(err_cleaning, clean_kmers_thresh), 6},
+  {"cleaned against graph name", FT_TEXT, offsetof(err_cleaning, intersection_name), 6},
+};
+#define NFIELDS(t) (sizeof(t) / sizeof((t)[0]))
+
+static size_t hdr_take(ctx_reader *r, void *dst, size_t n, const char *what)
 {
-  const size_t got = fread(ptr, 1, n, r->fh);
-  if (got != n) die("Unexpected end of file: %s [%s; read %zu of %zu bytes]", r->path, entry, got, n);
+  const size_t got = fread(dst, 1, n, r->fh);
+  if (got != n) die("Unexpected end of file: %s [%s; read %zu of %zu bytes]", r->path, what, got, n);
+  return n;
 }
 
-static char *read_name(ctx_reader *r, const char *what, size_t colour, size_t *bytes_read)
+/* reads one field into record + f->offset; returns the bytes it took from the file */
+static size_t hdr_field_read(ctx_reader *r, const hdr_field *f, void *record, size_t colour)
 {
+  static const size_t width[] = {[FT_U8] = 1, [FT_U32] = 4, [FT_U64] = 8, [FT_LDBL] = 16};
+  char *dst = (char *)record + f->offset;
+  if (f->type != FT_TEXT) return hdr_take(r, dst, width[f->type], f->what);
   uint32_t len;
-  gfread(r, &len, 4, what);
+  size_t n = hdr_take(r, &len, 4, f->what);
   if (len > 10000) die("Very big sample name. Length: %u", len);
-  char *s = calloc((size_t)len + 1, 1);
-  gfread(r, s, len, what);
-  *bytes_read += 4 + len;
-  if (strlen(s) != len)
-    warn("Sample %zu name has length %u but is only %zu chars long (premature '\\0') [path: %s]\n", colour, len, strlen(s), r->path);
-  return s;
+  char *text = calloc((size_t)len + 1, 1);
+  if (!text) die("Out of memory");
+  n += hdr_take(r, text, len, f->what);
+  if (strlen(text) != len)
+    warn("Sample %zu name has length %u but is only %zu chars long (premature '\\0') [path: %s]\n", colour, len, strlen(text), r->path);
+  free(*(char **)dst);
+  *(char **)dst = text;
+  return n;
+}
+
+static size_t hdr_magic(ctx_reader *r, const char *what, bool at_end)
+{
+  char word[7] = {0};
+  hdr_take(r, word, 6, what);
+  if (memcmp(word, "CORTEX", 6) == 0) return 6;
+  if (at_end) die("Magic word doesn't match '%s' (end): '%s' [path: %s]\n", "CORTEX", word, r->path);
+  die("Magic word doesn't match '%s' (start): %s", "CORTEX", r->path);
+}
+
+static void hdr_check_dims(const ctx_reader *r)
+{
+  const uint32_t v = r->version, k = r->kmer_size, w = r->num_words;
+  if (v < 4 || v > 7) die("Sorry, we only support graph file versions 4, 5, 6 & 7 [version: %u; path: %s]\n", v, r->path);
+  if (!(k & 1)) die("kmer size is not an odd number [kmer_size: %u; path: %s]\n", k, r->path);
+  if (k < 3) die("kmer size is less than three [kmer_size: %u; path: %s]\n", k, r->path);
+  /* W*32 >= kmer_size > (W-1)*32 */
+  if ((uint64_t)w * 32 < k) die("Not enough bitfields for kmer size [kmer_size: %u; bitfields: %u; path: %s]\n", k, w, r->path);
+  if (((uint64_t)w - 1) * 32 >= k) die("using more than the minimum number of bitfields [path: %s]\n", r->path);
+  if (r->num_cols == 0) die("number of colours is zero [path: %s]\n", r->path);
+  if (r->num_cols > 10000) die("Very high number of colours: %zu [path: %s]", (size_t)r->num_cols, r->path);
+}
+
+/* "0 if not used": files up to version 6 may hold -1 there, and a threshold without its flag is dropped */
+static void hdr_settle_threshold(const ctx_reader *r, uint8_t used, uint32_t *thresh, const char *of)
+{
+  if (used) return;
+  if (r->version <= 6 && *thresh == UINT32_MAX) *thresh = 0;
+  if (*thresh == 0) return;
+  warn("Graph header gives cleaning threshold for %s when no cleaning was performed [path: %s]", of, r->path);
+  *thresh = 0;
 }
 
 static size_t read_header(ctx_reader *r)
 {
-  size_t bytes = 0;
-  char magic[7] = {0};
-  gfread(r, magic, 6, "Magic word");
-  if (strcmp(magic, "CORTEX") != 0) die("Magic word doesn't match '%s' (start): %s", "CORTEX", r->path);
-  bytes += 6;
-  gfread(r, &r->version, 4, "graph version");
-  gfread(r, &r->kmer_size, 4, "kmer size");
-  gfread(r, &r->num_words, 4, "num of bitfields");
-  gfread(r, &r->num_cols, 4, "number of colours");
-  bytes += 16;
-  if (r->version > 7 || r->version < 4)
-    die("Sorry, we only support graph file versions 4, 5, 6 & 7 [version: %u; path: %s]\n", r->version, r->path);
-  if (r->kmer_size % 2 == 0) die("kmer size is not an odd number [kmer_size: %u; path: %s]\n", r->kmer_size, r->path);
-  if (r->kmer_size < 3) die("kmer size is less than three [kmer_size: %u; path: %s]\n", r->kmer_size, r->path);
-  if (r->num_words * 32 < r->kmer_size)
-    die("Not enough bitfields for kmer size [kmer_size: %u; bitfields: %u; path: %s]\n", r->kmer_size, r->num_words, r->path);
-  if ((r->num_words - 1) * 32 >= r->kmer_size) die("using more than the minimum number of bitfields [path: %s]\n", r->path);
-  if (r->num_cols == 0) die("number of colours is zero [path: %s]\n", r->path);
-  if (r->num_cols > 10000) die("Very high number of colours: %zu [path: %s]", (size_t)r->num_cols, r->path);
+  size_t bytes = hdr_magic(r, "Magic word", false);
+  for (size_t f = 0; f < NFIELDS(hdr_dims); f++) bytes += hdr_field_read(r, &hdr_dims[f], r, 0);
+  hdr_check_dims(r);
 
   r->ginfo = calloc(r->num_cols, sizeof(col_info));
-  for (uint32_t i = 0; i < r->num_cols; i++) col_info_init(&r->ginfo[i]);
-  for (uint32_t i = 0; i < r->num_cols; i++) gfread(r, &r->ginfo[i].mean_read_length, 4, "mean read length for each colour");
-  for (uint32_t i = 0; i < r->num_cols; i++) gfread(r, &r->ginfo[i].total_sequence, 8, "total sequance loaded for each colour");
-  bytes += (size_t)r->num_cols * 12;
-  if (r->version >= 6) {
-    for (uint32_t i = 0; i < r->num_cols; i++) {
-      free(r->ginfo[i].name);
-      r->ginfo[i].name = read_name(r, "sample name", i, &bytes);
-    }
-    for (uint32_t i = 0; i < r->num_cols; i++) {
-      unsigned char b[16];
-      gfread(r, b, 16, "seq error rates");
-      memcpy(&r->ginfo[i].seq_err, b, 16);
-    }
-    bytes += 16 * (size_t)r->num_cols;
-    for (uint32_t i = 0; i < r->num_cols; i++) {
-      err_cleaning *ec = &r->ginfo[i].cleaning;
-      gfread(r, &ec->cleaned_tips, 1, "tip cleaning");
-      gfread(r, &ec->cleaned_unitigs, 1, "remove low covg unitig");
-      gfread(r, &ec->cleaned_kmers, 1, "remove low covg kmers");
-      gfread(r, &ec->is_graph_intersection, 1, "cleaned against graph");
-      uint32_t tu = 0, tk = 0;
-      gfread(r, &tu, 4, "remove low covg unitig threshold");
-      gfread(r, &tk, 4, "remove low covg kmer threshold");
-      bytes += 12;
-      if (r->version <= 6) { /* old versions wrote -1 for "no threshold" */
-        if (!ec->cleaned_unitigs && tu == (uint32_t)-1) tu = 0;
-        if (!ec->cleaned_kmers && tk == (uint32_t)-1) tk = 0;
-      }
-      if (!ec->cleaned_unitigs && tu > 0) {
-        warn("Graph header gives cleaning threshold for unitig when no cleaning was performed [path: %s]", r->path);
-        tu = 0;
-      }
-      if (!ec->cleaned_kmers && tk > 0) {
-        warn("Graph header gives cleaning threshold for nodes when no cleaning was performed [path: %s]", r->path);
-        tk = 0;
-      }
-      ec->clean_unitigs_thresh = tu; ec->clean_kmers_thresh = tk;
-      free(ec->intersection_name);
-      ec->intersection_name = read_name(r, "cleaned against graph name", i, &bytes);
-    }
+  if (!r->ginfo) die("Out of memory");
+  for (uint32_t c = 0; c < r->num_cols; c++) col_info_init(&r->ginfo[c]);
+
+  for (size_t f = 0; f < NFIELDS(hdr_colour_arrays); f++) {
+    if (r->version < hdr_colour_arrays[f].since) continue;
+    for (uint32_t c = 0; c < r->num_cols; c++) bytes += hdr_field_read(r, &hdr_colour_arrays[f], &r->ginfo[c], c);
   }
-  gfread(r, magic, 6, "magic word (end)");
-  if (strcmp(magic, "CORTEX") != 0) die("Magic word doesn't match '%s' (end): '%s' [path: %s]\n", "CORTEX", magic, r->path);
-  bytes += 6;
-  return bytes;
+  for (uint32_t c = 0; c < r->num_cols; c++) {
+    err_cleaning *ec = &r->ginfo[c].cleaning;
+    for (size_t f = 0; f < NFIELDS(hdr_cleaning); f++)
+      if (r->version >= hdr_cleaning[f].since) bytes += hdr_field_read(r, &hdr_cleaning[f], ec, c);
+    hdr_settle_threshold(r, ec->cleaned_unitigs, &ec->clean_unitigs_thresh, "unitig");
+    hdr_settle_threshold(r, ec->cleaned_kmers, &ec->clean_kmers_thresh, "nodes");
+  }
+  return bytes + hdr_magic(r, "magic word (end)", true);
 }
 
 void ctx_reader_open(ctx_reader *r, const char *input, size_t into_offset, size_t min_k, size_t max_k)
@@ -398,10 +407,9 @@ void ctx_reader_open_mode(ctx_reader *r, const char *input, const char *mode, si
 {
   memset(r, 0, sizeof(*r));
   r->input = dupstr(input);
-  const char *ps, *pe;
-  deconstruct_path(input, &ps, &pe);
-  r->path = calloc((size_t)(pe - ps) + 1, 1);
-  memcpy(r->path, ps, (size_t)(pe - ps));
+  const graph_arg ga = graph_arg_split(input);
+  r->path = calloc(ga.path.n + 1, 1);
+  memcpy(r->path, ga.path.s, ga.path.n);
   r->file_size = r->num_kmers = -1;
   if (strcmp(input, "-") != 0) {
     struct stat st;
@@ -414,7 +422,7 @@ void ctx_reader_open_mode(ctx_reader *r, const char *input, const char *mode, si
   } else if (!(r->fh = fopen(r->path, mode))) die("Cannot open file: %s [%s]", r->path, strerror(errno));
   setvbuf(r->fh, NULL, _IOFBF, 1 << 20);
   r->hdr_size = read_header(r);
-  filter_set_cols(r, r->num_cols, into_offset);
+  reader_set_filter(r, into_offset);
   /* db_graph_check_kmer_size: db_graph.c:386-393 */
   if (r->kmer_size < min_k || r->kmer_size > max_k)
     die("Cannot handle kmer size %zu [%zu-%zu; %s]", (size_t)r->kmer_size, min_k, max_k, r->path);

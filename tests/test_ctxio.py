@@ -142,6 +142,89 @@ def test_graph_option_argument_errors(mcx, tmp_path):
         assert msg in err, (args, err)
 
 
+def _probe(tmp_path):
+    """tests/ctx_filter_probe.c over the host program's own reader (no GPU needed)"""
+    exe = tmp_path / "ctx_filter_probe"
+    host = os.path.join(ROOT, "mccortex_amd", "host")
+    subprocess.check_call(["gcc", "-O1", "-I", host, "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "ctx_filter_probe.c"), os.path.join(host, "ctx_file.c"),
+                           os.path.join(host, "host_util.c"), "-o", str(exe), "-lm"])
+
+    def call(arg, into_offset=0):
+        p = subprocess.run([str(exe), arg, str(into_offset)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if p.returncode != 0:
+            return None, p.stderr.decode(errors="replace")
+        out = {"filter": [], "colour": []}
+        for line in p.stdout.decode().splitlines():
+            key, _, rest = line.partition(" ")
+            if key in ("filter",):
+                out["filter"].append(tuple(int(x) for x in rest.split()))
+            elif key == "colour":
+                out["colour"].append(rest.split("|"))
+            else:
+                out[key] = rest
+        return out, ""
+    return call
+
+
+def test_host_reader_filters_match_the_checker(tmp_path, monkeypatch):
+    """The C host program's "<into>:path:<from>" handling against oracle/ctxio.parse_filter: the
+    reference's documented cases, the edge cases of its list syntax, and random arguments."""
+    call = _probe(tmp_path)
+    ncols = 9
+    gis = [ctxio.GraphInfo() for _ in range(ncols)]
+    for c, g in enumerate(gis):
+        g.sample_name, g.total_sequence, g.mean_read_length = "s%d" % c, 1000 * c, 100 + c
+    gis[3].cleaning.cleaned_kmers, gis[3].cleaning.clean_kmers_thresh = 1, 7
+    gis[4].cleaning.is_graph_intersection, gis[4].cleaning.intersection_name = 1, "pop"
+    f = tmp_path / "nine.ctx"
+    hdr = ctxio.header_bytes(31, gis)
+    f.write_bytes(hdr + bytes(3 * (8 + 5 * ncols)))
+    plain, _ = call(str(f), 2)
+    assert plain["path"] == str(f) and plain["dims"] == "6 31 1 9 %d 3" % len(hdr)
+    assert plain["filter"] == [(c, c + 2) for c in range(ncols)] and plain["into_ncols"] == "11"
+    assert [c[1] for c in plain["colour"]] == ["s%d" % c for c in range(ncols)]
+    assert plain["colour"][3][5:8] == ["0010", "0", "7"] and plain["colour"][4][5] == "0001" and plain["colour"][4][8] == "pop"
+    assert [int(c[3]) for c in plain["colour"]] == [1000 * c for c in range(ncols)]
+
+    def same(arg, off=0):
+        got, err = call(arg, off)
+        try:
+            path, want = ctxio.parse_filter(arg, ncols, off)
+        except ctxio.CtxError:
+            assert got is None and "Invalid filter path" in err, (arg, got, err)
+            return False
+        assert got is not None, (arg, err)
+        assert got["path"] == path and got["filter"] == want, (arg, got, want)
+        assert int(got["into_ncols"]) == max(i for _, i in want) + 1
+        return True
+
+    p = str(f)
+    for arg in [p, p + ":0,6-8", "2:" + p + ":1", "0:" + p, "3,1:" + p + ":0-1", p + ":2-0", p + ":", p + ":8", "7-4:" + p + ":0-3",
+                "0-8:" + p, "12:" + p + ":5,5,5", p + ":0-0", p + ":3-3,4"]:
+        assert same(arg, 1), arg
+    for arg in [p + ":9", p + ":0,", p + ":,0", p + ":0,,1", p + ":1-", p + ":-1", p + ":1-2-3", "0,1,2:" + p + ":0-1", "0-1:" + p + ":0-2",
+                p + ":0-9", "1-:" + p, ",:" + p]:
+        assert not same(arg), arg
+    # a leading list that is not closed by ':' and a trailing one that is not opened by one belong to the path
+    odd = tmp_path / "7-8"
+    odd.write_bytes(f.read_bytes())
+    monkeypatch.chdir(tmp_path)
+    assert same("7-8") and same("./7-8:2") and same("1:./7-8:2") and same("3:./7-8")
+    rng = np.random.default_rng(5)
+    items = lambda n: ",".join(("%d" % a if a == b else "%d-%d" % (a, b))
+                               for a, b in zip(rng.integers(0, n, 3), rng.integers(0, n, 3)))[: int(rng.integers(1, 12))]
+    ok = 0
+    for _ in range(150):
+        arg = p
+        if rng.random() < 0.6:
+            arg = arg + ":" + items(10)
+        if rng.random() < 0.5:
+            arg = items(14) + ":" + arg
+        ok += same(arg, int(rng.integers(0, 4)))
+    assert 20 < ok < 140
+
+
 # ------------------------------------------------------------------------------------------
 def _random_records(rng, k, file_ncols, n, W):
     keys = np.zeros((n, W), dtype=np.uint64)
