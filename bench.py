@@ -54,6 +54,8 @@ KERNEL_ALG_BYTES = {"k_stream": 21.25, "k_stream_bin": 1.25 + 8.0, "k_tuples_bin
 # graph_checksum of the default workload (B = 5M reads per step, 200 Mbp genome, err 0.001) after
 # `steps` steps, as N=1 runs of this file report it (BENCH_r02.json: 20 steps; profiles/r02g: 10)
 N1_CHECKSUMS = {10: "c72ff066d6a527ec", 20: "bc686b82dd898aa5"}
+# the same for the C5 pass (4 colours, reads [c T/4, (c+1) T/4) of the timed reads to sample c): config.C5_reference of N=1 runs
+N1_C5_CHECKSUMS = {}
 
 
 def make_genome(n, device, seed):
@@ -216,7 +218,13 @@ def cpu_baseline(stream_dev, fastq_sample=None, batches_dev=None, oracle_steps=0
         kmers, dt = run(nt)
         scan[nt] = kmers / dt
     best = max(scan, key=scan.get)
-    out = {"value": scan[best], "unit": "k-mers/s", "cores": best, "kind": "port",
+    eff = effective_cores()
+    out = {"value": scan[best], "unit": "k-mers/s", "cores": best, "threads": best,
+           "effective_cores": round(eff, 2) if eff else ncores,
+           "cores_note": "`cores` = `threads` = worker threads of the timed run (the best of the scan); `effective_cores` = the CPU time per second the container's "
+                         "cgroup grants this job (cpu.max quota / period%s), which is what the threads share; host_cpus = CPUs visible"
+                         % ("" if eff else "; no quota set here: all visible CPUs"),
+           "kind": "port",
            "sample": "first %d reads of step 0 (%d k-mer occurrences) per thread count, oracle/mcx_oracle.c "
                      "bucket-locked table build from memory, arrays prefaulted; value = best thread count" % (nsample, kmers),
            "host_cpus": ncores, "cpu_model": cpu_model(),
@@ -496,6 +504,34 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
     r = run_config(mcx, steps, K, 4, cols, table_slots, c5_defer, pk)
     r["workload"] = "C5-like, colours interleaved: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
     out["other_configs"]["C5_like_interleaved_colours_1gpu"] = r
+    # C5 as the N > 1 run builds it (config.C5 there: the timed reads dealt out to 4 samples by their place in the input):
+    # the same coloured graph on one GPU -- its checksum is what N1_C5_CHECKSUMS holds for the N > 1 runs to compare with
+    try:
+        per_col = colour_slices(steps, 0, B, 4)
+        g = mcx.Graph(K, 4, table_slots)
+        g.configure("defer_tuples", c5_defer)
+        g.add_stream_dev(0, steps[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
+        g.sync(); g.reset(); g.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c, lst in enumerate(per_col):
+            for t in lst:
+                g.add_stream_dev(c, t, t.numel())
+        g.sync()
+        dt = time.perf_counter() - t0
+        st, ist = g.device_stats(), g.insert_stats()
+        cs, nodes = g.checksum()
+        g.close()
+        torch.cuda.empty_cache()
+        out["other_configs"]["C5_reference_1gpu"] = {
+            "value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt / len(steps), "steps": len(steps), "kmers_inserted": int(st.num_kmers_loaded),
+            "distinct_kmers": int(nodes), "graph_checksum": "%016x" % cs, "table_passes": ist["flushes"], "fallback_inserts": ist["fallback_inserts"],
+            "matches_known": (("%016x" % cs) == N1_C5_CHECKSUMS[len(steps)]) if (len(steps) in N1_C5_CHECKSUMS and B == BATCH_READS) else None,
+            "workload": "C5: k=31, 4 colours, the %d x %d timed reads dealt out to 4 samples in input order (%d reads each), table %d slots, ONE GPU; the graph "
+                        "`bench.py --gpus N` builds as config.C5" % (len(steps), B, len(steps) * B // 4, table_slots)}
+    except Exception as e:
+        out["other_configs"]["C5_reference_1gpu"] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
     # the reference's own published table benchmark, and the insert-bound worst case of SURVEY 8(d)
     for name, fn in (("hashtest", lambda: hashtest(mcx, device, table_slots)),
                      ("C2_stress", lambda: c2_stress(mcx, device, min(10, nsteps), B))):
@@ -665,6 +701,362 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
     return out
 
 
+def spawn_ranks(n):
+    """re-exec this command under torch.distributed.run with n ranks on this node (127.0.0.1 rendezvous on a free
+    port); stdout of the ranks is this process's stdout, so rank 0's JSON line is the one line printed"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def effective_cores():
+    """CPU time the container grants per second of wall clock (cgroup quota / period), or None when unlimited"""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] == "max":
+                    return None
+                return float(txt[0]) / float(txt[1])
+            q = float(txt[0])
+            if q <= 0:
+                return None
+            return q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+def colour_slices(step_batches, first_read, B, ncols):
+    """C5's samples: the job's timed reads in order (step 0's B reads, step 1's, ...) are dealt out to `ncols` samples,
+    reads [c T / ncols, (c + 1) T / ncols) of the T = steps x B to sample c (4 x 12.5 M reads at 10 steps) -- a function of
+    the read's place in the N = 1 input, so that every N builds the same coloured graph.  step_batches[i] holds reads
+    [first_read, first_read + n_i) of step i (this rank's slice).  -> per colour, the list of its stream slices."""
+    nsteps = len(step_batches)
+    T = nsteps * B
+    out = [[] for _ in range(ncols)]
+    for i, b in enumerate(step_batches):
+        rows = b.reshape(-1, READ_LEN + 1)
+        g0 = i * B + first_read                      # place of this slice's first read in the whole input
+        for c in range(ncols):
+            lo, hi = max(T * c // ncols, g0), min(T * (c + 1) // ncols, g0 + rows.shape[0])
+            if hi > lo:
+                out[c].append(rows[lo - g0:hi - g0].reshape(-1))
+    return out
+
+
+def _deal_colours(step_batches, first_read, B, ncols, xmax, shard, dist, world, device):
+    """colour_slices() cut into exchange steps of at most xmax bytes: [(colour, stream)], the same number of steps per
+    colour on every rank (a rank with fewer reads of a sample passes shorter, possibly empty, steps)"""
+    per_col = colour_slices(step_batches, first_read, B, ncols)
+    streams = [torch.cat(v) if v else torch.zeros(0, dtype=torch.uint8, device=device) for v in per_col]
+    most = torch.tensor([max(t.numel() for t in streams)], dtype=torch.int64, device=device)
+    if world > 1:
+        shard.all_reduce(most, op=dist.ReduceOp.MAX)
+    reads_per_x = max(1, xmax // (READ_LEN + 1))
+    nx = max(1, -(-(int(most.item()) // (READ_LEN + 1)) // reads_per_x))
+    out = []
+    for c, t in enumerate(streams):
+        rows = t.reshape(-1, READ_LEN + 1)
+        n = rows.shape[0]
+        for j in range(nx):
+            out.append((c, rows[n * j // nx:n * (j + 1) // nx].reshape(-1)))
+    return out
+
+
+def sharded_pass(mcx, shard, dist, args, device, local_rank, rank, world, fmt, ncols, x_timed, x_warm, xmax, slots_per_gpu, nsteps):
+    """ONE timed pass of the N > 1 path -- sender kernel -> all-to-all -> owner kernels (mccortex_amd/shard.py:
+    ShardedInserter), fresh graph -- in exchange format `fmt` ("v3": minimizer-owned super-k-mer records, ordinary
+    per-rank tables; "v2": packed tuples, table sharded by quotient-hash prefix).  x_timed / x_warm: [(colour, stream)].
+    Every rank returns the job-wide record (totals all-reduced, per-rank stage table all-gathered)."""
+    use_v3 = fmt == "v3"
+    if use_v3:
+        graph = mcx.Graph(K, ncols, slots_per_gpu, device=local_rank)
+    else:
+        graph = mcx.Graph(K, ncols, slots_per_gpu, device=local_rank, nparts=world, part=rank)
+    graph.configure("defer_tuples", args.defer_tuples)
+    probe = x_timed[0][1] if x_timed[0][1].numel() >= 1024 * (READ_LEN + 1) else max((x for _, x in x_timed), key=lambda t: t.numel())
+    nprobe = min(probe.numel(), 1024 * (READ_LEN + 1))
+    graph.add_stream_dev(0, probe[:nprobe], nprobe)   # the bin workspace is allocated on first use: outside the timed region
+    graph.sync()
+    graph.reset()
+    inserter = shard.ShardedInserter(graph, world, device, xmax, use_v3, max_tuples=xmax // (READ_LEN + 1) * (READ_LEN - K + 1))
+
+    def run(xs):
+        i = 0
+        while i < len(xs):   # consecutive exchange steps of one colour are one insert() call (double buffered inside)
+            j = i
+            while j < len(xs) and xs[j][0] == xs[i][0]:
+                j += 1
+            inserter.insert(xs[i][0], [(x, x.numel()) for _, x in xs[i:j]])
+            i = j
+
+    def fence():
+        torch.cuda.synchronize()
+        graph.sync()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(x_warm)
+    fence()
+    graph.reset()
+    fence()
+    inserter.reset_stats()
+    graph.configure("profile", 1)  # HIP events around every kernel launch on the handle's stream
+    t0 = time.perf_counter()
+    run(x_timed)
+    fence()
+    dt_local = time.perf_counter() - t0
+
+    st = graph.device_stats()
+    ist = graph.insert_stats()
+    prof = graph.profile()
+    cs_local, nodes_local = graph.checksum()
+    kmers_local = st.num_kmers_loaded
+    ident = torch.tensor([cs_local & 0xFFFFFFFF, cs_local >> 32, nodes_local, kmers_local, ist["flushes"], ist["fallback_inserts"], ist["foreign_inserts"]],
+                         dtype=torch.int64, device=device)
+    tmax = torch.tensor([dt_local, float(ist["flushes"])], dtype=torch.float64, device=device)
+    if world > 1:
+        shard.all_reduce(ident, op=dist.ReduceOp.SUM)   # 32-bit halves: the sums cannot overflow
+        shard.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    iv = [int(v) for v in ident.tolist()]
+    cs_total = (iv[0] + (iv[1] << 32)) & 0xFFFFFFFFFFFFFFFF
+    dt = float(tmax[0].item())
+    stage_of = {"k_stream_superk": "sender", "k_stream_bin": "sender", "k_superk_bin": "owner", "k_tuples_bin": "split",
+                "k_lds_insert": "insert", "k_insert_tuples": "owner_overflow"}
+    mine = {"rank": rank, "device": local_rank, "wall_s": round(dt_local, 5),
+            "kmers_kmerised": int(kmers_local), "distinct_kmers_owned": int(nodes_local), "table_passes": ist["flushes"],
+            "stage_ms": {}, "exchange_ms": round(inserter.stats["exchange_ms"], 3), "exchange_steps": inserter.stats["steps"],
+            "link_bytes_sent": inserter.stats["link_bytes_sent"], "stream_bytes": inserter.stats["stream_bytes"]}
+    for kn, (c, t) in prof.items():
+        e = mine["stage_ms"].setdefault(stage_of.get(kn, kn), {"kernel": kn, "launches": 0, "total_ms": 0.0})
+        e["launches"] += c
+        e["total_ms"] = round(e["total_ms"] + t, 3)
+    mine["link_bytes_per_occurrence"] = round(mine["link_bytes_sent"] / max(1, kmers_local), 3)
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
+    graph.close()
+    del inserter, graph
+    torch.cuda.empty_cache()
+    kmers_total = iv[3]
+    link = sum(r["link_bytes_sent"] for r in per_rank)
+    return {"exchange_format": fmt, "colours": ncols, "value": kmers_total / dt, "unit": "k-mers/s", "seconds": dt, "ms_per_step": 1e3 * dt / nsteps,
+            "kmers_inserted": kmers_total, "distinct_kmers_total": iv[2], "graph_checksum": "%016x" % cs_total,
+            "exchange_steps": per_rank[0]["exchange_steps"], "link_bytes_total": link, "link_bytes_per_occurrence": round(link / max(1, kmers_total), 3),
+            "exchange_ms_max": max(r["exchange_ms"] for r in per_rank),
+            "stage_ms_max": {sname: round(max(r["stage_ms"].get(sname, {}).get("total_ms", 0.0) for r in per_rank), 3)
+                             for sname in sorted({k_ for r in per_rank for k_ in r["stage_ms"]})},
+            "table_passes_max": int(tmax[1].item()), "fallback_inserts_total": iv[5], "foreign_inserts_total": iv[6],
+            "sharding": ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
+            "per_rank": per_rank}
+
+
+def inprocess_multi(args):
+    """The C ABI's ONE-process table over devices 0..N-1 (mcx_graph_create_multi: the driver `mccortex31 build -D 0,1,..`
+    runs; peer-mapped copy kernel instead of RCCL) on the N = 1 reads: every device holds its 1/N of every step's
+    reads and k-merises them as the sender, the owners insert.  Run by the N > 1 bench as a subprocess (a fault on a
+    path that has never met two GPUs must not cost the RCCL figures their line)."""
+    import __graft_entry__
+    __graft_entry__.build()
+    import mccortex_amd as mcx
+    n, B, nsteps, nwarm = args.inprocess_multi, args.batch_reads, args.steps, args.warmup
+    dev0 = torch.device("cuda", 0)
+    genome = make_genome(args.genome, dev0, seed=42)
+    per_dev = [[] for _ in range(n)]
+    for i in range(nsteps + nwarm):
+        full = make_batch(genome, B, seed=1000 + i, device=dev0, err_rate=args.err).reshape(B, READ_LEN + 1)
+        for d in range(n):
+            per_dev[d].append(full[B * d // n:B * (d + 1) // n].reshape(-1).to(torch.device("cuda", d)))
+        del full
+    del genome
+    for d in range(n):
+        torch.cuda.synchronize(d)
+    torch.cuda.empty_cache()
+    g = mcx.Graph(K, 1, args.table_slots, devices=list(range(n)))
+    g.configure("defer_tuples", max(1 << 28, args.defer_tuples // n))
+
+    def run(idx):
+        for i in idx:
+            for d in range(n):
+                g.add_stream_dev(0, per_dev[d][i], per_dev[d][i].numel())
+        g.sync()
+
+    run(range(nsteps, nsteps + nwarm))
+    g.reset(); g.sync()
+    g.configure("profile", 1)
+    t0 = time.perf_counter()
+    run(range(nsteps))
+    dt = time.perf_counter() - t0
+    st, ist = g.device_stats(), g.insert_stats()
+    cs, nodes = g.checksum()
+    stage_of = {"k_stream_superk": "sender", "k_stream_bin": "sender", "k_superk_bin": "owner", "k_tuples_bin": "split", "k_lds_insert": "insert"}
+    stages = {}
+    for kn, (c, t) in g.profile().items():
+        name, _, shard_ix = kn.partition("@")
+        e = stages.setdefault(stage_of.get(name, name), {})
+        e[shard_ix or "0"] = round(e.get(shard_ix or "0", 0.0) + t, 2)
+    g.close()
+    return {"value": st.num_kmers_loaded / dt, "unit": "k-mers/s", "n_gpus": n, "seconds": dt, "ms_per_step": 1e3 * dt / nsteps, "steps": nsteps,
+            "kmers_inserted": int(st.num_kmers_loaded), "distinct_kmers_total": int(nodes), "graph_checksum": "%016x" % cs,
+            "table_passes_all_shards": ist["flushes"], "fallback_inserts": ist["fallback_inserts"], "spilled": ist["spilled"],
+            "stage_span_ms_by_shard": stages,
+            "what": "mcx_graph_create_multi over devices 0..%d in ONE process (one host thread issues every launch; exchange over peer-mapped "
+                    "pointers, k_copy_filled), the N = 1 reads dealt out to the devices, %d slots in total" % (n - 1, args.table_slots)}
+
+
+def sharded_main(mcx, shard, dist, args, device, local_rank, rank, world, force_shard):
+    """N > 1 (one process per GPU; also N = 1 under MCX_BENCH_FORCE_SHARD=1): the exchange path in BOTH formats on one
+    colour, then config C5 (4 colours) in the faster one, then the C ABI's one-process driver as a subprocess.
+    `value` is the better one-colour figure; everything else sits in `config`."""
+    B, nsteps, nwarm = args.batch_reads, args.steps, args.warmup
+    strong = args.scaling == "strong" and not args.iid
+    if args.iid:
+        batches = [make_batch_iid(B, seed=1000 * (rank + 1) + i, device=device) for i in range(nsteps + nwarm)]
+    elif strong:
+        # C3: the reads of the N = 1 run.  Step i is the batch N = 1 uses for step i (same seed);
+        # this rank takes reads [rank B / N, (rank + 1) B / N) of it.
+        genome = make_genome(args.genome, device, seed=42)
+        r_lo, r_hi = B * rank // world, B * (rank + 1) // world
+        batches = []
+        for i in range(nsteps + nwarm):
+            full = make_batch(genome, B, seed=1000 + i, device=device, err_rate=args.err)
+            batches.append(full.reshape(B, READ_LEN + 1)[r_lo:r_hi].reshape(-1).clone())
+            del full
+        del genome
+    else:
+        genome = make_genome(args.genome * world, device, seed=42)
+        batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device, err_rate=args.err) for i in range(nsteps + nwarm)]
+        del genome
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    slots_per_gpu = max(1 << 20, args.table_slots // world) if strong else args.table_slots
+
+    def exchange_steps(idx):
+        """the streams one all-to-all step moves: a rank's own batch (weak), or -- strong, where a rank's share of a
+        step is B / N reads -- its shares of N consecutive steps in one piece, so that an exchange step carries as
+        many reads as at N = 1"""
+        idx = list(idx)
+        if not strong:
+            return [batches[i] for i in idx]
+        return [torch.cat([batches[i] for i in idx[j:j + world]]) for j in range(0, len(idx), world)]
+
+    x_timed, x_warm = exchange_steps(range(nsteps)), exchange_steps(range(nsteps, nsteps + nwarm))
+    per_step_max = (-(-B // world)) if strong else B          # reads of one step on the fullest rank
+    xmax = (per_step_max * (world if strong else 1) + 1) * (READ_LEN + 1)   # same on every rank
+
+    formats = ["v3", "v2"] if mcx.superk_supported(K) else ["v2"]
+    if os.environ.get("MCX_EXCHANGE") in formats:
+        formats = [os.environ["MCX_EXCHANGE"]]   # (tests, experiments: one format only)
+    one = {}
+    for fmt in formats:
+        one[fmt] = sharded_pass(mcx, shard, dist, args, device, local_rank, rank, world, fmt, 1,
+                                [(0, x) for x in x_timed], [(0, x) for x in x_warm], xmax, slots_per_gpu, nsteps)
+    best = max(one, key=lambda f: one[f]["value"])
+    c5 = None
+    if not args.iid and os.environ.get("MCX_BENCH_C5", "1") != "0":
+        c5_timed = _deal_colours(batches[:nsteps], (B * rank // world) if strong else 0, B, 4, xmax, shard, dist, world, device)
+        c5_warm = [(i % 4, x) for i, x in enumerate(x_warm)]
+        c5 = sharded_pass(mcx, shard, dist, args, device, local_rank, rank, world, best, 4, c5_timed, c5_warm, xmax, slots_per_gpu, nsteps)
+        del c5_timed, c5_warm
+    del x_timed, x_warm, batches
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+
+    r = one[best]
+    scaling = "strong" if strong else "weak"
+    if strong:
+        shape = ("C3: the N=1 reads (%d reads x %d bp per step from a %d Mbp random genome) dealt out to %d GPUs, %d reads per step per GPU, "
+                 "table %d slots in total = %d per GPU" % (B, READ_LEN, args.genome // 1_000_000, world, B // world, args.table_slots, slots_per_gpu))
+    else:
+        shape = ("%d reads x %d bp per step per GPU from a %d Mbp random genome, table %d slots per GPU" % (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots))
+    transport = shard.dist_backend() + (" (TEST transport: host-staged collectives, all ranks on one device)" if shard.dist_backend() != "nccl" else " (RCCL)")
+    cfg = {"workload": ("C2-stress: k=31, 1 colour, %d iid random reads x %d bp per step per GPU, table %d slots per GPU" % (B, READ_LEN, args.table_slots)) if args.iid else
+                       "C2: k=31, 1 colour, %s; input already resident in HBM as an ASCII byte stream (parse and H2D outside `value`)" % shape,
+           "input": "device-resident ASCII stream", "kmer_size": K, "colours": 1,
+           "reads_per_step_per_gpu": (B // world) if strong else B, "read_len": READ_LEN,
+           "table_slots_per_gpu": slots_per_gpu, "table_slots_total": slots_per_gpu * world,
+           "sharding": r["sharding"], "exchange_format": best, "transport": transport,
+           "insert_path": "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
+           "kmers_inserted": r["kmers_inserted"], "distinct_kmers_total": r["distinct_kmers_total"], "graph_checksum": r["graph_checksum"],
+           "table_passes_max_over_ranks": r["table_passes_max"], "fallback_inserts_total": r["fallback_inserts_total"], "foreign_inserts_total": r["foreign_inserts_total"]}
+    # the same reads must give the same graph whatever N and whatever the exchange format
+    known = (strong or world == 1) and not args.iid and B == BATCH_READS and args.genome == GENOME_PER_GPU and args.err == 0.001 \
+        and READ_LEN == 150 and nsteps in N1_CHECKSUMS
+    if known:
+        cfg["checksum_matches_n1"] = all(v["graph_checksum"] == N1_CHECKSUMS[nsteps] for v in one.values())
+    cfg["formats_agree"] = len({(v["graph_checksum"], v["distinct_kmers_total"], v["kmers_inserted"]) for v in one.values()}) == 1
+    slim = lambda v: {k_: v[k_] for k_ in v if k_ != "per_rank"}
+    cfg["exchange_formats"] = {f: dict(slim(v), per_rank=v["per_rank"]) for f, v in one.items()}
+    cfg["exchange_formats"]["what"] = ("the same steps timed once per exchange format (fresh tables each time; `value` is the faster one): per format the job-wide figure, "
+                                       "max-over-ranks HIP-event spans per stage (sender = k-merise own reads into per-owner bins, owner = k-merise received super-k-mers "
+                                       "into region bins, split = region -> sub-table bins, insert = LDS insert), the exchange's span on torch's stream, the bytes put "
+                                       "on the links, and the per-rank table")
+    if c5 is not None:
+        c5["workload"] = ("C5: k=31, 4 colours, the timed reads dealt out to 4 samples (%d reads each job-wide), exchange format %s, table %d slots in total"
+                          % (nsteps * B * (1 if strong else world) // 4, best, slots_per_gpu * world))
+        # same reads as the one-colour pass: the union graph has the same nodes and the same number of occurrences
+        c5["nodes_and_kmers_match_one_colour"] = (c5["distinct_kmers_total"] == r["distinct_kmers_total"] and c5["kmers_inserted"] == r["kmers_inserted"])
+        if known and nsteps in N1_C5_CHECKSUMS:
+            c5["checksum_matches_n1"] = c5["graph_checksum"] == N1_C5_CHECKSUMS[nsteps]
+        cfg["C5"] = c5
+    # the C ABI's one-process driver over the same devices (bounded subprocess; rank 0 only, the other ranks have
+    # released their memory and wait at the closing barrier)
+    if world > 1 and strong and shard.dist_backend() == "nccl" and os.environ.get("MCX_BENCH_INPROCESS", "1") != "0":
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--inprocess-multi", str(world), "--steps", str(nsteps), "--warmup", str(min(nwarm, 1)),
+               "--batch-reads", str(B), "--table-slots", str(args.table_slots), "--genome", str(args.genome), "--err", str(args.err),
+               "--defer-tuples", str(args.defer_tuples)]
+        env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                   "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+        env["MCX_TIMING"] = "1"   # (peer matrix and self-test verdict on stderr)
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=420)
+            lines = p.stdout.decode(errors="replace").strip().splitlines()
+            if p.returncode == 0 and lines:
+                rec = json.loads(lines[-1])
+                rec["graph_matches_rccl_path"] = rec["graph_checksum"] == r["graph_checksum"] and rec["distinct_kmers_total"] == r["distinct_kmers_total"]
+                rec["peer_selftest"] = [ln for ln in p.stderr.decode(errors="replace").splitlines() if "peer" in ln][-12:]
+                cfg["inprocess_multi"] = rec
+            else:
+                cfg["inprocess_multi"] = {"error": "rc %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-400:])}
+        except Exception as e:
+            cfg["inprocess_multi"] = {"error": str(e)[:300]}
+    # roofline of the job: SURVEY 8(d) bytes over the wall clock of the timed region, against N x 8 TB/s
+    pipe_bytes = ALG_BYTES_PER_KMER * r["kmers_inserted"] + ALG_BYTES_PER_NOVEL * r["distinct_kmers_total"]
+    ach = pipe_bytes / r["seconds"] / 1e9
+    out = {"metric": "k-mers/s inserted (build), k=31, 50M x 150bp synthetic reads",
+           "value": r["value"], "unit": "k-mers/s", "n_gpus": world, "steps": nsteps, "warmup": nwarm,
+           "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": scaling,
+           "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": cfg,
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world), "traffic": None,
+                        "what": "SURVEY 8(d): (21.25 B x k-mer occurrences + 8 B x novel keys) / wall clock of the timed region (max over ranks), against %d x 8 TB/s; "
+                                "per-stage spans per rank: config.exchange_formats" % world,
+                        "alg_bytes": pipe_bytes, "seconds": r["seconds"]},
+           "multi_gpu": {"transport": transport, "exchange_format": best, "per_rank": r["per_rank"]},
+           "summary": {"value_gkmers_per_s": round(r["value"] / 1e9, 2),
+                       **{"%s_gkmers_per_s" % f: round(v["value"] / 1e9, 2) for f, v in one.items()},
+                       **({"C5_gkmers_per_s": round(c5["value"] / 1e9, 2)} if c5 else {}),
+                       **({"inprocess_multi_gkmers_per_s": round(cfg["inprocess_multi"]["value"] / 1e9, 2)} if "value" in cfg.get("inprocess_multi", {}) else {})}}
+    for key in ("checksum_matches_n1", "formats_agree"):
+        if key in cfg:
+            out["summary"][key] = cfg[key]
+    cfg["summary"] = out["summary"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -688,6 +1080,9 @@ def main():
     ap.add_argument("--iid", action="store_true", help="experiments only: C2-stress, iid random reads (every k-mer novel)")
     ap.add_argument("--direct", action="store_true", help="insert with HBM atomics instead of partition + LDS insert")
     ap.add_argument("--defer-tuples", type=int, default=DEFER_TUPLES)
+    ap.add_argument("--inprocess-multi", type=int, default=0,
+                    help="(used by the N > 1 run itself, as a subprocess) the C ABI's one-process table over devices 0..N-1 "
+                         "(mcx_graph_create_multi: what `mccortex31 build -D 0,1,..` runs) on the same reads; prints its own JSON line")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 (make,
@@ -699,9 +1094,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.inprocess_multi:
+        os.write(json_fd, (json.dumps(inprocess_multi(args)) + "\n").encode())
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver types it: start the N ranks ourselves (one process per GPU,
+        # torch.distributed.run on this node) and hand their ONE JSON line (rank 0's) through
+        os.dup2(json_fd, 1)
+        raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
     from mccortex_amd import shard
     # (MCX_DIST_BACKEND=gloo + MCX_DIST_ONE_DEVICE=0: shard.py's test transport -- several ranks on the one GPU of a
@@ -712,9 +1114,13 @@ def main():
     # MCX_BENCH_FORCE_SHARD=1: run the partition -> all-to-all -> insert path even at N=1
     # (validation of the N>1 code on a 1-GPU box; never used for the reported N=1 number)
     force_shard = os.environ.get("MCX_BENCH_FORCE_SHARD") == "1"
+    cpu_group = None
     if world > 1 or force_shard:
         os.environ.setdefault("MASTER_PORT", "29531")
         shard.init_process_group(device, rank, world)
+        if world > 1:
+            import datetime
+            cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
 
     import __graft_entry__
     if rank == 0:
@@ -723,42 +1129,34 @@ def main():
         dist.barrier()
     import mccortex_amd as mcx
 
+    if world > 1 or force_shard:
+        # one process per GPU: both exchange formats, C5, the one-process driver (sharded_main); the rest of this
+        # function is the N = 1 run
+        out = sharded_main(mcx, shard, dist, args, device, local_rank, rank, world, force_shard)
+        if cpu_group is not None:
+            dist.barrier(group=cpu_group)   # (a host-side wait: rank 0 may still be timing the one-process driver on these GPUs)
+        dist.destroy_process_group()
+        if rank == 0:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())  # the ONE JSON line on stdout
+        return
+
     B = args.batch_reads
     nsteps, nwarm = args.steps, args.warmup
-    sharded = world > 1 or force_shard
-    strong = sharded and args.scaling == "strong" and not args.iid  # (also under MCX_BENCH_FORCE_SHARD=1 at N = 1: the same code path)
     if args.iid:
-        batches = [make_batch_iid(B, seed=1000 * (rank + 1) + i, device=device) for i in range(nsteps + nwarm)]
-    elif strong:
-        # C3: the reads of the N = 1 run.  Step i is the batch N = 1 uses for step i (same seed);
-        # this rank takes reads [rank B / N, (rank + 1) B / N) of it.
-        genome = make_genome(args.genome, device, seed=42)
-        r_lo, r_hi = B * rank // world, B * (rank + 1) // world
-        batches = []
-        for i in range(nsteps + nwarm):
-            full = make_batch(genome, B, seed=1000 + i, device=device, err_rate=args.err)
-            batches.append(full.reshape(B, READ_LEN + 1)[r_lo:r_hi].reshape(-1).clone())
-            del full
-        del genome
+        batches = [make_batch_iid(B, seed=1000 + i, device=device) for i in range(nsteps + nwarm)]
     else:
-        genome = make_genome(args.genome * world, device, seed=42)
-        batches = [make_batch(genome, B, seed=1000 * (rank + 1) + i, device=device, err_rate=args.err)
-                   for i in range(nsteps + nwarm)]
+        genome = make_genome(args.genome, device, seed=42)
+        batches = [make_batch(genome, B, seed=1000 + i, device=device, err_rate=args.err) for i in range(nsteps + nwarm)]
         del genome
     torch.cuda.synchronize()
     torch.cuda.empty_cache()  # hand the generator's temporaries back before the graph allocates
 
-    # N > 1, weak: every rank holds a table of the same per-GPU size; strong: the N = 1 table split N ways.
-    # Exchange format: v3 (super-k-mer records, minimizer ownership, ordinary per-rank tables) when
-    # k allows it, else v2 (packed tuples, table sharded by quotient-hash prefix); MCX_EXCHANGE=v2 forces v2
-    slots_per_gpu = max(1 << 20, args.table_slots // world) if strong else args.table_slots
-    use_v3 = sharded and mcx.superk_supported(K) and os.environ.get("MCX_EXCHANGE", "v3") != "v2"
-    # the device's streaming and random-RMW ceilings, measured in this run (rank 0, N = 1)
-    ceil = ceilings(mcx, slots_per_gpu * 16) if (rank == 0 and not sharded) else {}
-    if use_v3:
-        graph = mcx.Graph(K, 1, slots_per_gpu, device=local_rank)
-    else:
-        graph = mcx.Graph(K, 1, slots_per_gpu, device=local_rank, nparts=world, part=rank)
+    slots_per_gpu = args.table_slots
+    # the device's streaming and random-RMW ceilings, measured in this run
+    ceil = ceilings(mcx, slots_per_gpu * 16)
+    graph = mcx.Graph(K, 1, slots_per_gpu, device=local_rank)
     if args.direct:
         graph.configure("defer", 0)
     else:
@@ -768,69 +1166,34 @@ def main():
         graph.add_stream_dev(0, batches[0][:1024 * (READ_LEN + 1)], 1024 * (READ_LEN + 1))
         graph.sync()
         graph.reset()
-    use_packed = args.input == "packed" and not sharded
+    use_packed = args.input == "packed"
     packed = pack_batches(mcx, batches) if use_packed else None
     ext = torch.cuda.ExternalStream(graph.stream, device=device)
-    W = graph.W
 
-    def exchange_steps(idx):
-        """the streams one all-to-all step moves: a rank's own batch (weak), or -- strong, where a
-        rank's share of a step is B / N reads -- its shares of N consecutive steps in one piece, so that an
-        exchange step carries as many reads as at N = 1"""
-        idx = list(idx)
-        if not strong:
-            return [batches[i] for i in idx]
-        return [torch.cat([batches[i] for i in idx[j:j + world]]) for j in range(0, len(idx), world)]
-
-    if sharded:
-        # partition -> all-to-all -> insert, double buffered (mccortex_amd/shard.py: ShardedInserter)
-        x_timed, x_warm = exchange_steps(range(nsteps)), exchange_steps(range(nsteps, nsteps + nwarm))
-        xmax = max(x.numel() for x in x_timed + x_warm)
-        inserter = shard.ShardedInserter(graph, world, device, xmax, use_v3,
-                                         max_tuples=xmax // (READ_LEN + 1) * (READ_LEN - K + 1))
-        if strong:
-            batches = batches[:1]  # (the exchange steps hold copies of the slices)
-            torch.cuda.empty_cache()
-
-    def run_steps(idx, xs=None):
-        idx = list(idx)
-        if not idx:
-            return
-        if not sharded:
-            for i in idx:
-                if use_packed:
-                    graph.add_packed_dev(0, *packed[i])
-                else:
-                    graph.add_stream_dev(0, batches[i], batches[i].numel())
-            return
-        try:
-            inserter.insert(0, [(x, x.numel()) for x in xs])
-        except RuntimeError as e:
-            raise SystemExit(str(e))
+    def run_steps(idx):
+        for i in idx:
+            if use_packed:
+                graph.add_packed_dev(0, *packed[i])
+            else:
+                graph.add_stream_dev(0, batches[i], batches[i].numel())
 
     def fence():
         torch.cuda.synchronize()
         graph.sync()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
 
-    run_steps(range(nsteps, nsteps + nwarm), x_warm if sharded else None)
+    run_steps(range(nsteps, nsteps + nwarm))
     fence()
     graph.reset()
     fence()
 
-    if sharded:
-        inserter.reset_stats()
     graph.configure("profile", 1)  # HIP events around every kernel launch on the handle's stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(ext)
-    run_steps(range(nsteps), x_timed if sharded else None)
+    run_steps(range(nsteps))
     fence()
     ev1.record(ext)
     dt = time.perf_counter() - t0
-    dt_local = dt
     torch.cuda.synchronize()
 
     st = graph.device_stats()
@@ -843,7 +1206,7 @@ def main():
     # of the two kernels contain each other.  A second pass over the same steps with the overlap off gives
     # isolated durations (one kernel at a time on one stream); roofline.kernels / roofline.dominant use those.
     prof_iso, gpu_ms_iso = None, None
-    if not sharded and not args.direct:
+    if not args.direct:
         graph.reset()
         graph.configure("flush_overlap", 0)
         fence()
@@ -859,52 +1222,12 @@ def main():
         if (cs_iso, nodes_iso) != (cs_local, nodes_local):
             raise SystemExit("bench: the non-overlapped pass built another graph (%016x / %d against %016x / %d)" % (cs_iso, nodes_iso, cs_local, nodes_local))
         graph.configure("flush_overlap", 1)
-    ident = torch.tensor([cs_local & 0xFFFFFFFF, cs_local >> 32, nodes_local], dtype=torch.int64, device=device)
-    if world > 1:
-        shard.all_reduce(ident, op=dist.ReduceOp.SUM)   # 32-bit halves: the sums cannot overflow
-    cs_total = (int(ident[0].item()) + (int(ident[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
-    nodes_total = int(ident[2].item())
-    tot = torch.tensor([float(kmers_local), dt], dtype=torch.float64, device=device)
-    if world > 1:
-        k_all = tot[:1].clone()
-        shard.all_reduce(k_all, op=dist.ReduceOp.SUM)
-        t_all = tot[1:].clone()
-        shard.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        kmers_total, dt = float(k_all.item()), float(t_all.item())
-    else:
-        kmers_total = float(kmers_local)
-    # N > 1 diagnostics: what every rank spent per stage (HIP-event spans on its own streams) and put on the links
-    per_rank = None
-    if sharded:
-        stage_of = {"k_stream_superk": "sender", "k_stream_bin": "sender", "k_superk_bin": "owner", "k_tuples_bin": "split",
-                    "k_lds_insert": "insert", "k_insert_tuples": "owner_overflow"}
-        mine = {"rank": rank, "device": local_rank, "wall_s": dt_local,
-                "kmers_kmerised": int(kmers_local), "distinct_kmers_owned": int(nodes_local),
-                "stage_ms": {}, "exchange_ms": round(inserter.stats["exchange_ms"], 3), "exchange_steps": inserter.stats["steps"],
-                "link_bytes_sent": inserter.stats["link_bytes_sent"], "stream_bytes": inserter.stats["stream_bytes"]}
-        for kn, (c, t) in prof.items():
-            st_name = stage_of.get(kn, kn)
-            e = mine["stage_ms"].setdefault(st_name, {"kernel": kn, "launches": 0, "total_ms": 0.0})
-            e["launches"] += c
-            e["total_ms"] = round(e["total_ms"] + t, 3)
-        mine["link_bytes_per_occurrence"] = mine["link_bytes_sent"] / max(1, kmers_local)
-        if world > 1:
-            per_rank = [None] * world
-            dist.all_gather_object(per_rank, mine)
-        else:
-            per_rank = [mine]
+    cs_total, nodes_total, kmers_total = cs_local, int(nodes_local), float(kmers_local)
 
     if rank == 0:
         value = kmers_total / dt
-        scaling = "strong" if strong else "weak"
-        if world == 1 and not strong:
-            shape = "%d reads x %d bp per step from a %d Mbp random genome, table %d slots" % (B, READ_LEN, args.genome // 1_000_000, args.table_slots)
-        elif strong:
-            shape = ("C3: the N=1 reads (%d reads x %d bp per step from a %d Mbp random genome) dealt out to %d GPUs, %d reads per step per GPU, "
-                     "table %d slots in total = %d per GPU" % (B, READ_LEN, args.genome // 1_000_000, world, B // world, args.table_slots, slots_per_gpu))
-        else:
-            shape = ("%d reads x %d bp per step per GPU from a %d Mbp random genome, table %d slots per GPU" %
-                     (B, READ_LEN, args.genome * world // 1_000_000, args.table_slots))
+        scaling = "weak"  # (N = 1: the word means nothing here; N > 1 reports what it ran, strong by default)
+        shape = "%d reads x %d bp per step from a %d Mbp random genome, table %d slots" % (B, READ_LEN, args.genome // 1_000_000, args.table_slots)
         out = {
             "metric": "k-mers/s inserted (build), k=31, 50M x 150bp synthetic reads",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": nsteps, "warmup": nwarm,
@@ -917,9 +1240,9 @@ def main():
                                                                                 "the packed stream mcx_graph_add_reads stages (2-bit codes + invalid flags, 3 bits per position: packing OUTSIDE the clock)"
                                                                                 if use_packed else "an ASCII byte stream (1 byte per position: the 2-bit packing is inside the clock)"),
                        "input": "device-resident packed stream (3 bits per position)" if use_packed else "device-resident ASCII stream",
-                       "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": (B // world) if strong else B, "read_len": READ_LEN,
-                       "table_slots_per_gpu": slots_per_gpu, "table_slots_total": slots_per_gpu * world,
-                       "sharding": "none" if not sharded else ("minimizer-owned super-k-mers x%d, all-to-all" if use_v3 else "hash-prefix x%d, all-to-all") % world,
+                       "kmer_size": K, "colours": 1, "reads_per_step_per_gpu": B, "read_len": READ_LEN,
+                       "table_slots_per_gpu": slots_per_gpu, "table_slots_total": slots_per_gpu,
+                       "sharding": "none",
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel),
                        "distinct_kmers_total": nodes_total, "graph_checksum": "%016x" % cs_total,
@@ -929,17 +1252,8 @@ def main():
         out["summary"] = {}
         # the same reads must give the same graph whatever N is (strong scaling and N = 1): the sum of the
         # ranks' order-independent checksums against what N = 1 runs of this file report for `steps` steps
-        if (world == 1 or strong) and not args.iid and B == BATCH_READS and args.genome == GENOME_PER_GPU and args.err == 0.001 \
-                and READ_LEN == 150 and nsteps in N1_CHECKSUMS:
+        if not args.iid and B == BATCH_READS and args.genome == GENOME_PER_GPU and args.err == 0.001 and READ_LEN == 150 and nsteps in N1_CHECKSUMS:
             out["config"]["checksum_matches_n1"] = ("%016x" % cs_total) == N1_CHECKSUMS[nsteps]
-        if per_rank is not None:
-            out["multi_gpu"] = {"transport": shard.dist_backend() + (" (TEST transport: host-staged collectives, all ranks on one device)"
-                                                                     if shard.dist_backend() != "nccl" else " (RCCL)"),
-                                "exchange_format": "v3" if use_v3 else "v2",
-                                "what": "per rank: HIP-event spans per stage on the graph's stream (sender = k-merise own reads into per-owner bins, owner = k-merise "
-                                        "received super-k-mers into region bins, split = region -> sub-table bins, insert = LDS insert), the exchange's span on torch's "
-                                        "stream, and the bytes the rank sent to OTHER ranks",
-                                "per_rank": per_rank}
         gpu_ms = ev0.elapsed_time(ev1)
         kprof = prof_iso if prof_iso is not None else prof  # isolated durations where they exist
         dom = max(kprof, key=lambda n: kprof[n][1])
@@ -994,7 +1308,7 @@ def main():
                                             "peak_source": "mcx_ubench_random_rmw in this run" if ceil.get("measured_random_rmw_per_s") else "profiles/r01_ubench_atomics.log (round 1)",
                                             "ratio": kmers_local / (gpu_ms * 1e-3) / rmw_peak}
         ex = {}
-        if not sharded and not args.no_extras and not args.iid and not args.direct:
+        if not args.no_extras and not args.iid and not args.direct:
             graph.close()
             torch.cuda.empty_cache()
             osteps = 0 if args.no_cpu_baseline else max(0, min(args.oracle_steps, nsteps))
@@ -1002,7 +1316,7 @@ def main():
             for key in ("host_fed", "e2e", "e2e_full", "default_defer", "ascii_resident", "packed_resident", "other_configs", "inprocess_2_shards_1gpu", "inprocess_8_shards_1gpu"):
                 if key in ex:
                     out[key] = ex[key]
-        if not args.no_cpu_baseline and not sharded:
+        if not args.no_cpu_baseline:
             gref = ex.get("_gpu_oracle_steps")
             out["cpu_baseline"] = cpu_baseline(batches[0], ex.get("_fastq_sample"), batches, gref["steps"] if gref else 0, args.table_slots)
             full = out["cpu_baseline"].get("full_size", {})
@@ -1044,9 +1358,24 @@ def main():
             sm["e2e_full_checksum_matches_device_resident_build"] = v
         if "cpu_baseline" in out:
             sm["gpu_over_cpu_port"] = round(value / max(1.0, out["cpu_baseline"]["value"]), 1)
-    if world > 1 or force_shard:
-        dist.barrier()
-        dist.destroy_process_group()
+            sm["cpu_threads"], sm["cpu_effective_cores"] = out["cpu_baseline"].get("threads"), out["cpu_baseline"].get("effective_cores")
+        # SURVEY 8(d)'s clock ("first batch submitted -> table drained", input in HOST memory) next to the device-resident headline
+        hf = _g(out, "host_fed", "value")
+        if isinstance(hf, (int, float)):
+            novel_per_kmer = st.num_kmers_novel / max(1.0, float(kmers_total))
+            sm["host_fed_roofline_frac"] = round(hf * (ALG_BYTES_PER_KMER + ALG_BYTES_PER_NOVEL * novel_per_kmer) / 1e9 / HBM_PEAK_GBS, 4)
+        for name, path, scale in (("C2_stress_roofline_frac", ("other_configs", "C2_stress", "roofline_frac"), 1), ("hashtest_roofline_frac", ("other_configs", "hashtest", "roofline_frac"), 1),
+                                  ("C5_like_roofline_frac", ("other_configs", "C5_like_4_colours_1gpu", "roofline_frac"), 1),
+                                  ("C5_reference_gkmers_per_s", ("other_configs", "C5_reference_1gpu", "value"), 1e-9)):
+            v = _g(out, *path)
+            if isinstance(v, (int, float)):
+                sm[name] = round(v * scale, 4)
+        v = _g(out, "other_configs", "C5_reference_1gpu", "graph_checksum")
+        if v:
+            sm["C5_reference_checksum"] = v
+        out["config"]["summary"] = sm   # (the driver's record keeps `config`, `roofline`, `cpu_baseline` whole and only the NAMES of other keys)
+        out["roofline"]["host_fed"] = {"kmers_per_s": hf, "frac": sm.get("host_fed_roofline_frac"),
+                                       "what": "the SURVEY 8(d) clock proper: reads in host memory -> first batch submitted -> table drained (staging threads, PCIe and kernels inside)"}
     if rank == 0:
         sys.stdout.flush()
         sys.stderr.flush()

@@ -128,12 +128,20 @@ int mcx_graph_profile(mcx_graph *g, char *buf, size_t buflen);
  * low-complexity input (poly-G reads, satellite repeats) do not overflow the exchange: what fits neither
  * its segment nor the owner's overflow bin is spilled on the sender and routed by the host.  Format v2's
  * spill area holds a whole piece, so nothing can be lost; format v3 has room for 3 records per 16
- * positions in the segments and 4 more in the spill area (random reads make 2.3, low-complexity input
- * fewer: long runs) -- only a piece that changes owner at nearly every k-mer throughout could exceed
- * that, and is then reported with MCX_ERR_FULL, never dropped silently.  Not available on such a handle: the
+ * positions in the segments (random reads make 2.3, low-complexity input fewer: long runs) and its spill
+ * area holds one record per start position of a piece -- a record is a run of >= 1 k-mers, so no input
+ * can overflow it.  Start-up runs a peer self-test: for every ordered pair of distinct devices one copy
+ * kernel writes a pattern into the other device's memory through the peer mapping and the result is read
+ * back; a pair that fails switches the group to hipMemcpyPeerAsync copies (what MCX_MULTI_COPY=memcpy
+ * selects by hand) with one line on stderr.  Not available on such a handle: the
  * device-pointer exchange calls below (those take a single shard).  ndevices == 1 is mcx_graph_create. */
 int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers,
                            const int *devices, int ndevices);
+/* HBM per device that the exchange buffers of such a table take on first use (send / receive sets of
+ * one piece, spill areas), for the caller's memory check next to the table itself: the build command
+ * adds it when it checks -m / -n against the free HBM (src/graph/cmd_mem.c:133-151).  0 for one device.
+ * When the buffers do not fit after all, the library halves the piece instead of failing. */
+int mcx_multi_exchange_bytes(int kmer_size, int ndevices, uint64_t capacity_kmers, uint64_t *bytes_per_device);
 /* Devices the handle spans (1 for an ordinary graph). */
 int mcx_graph_ndevices(const mcx_graph *g);
 

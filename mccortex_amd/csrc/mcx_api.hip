@@ -329,6 +329,16 @@ extern "C" int mcx_graph_create(mcx_graph **out, int kmer_size, int ncols, uint6
   return mcx_graph_create_shard(out, kmer_size, ncols, capacity_kmers, device, 1, 0);
 }
 
+// log2 of the number of regions of a table of nsub sub-tables that is one of 2^lbo hash-prefix shards
+static uint32_t region_bits(uint64_t nsub, uint32_t lbo)
+{
+  uint32_t lb1 = 0;
+  const uint32_t lb1_max = lbo ? std::min<uint32_t>(9, 11 - lbo) : 9;  // shards x regions <= 2048 sender bins
+  while (lb1 < lb1_max && (2ull << lb1) <= nsub) lb1++;             // up to 512 regions ...
+  while (lb1 < 11 && ((nsub + (1ull << lb1) - 1) >> lb1) > (uint64_t)kMaxBins) lb1++;  // ... more for huge tables
+  return lb1;
+}
+
 extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers, int device,
                                       int nparts, int part)
 {
@@ -355,10 +365,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   uint64_t nsub = (std::max<uint64_t>(capacity_kmers, 1024) + sub_slots - 1) / sub_slots;
   uint32_t lbo = 0;
   while ((1 << lbo) < nparts) lbo++;
-  uint32_t lb1 = 0;
-  const uint32_t lb1_max = lbo ? std::min<uint32_t>(9, 11 - lbo) : 9;  // shards x regions <= 2048 sender bins
-  while (lb1 < lb1_max && (2ull << lb1) <= nsub) lb1++;             // up to 512 regions ...
-  while (lb1 < 11 && ((nsub + (1ull << lb1) - 1) >> lb1) > (uint64_t)kMaxBins) lb1++;  // ... more for huge tables
+  uint32_t lb1 = region_bits(nsub, lbo);
   if (const char *e = getenv("MCX_LB1")) { const uint32_t v = (uint32_t)atoi(e); if (!lbo && v >= 6 && v <= 11 && ((nsub + (1ull << v) - 1) >> v) <= (uint64_t)kMaxBins && ((nsub + (1ull << v) - 1) >> v) >= 1) lb1 = v; }  // experiments
   if (lbo && lb1 + lbo > 11) {
     // (owner, region) bins of the sender kernel: at most 2048, and mix_bucket() takes its bits below

@@ -115,30 +115,67 @@ static void group_free_buffers(mcx_group *G)
   G->buffers = false;
 }
 
-// Exchange buffers, allocated on first use.  A piece covers at most max_pos start positions: the
-// staged chunks of mcx_graph_add_reads are 32 MiB, device streams are cut to this size.
-static int group_ensure_buffers(mcx_group *G)
+// Geometry of one exchange piece of at most max_pos k-mer start positions (everything group_alloc_buffers sizes).
+// v3: ~2.3 records per 16 positions on random reads; room for 3: what does not fit a segment goes to the sender's
+// spill area and is routed by the host.  A record is a run of >= 1 k-mers, so a piece yields at most one record per
+// start position: a spill area of max_pos records cannot overflow WHATEVER the input is -- one owner taking
+// everything, or an owner change at every k-mer.  v2: a segment holds mean + 8 sigma of the Poisson fill + room for
+// a short run of one k-mer; what does not fit goes to the owner's overflow bin (hot k-mers), beyond that to the
+// spill area, which holds a whole piece as well.
+static int group_layout(mcx_group *G, uint64_t max_pos)
 {
-  if (G->buffers) return MCX_OK;
   mcx_graph *g0 = G->part[0];
   const int N = G->n, W = g0->W;
-  G->max_pos = std::max<uint64_t>(kStageBytes + kCarry, 32ull << 20);
-  if (const char *e = getenv("MCX_MULTI_PIECE")) G->max_pos = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));  // tests
+  G->max_pos = max_pos;
   if (G->v3) {
-    // ~2.3 records per 16 positions on random reads; room for 3: what does not fit a segment goes to the
-    // sender's spill area and is routed by the host.  A record is a run of >= 1 k-mers, so a piece yields at most
-    // one record per start position: a spill area of max_pos records cannot overflow WHATEVER the input is -- one
-    // owner taking everything, or an owner change at every k-mer (512 MiB per send set at k <= 31; until round 5 it
-    // held 4 records per 16 positions and an input beyond that ended in MCX_ERR_FULL where one GPU succeeds).
-    const uint64_t recb = 16ull * W;
     G->sk_segs = kSuperkRep;
-    G->sk_cap = G->max_pos * 3 / 16 / ((uint64_t)N * G->sk_segs) + 4096;
-    G->sp_cap = G->max_pos + 16;
+    G->sk_cap = max_pos * 3 / 16 / ((uint64_t)N * G->sk_segs) + 4096;
+    G->sp_cap = max_pos + 16;
     if (const char *e = getenv("MCX_MULTI_SKCAP")) G->sk_cap = std::max<uint64_t>(16, strtoull(e, nullptr, 10));  // tests: force the spill path
-    G->send.resize(N);
-    G->recv.assign(N, std::vector<std::array<XBuf, kSets>>(N));
-    G->h_spill.assign(N, {});
-    G->spill_colour.assign(N, {});
+    return MCX_OK;
+  }
+  const uint32_t b1 = 1u << g0->t.lb1;
+  G->segs = kShardRep * b1;
+  const double mean = (double)max_pos / ((double)N * G->segs);
+  G->seg_cap = ((uint64_t)(mean + 8.0 * sqrt(mean + 1.0)) + 64 + 1) & ~1ull;
+  G->ov_cap = (std::max<uint64_t>(1u << 16, max_pos / (uint64_t)N / 16) + 15) & ~15ull;  // (16-byte aligned edge-byte rows: k_copy_filled)
+  G->sp_cap = max_pos;
+  // k_copy_filled addresses segment js at js * ceil(cap * item_bytes / 16) 16-byte units: that is the real stride
+  // only when a segment is a whole number of units
+  if ((G->seg_cap * 8 * W) % 16 || (G->ov_cap * 8 * W) % 16 || G->ov_cap % 16)
+    return fail(MCX_ERR_ARG, "internal: exchange segment stride is not a multiple of 16 bytes (seg_cap %llu, ov_cap %llu)",
+                (unsigned long long)G->seg_cap, (unsigned long long)G->ov_cap);
+  return MCX_OK;
+}
+
+// HBM the exchange buffers of the present layout take on ONE device: kSets send sets + its receive slots for all N senders.
+// With the default piece (128 Mi positions) at 8 devices: 8.7 GB (v3, k <= 31), 14.5 GB (v3, k = 63), 11 GB (v2, k <= 31),
+// of which the spill areas are 6.4 / 12.9 / 3.4 GB -- the price of "no input can overflow".
+static uint64_t group_buffer_bytes(const mcx_group *G)
+{
+  const uint64_t N = (uint64_t)G->n, W = (uint64_t)G->part[0]->W;
+  if (G->v3) {
+    const uint64_t recb = 16 * W, blk_recs = (uint64_t)G->sk_segs * G->sk_cap;
+    const uint64_t send = N * blk_recs * recb + 2 * N * G->sk_segs * 8 + G->sp_cap * (recb + 1) + 8;
+    const uint64_t recv = N * (blk_recs * recb + (uint64_t)G->sk_segs * 8);
+    return kSets * (send + recv);
+  }
+  const uint64_t blk = (uint64_t)G->segs * G->seg_cap;
+  const uint64_t send = N * blk * 8 * W + N * G->segs * 8 + (N * G->ov_cap + G->sp_cap) * (8 * W + 1) + (N + 2) * 8;
+  const uint64_t recv = N * (blk * 8 * W + (uint64_t)G->segs * 8 + G->ov_cap * (8 * W + 1) + 8);
+  return kSets * (send + recv);
+}
+
+static int group_alloc_buffers(mcx_group *G)
+{
+  const int N = G->n, W = G->part[0]->W;
+  G->send.clear(); G->recv.clear();  // (a failed attempt has been released by group_free_buffers)
+  G->send.resize(N);
+  G->recv.assign(N, std::vector<std::array<XBuf, kSets>>(N));
+  G->h_spill.assign(N, {});
+  G->spill_colour.assign(N, {});
+  if (G->v3) {
+    const uint64_t recb = 16ull * W;
     const uint64_t blk_recs = (uint64_t)G->sk_segs * G->sk_cap;
     for (int i = 0; i < N; i++) {
       GRP_TRY(hipSetDevice(G->part[i]->device));
@@ -159,26 +196,8 @@ static int group_ensure_buffers(mcx_group *G)
         }
       }
     }
-    G->buffers = true;
     return MCX_OK;
   }
-  const uint32_t b1 = 1u << g0->t.lb1;
-  G->segs = kShardRep * b1;
-  const double mean = (double)G->max_pos / ((double)N * G->segs);
-  // mean + 8 sigma of the Poisson fill + room for a short run of one k-mer; what does not fit goes
-  // to the owner's overflow bin (hot k-mers), and beyond that raises MCX_ERR_FULL on the sender
-  G->seg_cap = ((uint64_t)(mean + 8.0 * sqrt(mean + 1.0)) + 64 + 1) & ~1ull;
-  G->ov_cap = (std::max<uint64_t>(1u << 16, G->max_pos / (uint64_t)N / 16) + 15) & ~15ull;  // (16-byte aligned edge-byte rows: k_copy_filled)
-  G->sp_cap = G->max_pos;
-  // k_copy_filled addresses segment js at js * ceil(cap * item_bytes / 16) 16-byte units: that is the real stride
-  // only when a segment is a whole number of units
-  if ((G->seg_cap * 8 * W) % 16 || (G->ov_cap * 8 * W) % 16 || G->ov_cap % 16)
-    return fail(MCX_ERR_ARG, "internal: exchange segment stride is not a multiple of 16 bytes (seg_cap %llu, ov_cap %llu)",
-                (unsigned long long)G->seg_cap, (unsigned long long)G->ov_cap);
-  G->send.resize(N);
-  G->h_spill.assign(N, {});
-  G->spill_colour.assign(N, {});
-  G->recv.assign(N, std::vector<std::array<XBuf, kSets>>(N));
   const uint64_t blk = (uint64_t)G->segs * G->seg_cap;  // tuples of one owner's block
   for (int i = 0; i < N; i++) {
     GRP_TRY(hipSetDevice(G->part[i]->device));
@@ -201,6 +220,33 @@ static int group_ensure_buffers(mcx_group *G)
         GRP_TRY(hipMalloc((void **)&r.ov_counts, 8));
       }
     }
+  }
+  return MCX_OK;
+}
+
+static uint64_t group_default_piece()
+{
+  uint64_t max_pos = std::max<uint64_t>(kStageBytes + kCarry, 32ull << 20);  // a staged chunk of mcx_graph_add_reads is one piece
+  if (const char *e = getenv("MCX_MULTI_PIECE")) max_pos = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));  // tests
+  return max_pos;
+}
+
+// Exchange buffers, allocated on first use.  A piece covers at most max_pos start positions: a staged chunk of
+// mcx_graph_add_reads (128 Mi positions by default) is one piece, longer device streams are cut to this size.  When the
+// buffers do not fit beside the tables -- they are allocated after the tables and the partition workspace -- the piece
+// is halved (down to 8 Mi positions: more launches per chunk, same result) instead of failing the build.
+static int group_ensure_buffers(mcx_group *G)
+{
+  if (G->buffers) return MCX_OK;
+  for (uint64_t max_pos = group_default_piece();; max_pos /= 2) {
+    int rc = group_layout(G, max_pos);
+    if (rc != MCX_OK) return rc;
+    rc = group_alloc_buffers(G);
+    if (rc == MCX_OK) break;
+    group_free_buffers(G);
+    if (rc != MCX_ERR_NOMEM || max_pos / 2 < (8ull << 20)) return rc;
+    (void)hipGetLastError();
+    if (getenv("MCX_TIMING")) fprintf(stderr, "[timing] exchange buffers for pieces of %llu positions do not fit: halving the piece\n", (unsigned long long)max_pos);
   }
   G->buffers = true;
   return MCX_OK;
@@ -466,6 +512,110 @@ static void group_destroy(mcx_group *G)
   delete G;
 }
 
+// Peer self-test at start-up: the can-access-peer matrix as the runtime reports it, and for every ordered pair of
+// distinct devices ONE k_copy_filled launch on the sender's copy stream that writes a pattern and its fill into a
+// buffer on the owner's device through the peer-mapped pointer, read back from the owner.  A pair that fails turns
+// the kernel copy off for the whole group (hipMemcpyPeerAsync of whole blocks instead: what MCX_MULTI_COPY=memcpy
+// selects by hand) and says so once on stderr -- a build must not find out at its first piece, or not at all, that
+// stores to a peer do not land.  (A fault inside the kernel cannot be caught here: on a node where peer mappings are
+// broken outright, MCX_MULTI_COPY=memcpy skips the test.)  MCX_TIMING=1 prints the matrix.
+static void group_peer_selftest(mcx_group *G, const int *devices)
+{
+  const int N = G->n;
+  const bool verbose = getenv("MCX_TIMING") != nullptr;
+  bool distinct = false;
+  for (int i = 0; i < N; i++) for (int j = 0; j < i; j++) if (devices[i] != devices[j]) distinct = true;
+  if (!distinct) return;
+  if (verbose) {
+    fprintf(stderr, "[timing] peer access (row = from device, column = to device; 1 = mapped):\n");
+    for (int i = 0; i < N; i++) {
+      fprintf(stderr, "[timing]   %2d:", devices[i]);
+      for (int j = 0; j < N; j++) {
+        int can = devices[i] == devices[j];
+        if (!can) (void)hipDeviceCanAccessPeer(&can, devices[i], devices[j]);
+        fprintf(stderr, " %d", can);
+      }
+      fprintf(stderr, "\n");
+    }
+  }
+  if (!group_copy_kernel(G)) {
+    if (!G->peer_ok) fprintf(stderr, "mcx: not every pair of the %d devices can map each other's memory: copies between the shards use hipMemcpyPeerAsync\n", N);
+    return;
+  }
+  constexpr uint32_t kItems = 1024;  // 16 KiB of 16-byte items
+  std::vector<ulonglong2> pat(kItems), back(kItems);
+  const char *why = nullptr;
+  int bad_i = -1, bad_j = -1;
+  for (int i = 0; i < N && !why; i++)
+    for (int j = 0; j < N && !why; j++) {
+      if (devices[i] == devices[j]) continue;
+      bool seen = false;  // (a device named twice: test each ordered pair of DEVICES once)
+      for (int a = 0; a < i; a++) for (int b = 0; b < N; b++) if (devices[a] == devices[i] && devices[b] == devices[j]) seen = true;
+      for (int b = 0; b < j; b++) if (devices[b] == devices[j]) seen = true;
+      if (seen) continue;
+      ulonglong2 *src = nullptr, *dst = nullptr;
+      unsigned long long *fsrc = nullptr, *fdst = nullptr;
+      const unsigned long long fill = kItems - 3, zero = 0;
+      for (uint32_t t = 0; t < kItems; t++) pat[t] = make_ulonglong2(0x9E3779B97F4A7C15ull * (t + 1) + (uint64_t)i, ((uint64_t)i << 32 | (uint64_t)j) ^ t);
+      auto ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && !why) { why = what; (void)hipGetLastError(); } return e == hipSuccess; };
+      bool good = ok(hipSetDevice(devices[j]), "hipSetDevice") && ok(hipMalloc((void **)&dst, kItems * 16), "hipMalloc") && ok(hipMalloc((void **)&fdst, 8), "hipMalloc") &&
+                  ok(hipMemset(dst, 0, kItems * 16), "hipMemset") && ok(hipMemcpy(fdst, &zero, 8, hipMemcpyHostToDevice), "hipMemcpy") &&
+                  ok(hipSetDevice(devices[i]), "hipSetDevice") && ok(hipMalloc((void **)&src, kItems * 16), "hipMalloc") && ok(hipMalloc((void **)&fsrc, 8), "hipMalloc") &&
+                  ok(hipMemcpy(src, pat.data(), kItems * 16, hipMemcpyHostToDevice), "hipMemcpy") && ok(hipMemcpy(fsrc, &fill, 8, hipMemcpyHostToDevice), "hipMemcpy");
+      if (good) {
+        PeerDst pd{};
+        pd.data[0] = dst; pd.fills[0] = fdst;
+        hipLaunchKernelGGL(k_copy_filled, dim3(4), dim3(256), 0, G->cs[i], (const ulonglong2 *)src, (const unsigned long long *)fsrc, pd, 1u, 1u, (uint64_t)kItems, 16u);
+        good = ok(hipGetLastError(), "k_copy_filled launch") && ok(hipStreamSynchronize(G->cs[i]), "k_copy_filled over a peer mapping");
+      }
+      unsigned long long got_fill = 0;
+      if (good) good = ok(hipSetDevice(devices[j]), "hipSetDevice") && ok(hipMemcpy(back.data(), dst, kItems * 16, hipMemcpyDeviceToHost), "read back") &&
+                       ok(hipMemcpy(&got_fill, fdst, 8, hipMemcpyDeviceToHost), "read back");
+      if (good && (got_fill != fill || memcmp(back.data(), pat.data(), (size_t)fill * 16) != 0)) { why = "the stores did not land (pattern mismatch)"; good = false; }
+      if (!good) { bad_i = devices[i]; bad_j = devices[j]; }
+      (void)hipSetDevice(devices[i]); (void)hipFree(src); (void)hipFree(fsrc);
+      (void)hipSetDevice(devices[j]); (void)hipFree(dst); (void)hipFree(fdst);
+    }
+  if (why) {
+    G->peer_ok = false;
+    fprintf(stderr, "mcx: peer self-test failed from device %d to device %d (%s): copies between the shards fall back to hipMemcpyPeerAsync "
+                    "(MCX_MULTI_COPY=memcpy selects that without the test)\n", bad_i, bad_j, why);
+  } else if (verbose) {
+    fprintf(stderr, "[timing] peer self-test: k_copy_filled round trip passed for every ordered pair of devices\n");
+  }
+  (void)hipSetDevice(devices[0]);
+}
+
+// HBM per device that the exchange buffers of an N-device table will take (sizing: host/cmd_build.c adds it to the
+// table when it checks -m / -n against the free HBM).  Same arithmetic as group_ensure_buffers' first attempt.
+extern "C" int mcx_multi_exchange_bytes(int kmer_size, int ndevices, uint64_t capacity_kmers, uint64_t *bytes_per_device)
+{
+  if (!bytes_per_device) return fail(MCX_ERR_ARG, "null result pointer");
+  *bytes_per_device = 0;
+  if (ndevices <= 1) return MCX_OK;
+  if (ndevices > 32 || (ndevices & (ndevices - 1))) return fail(MCX_ERR_ARG, "the number of devices must be a power of two <= 32 (got %d)", ndevices);
+  if (check_k(kmer_size) != MCX_OK) return MCX_ERR_ARG;
+  mcx_group G;
+  mcx_graph proto;
+  proto.k = kmer_size; proto.W = words_for_k(kmer_size);
+  const char *e = getenv("MCX_MULTI_EXCHANGE");
+  G.n = ndevices;
+  G.v3 = mcx_superk_supported(kmer_size) && !(e && !strcmp(e, "v2"));
+  G.part.assign(1, &proto);
+  if (!G.v3) {  // the region count of a shard's table decides the segment count
+    const uint64_t min_shard = 64ull << sub_shift_for_words(proto.W);
+    const uint64_t per = std::max<uint64_t>((capacity_kmers + (uint64_t)ndevices - 1) / (uint64_t)ndevices, min_shard);
+    const uint64_t sub_slots = 1ull << sub_shift_for_words(proto.W);
+    uint32_t lbo = 0;
+    while ((1 << lbo) < ndevices) lbo++;
+    proto.t.lb1 = region_bits((std::max<uint64_t>(per, 1024) + sub_slots - 1) / sub_slots, lbo);
+  }
+  int rc = group_layout(&G, group_default_piece());
+  if (rc == MCX_OK) *bytes_per_device = group_buffer_bytes(&G);
+  G.part.clear();
+  return rc;
+}
+
 extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols, uint64_t capacity_kmers,
                                       const int *devices, int ndevices)
 {
@@ -531,6 +681,7 @@ extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols,
       for (int b = 0; b < kSets; b++) MK_TRY(hipEventCreateWithFlags(&G->consumed[j][i][b], hipEventDisableTiming));
   }
 #undef MK_TRY
+  group_peer_selftest(G, devices);
   mcx_graph *f = new mcx_graph();  // the facade: no device state of its own
   f->k = kmer_size; f->W = W; f->ncols = ncols; f->ncols_vis = ncols;
   f->device = devices[0];

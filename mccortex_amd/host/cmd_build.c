@@ -652,13 +652,19 @@ int ctx_build(int argc, char **argv)
   const size_t dev_cols = ncols + (ngisec > 0 ? 1 : 0); /* + the hidden colour of the intersection edges */
   /* per device: its share of the table (+ the read-start table of --remove-pcr, + the overflow area) */
   const uint64_t dev_bytes = (kmers_in_hash / (uint64_t)ndevices + kmers_in_hash / (uint64_t)ndevices / 32) * 8 * (W + dev_cols + (remove_pcr_used ? 1 : 0));
+  uint64_t xchg_bytes = 0; /* exchange buffers between the devices of a split table (0 on one device) */
+  mcx_check(mcx_multi_exchange_bytes((int)kmer_size, ndevices, kmers_in_hash, &xchg_bytes), "exchange sizing");
   for (int d = 0; d < ndevices; d++) {
     uint64_t hbm_free = 0, hbm_total = 0;
     mcx_check(mcx_device_memory(devices[d], &hbm_free, &hbm_total), "device query");
     if (dev_bytes > hbm_free)
       die("Requesting more memory than is available [ Reqeusted: %s HBM free: %s ]",
           bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_free, 1, s2));
+    if (xchg_bytes && dev_bytes + xchg_bytes > hbm_free)
+      warn("device %d: table %s + exchange buffers %s exceed the free HBM: the exchange will run in smaller pieces",
+           devices[d], bytes_to_str(dev_bytes, 1, s1), bytes_to_str(xchg_bytes, 1, s2));
     status("[memory] device %d: table %s of %s HBM\n", devices[d], bytes_to_str(dev_bytes, 1, s1), bytes_to_str(hbm_total, 1, s2));
+    if (xchg_bytes) status("[memory] device %d: exchange buffers %s\n", devices[d], bytes_to_str(xchg_bytes, 1, s1));
   }
 
   /* ---- output path (futil_create_output: file_util.c:164-186) ---- */

@@ -74,29 +74,53 @@ def test_tool_matches_oracle(mcx, orc, tmp_path, k, exchange, world):
 
 
 def test_bench_two_ranks_strong_reproduces_the_single_gpu_graph(mcx, tmp_path):
-    """bench.py --gpus 2 (strong scaling = BASELINE config C3: the N = 1 reads dealt out to the ranks, the N = 1 table
-    split 2 ways) as two processes on cuda:0: the sum of the ranks' graph checksums and node counts must be what the
-    N = 1 run of the same steps reports, and the line must carry the per-rank stage table."""
+    """`python bench.py --gpus 2` AS THE DRIVER TYPES IT -- a plain subprocess, no launcher: bench.py starts its two ranks
+    itself -- on cuda:0 through the test transport.  Strong scaling = BASELINE config C3 (the N = 1 reads dealt out to the
+    ranks, the N = 1 table split 2 ways): one JSON line that times BOTH exchange formats and the C5 pass (4 colours);
+    the sum of the ranks' graph checksums and node counts must be what the N = 1 run of the same steps reports in either
+    format, and the coloured graph must be the one a single rank builds."""
     import json
     # (--defer-tuples: two ranks and this pytest process share the one device's HBM here)
     common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batch-reads", "1000000", "--defer-tuples", "1000000000"]
     e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
-    one = json.loads(p.stdout.decode().strip().splitlines()[-1])
-    for exchange in ("v3", "v2"):
-        rc, out, err = _launch(2, 29851 + (exchange == "v2"), ["bench.py", "--gpus", "2", "--scaling", "strong"] + common, env={"MCX_EXCHANGE": exchange})
-        assert rc == 0, err[-3000:]
-        two = json.loads(out.strip().splitlines()[-1])
-        assert two["n_gpus"] == 2 and two["scaling"] == "strong"
-        assert two["config"]["graph_checksum"] == one["config"]["graph_checksum"], exchange
-        assert two["config"]["distinct_kmers_total"] == one["config"]["distinct_kmers_total"]
-        assert two["config"]["kmers_inserted"] == one["config"]["kmers_inserted"]
-        ranks = two["multi_gpu"]["per_rank"]
-        assert [r["rank"] for r in ranks] == [0, 1] and two["multi_gpu"]["exchange_format"] == exchange
-        assert sum(r["kmers_kmerised"] for r in ranks) == one["config"]["kmers_inserted"]
-        for r in ranks:
-            assert r["link_bytes_sent"] > 0 and r["exchange_steps"] == 1 and {"sender", "insert"} <= set(r["stage_ms"])
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(v, None)
+
+    def bench(n, env=None):
+        p = subprocess.run([sys.executable, "bench.py", "--gpus", str(n)] + common, cwd=ROOT, env=dict(e, **(env or {})),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+        assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+        lines = p.stdout.decode().strip().splitlines()
+        assert len(lines) == 1, lines[:3]   # ONE JSON line on stdout
+        return json.loads(lines[0])
+
+    one = bench(1)
+    ref = bench(1, {"MCX_BENCH_FORCE_SHARD": "1", "MASTER_PORT": "29853"})   # the N > 1 code with one rank (RCCL): its C5 graph is the reference
+    two = bench(2, ONE_GPU)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["steps"] == 2
+    cfg = two["config"]
+    assert set(cfg["exchange_formats"]) >= {"v3", "v2"} and cfg["formats_agree"] is True
+    for fmt in ("v3", "v2"):
+        r = cfg["exchange_formats"][fmt]
+        assert r["graph_checksum"] == one["config"]["graph_checksum"], fmt
+        assert r["distinct_kmers_total"] == one["config"]["distinct_kmers_total"]
+        assert r["kmers_inserted"] == one["config"]["kmers_inserted"]
+        assert r["fallback_inserts_total"] == 0
+        ranks = r["per_rank"]
+        assert [x["rank"] for x in ranks] == [0, 1]
+        assert sum(x["kmers_kmerised"] for x in ranks) == one["config"]["kmers_inserted"]
+        for x in ranks:
+            assert x["link_bytes_sent"] > 0 and x["exchange_steps"] == 1 and {"sender", "insert"} <= set(x["stage_ms"])
+    assert cfg["exchange_formats"]["v3"]["link_bytes_per_occurrence"] < cfg["exchange_formats"]["v2"]["link_bytes_per_occurrence"]
+    assert two["value"] == max(cfg["exchange_formats"][f]["value"] for f in ("v3", "v2"))
+    assert two["multi_gpu"]["exchange_format"] == cfg["exchange_format"] and cfg["summary"]["formats_agree"] is True
+    c5 = cfg["C5"]
+    assert c5["colours"] == 4 and c5["nodes_and_kmers_match_one_colour"] is True
+    assert [x["rank"] for x in c5["per_rank"]] == [0, 1]
+    rc5 = ref["config"]["C5"]
+    assert ref["config"]["graph_checksum"] == one["config"]["graph_checksum"]
+    assert (c5["graph_checksum"], c5["distinct_kmers_total"], c5["kmers_inserted"]) == (rc5["graph_checksum"], rc5["distinct_kmers_total"], rc5["kmers_inserted"])
+    assert c5["graph_checksum"] != one["config"]["graph_checksum"]   # (colours are part of a record)
 
 
 @pytest.mark.parametrize("use_v3", [True, False])
