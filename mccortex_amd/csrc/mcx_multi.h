@@ -149,8 +149,8 @@ static int group_layout(mcx_group *G, uint64_t max_pos)
 }
 
 // HBM the exchange buffers of the present layout take on ONE device: kSets send sets + its receive slots for all N senders.
-// With the default piece (128 Mi positions) at 8 devices: 8.7 GB (v3, k <= 31), 14.5 GB (v3, k = 63), 11 GB (v2, k <= 31),
-// of which the spill areas are 6.4 / 12.9 / 3.4 GB -- the price of "no input can overflow".
+// With the default piece (128 Mi positions): 9.3 GB (v3, k <= 31), 18.2 GB (v3, k = 63), 11.1 GB (v2, k <= 31) whatever
+// the number of devices, of which the spill areas are 6.8 / 13.3 / 3.6 GB -- the price of "no input can overflow".
 static uint64_t group_buffer_bytes(const mcx_group *G)
 {
   const uint64_t N = (uint64_t)G->n, W = (uint64_t)G->part[0]->W;

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
     "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash", "mcx_pack_bases", "mcx_pack_reads_host", "mcx_pack_stream_dev", "mcx_graph_add_packed_dev",
-    "mcx_ubench_stream", "mcx_ubench_random_rmw", "mcx_graph_insert_stats",
+    "mcx_ubench_stream", "mcx_ubench_random_rmw", "mcx_graph_insert_stats", "mcx_multi_exchange_bytes",
 ]
 
 
@@ -419,6 +419,17 @@ def records_sorted(recs, kmer_size, ncols, device=0):
 
 def superk_supported(kmer_size):
     return bool(lib().mcx_superk_supported(kmer_size))
+
+
+def multi_exchange_bytes(kmer_size, ndevices, capacity_kmers):
+    """HBM per device that the exchange buffers of an N-device table take (mcx_multi_exchange_bytes; no GPU needed)"""
+    out = C.c_uint64(0)
+    L = lib()
+    L.mcx_multi_exchange_bytes.argtypes = [C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]
+    rc = L.mcx_multi_exchange_bytes(kmer_size, ndevices, capacity_kmers, C.byref(out))
+    if rc != 0:
+        raise McxError(rc, L.mcx_last_error().decode())
+    return int(out.value)
 
 
 def superk_record_words(kmer_size):

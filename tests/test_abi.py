@@ -157,3 +157,15 @@ def test_one_pass_read_packer_matches_assemble_then_pack(mcx):
         assert np.array_equal(out[0][1], out[1][1]), "invalid flags, case %d" % case
         # codes only have to agree where a position is valid; the packers agree everywhere, which is simpler to state
         assert np.array_equal(out[0][0], out[1][0]), "codes, case %d" % case
+
+
+def test_multi_exchange_bytes_sizing(mcx):
+    """mcx_multi_exchange_bytes (no GPU needed): what the build command adds to the table when it checks -m / -n against
+    the free HBM of every device of a split table"""
+    assert mcx.multi_exchange_bytes(31, 1, 1 << 30) == 0
+    v3 = mcx.multi_exchange_bytes(31, 8, 1 << 30)
+    assert 8e9 < v3 < 11e9                                   # 3 send + 3 x 8 receive sets of a 128 Mi-position piece
+    assert mcx.multi_exchange_bytes(63, 8, 1 << 30) > 1.8 * v3  # 32-byte records
+    assert 9e9 < mcx.multi_exchange_bytes(21, 8, 1 << 30) < 13e9  # k < 29: format v2 (packed tuples)
+    with pytest.raises(mcx.McxError):
+        mcx.multi_exchange_bytes(31, 3, 1 << 30)
