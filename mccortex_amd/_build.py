@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcxgpu.so")
-SOURCES = ["mcx_api.hip", "mcx_kernels.h", "mcx_kmer.h", "mcx_defer.h", "mcx_superk.h", "mcx_multi.h", "mcx_ubench.h"]
+SOURCES = ["mcx_api.hip", "mcx_kernels.h", "mcx_kmer.h", "mcx_defer.h", "mcx_superk.h", "mcx_streamfc.h", "mcx_multi.h", "mcx_ubench.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

@@ -26,6 +26,7 @@
 #include "../../include/mcx_gpu.h"
 #include "mcx_kernels.h"
 #include "mcx_superk.h"
+#include "mcx_streamfc.h"
 #include "mcx_ubench.h"
 
 using namespace mcx;
@@ -188,7 +189,7 @@ struct mcx_graph {
   uint32_t nsub = 0;            // sub-tables
   uint32_t b1 = 0, subs_per_bin = 0;
   uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 (replica, bin) segment / per L2 (sub-table) bin
-  uint32_t rep1 = 8;            // replicas of every L1 bin (one per XCD)
+  uint32_t rep1 = 8;            // replicas of every L1 bin (one per XCD); MCX_REP1: experiments (k_stream_fc with private replicas)
   uint64_t *l1_keys = nullptr, *l2_keys = nullptr;  // packed tuples: W words each
   uint64_t l2_off = 0;            // first sub-table bin the next split / insert launch uses (flush overlap: two halves)
   hipStream_t stream2 = nullptr;  // flush overlap: the LDS insert of group g runs beside the split of group g + 1
@@ -395,6 +396,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   g->t.max_probe = (uint32_t)sub_slots;  // a probe sequence never leaves its sub-table
   { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
   { const char *e = getenv("MCX_GRID_STREAM"); if (e) g->grid_stream = atoi(e); }  // experiments
+  { const char *e = getenv("MCX_REP1"); if (e && atoi(e) >= 1 && atoi(e) <= 4096) g->rep1 = (uint32_t)atoi(e); }
   { const char *e = getenv("MCX_GRID_SPLIT"); if (e) g->grid_split = atoi(e); }
   { const char *e = getenv("MCX_GRID_INSERT"); if (e) g->grid_insert = atoi(e); }
   g->table_bytes = slots * g->t.S * 8;
@@ -592,6 +594,21 @@ static void launch_bin_stream_pk(mcx_graph *g, const StreamArgs &a, uint64_t nt,
   SpanGuard sp(g, "k_stream_bin");
   // region bins of an unsharded one-word table: 512-thread blocks, two tiles sorted as one (MCX_STREAM_T=256: the old geometry)
   if constexpr (W == 1 && !FULL && SH == 0) {
+    // MCX_STREAM_FC=1: fixed-capacity LDS segments instead of the LDS sort (mcx_streamfc.h; an experiment of round 6 that
+    // lost to the sort -- profiles/r06_experiments.md -- and is kept compiled for the record: 30.3 against 22.0 ms at C2)
+    static const int fc_cap = [] { const char *e = getenv("MCX_STREAM_FC"); return e ? atoi(e) : 0; }();
+    if (fc_cap && bs.nlocal <= 512) {
+      const dim3 gridf((unsigned)std::min<uint64_t>(nt, (uint64_t)(g->grid_stream ? g->grid_stream : g->grid)));
+#define MCX_FC_LAUNCH(CAPV, PRIVV) { \
+        static bool once_f[64] = {false}; \
+        if (!once_f[g->device & 63]) { allow_lds(k_stream_fc<ONECOL, PK, CAPV, PRIVV>, sizeof(FcLds<CAPV>)); once_f[g->device & 63] = true; } \
+        hipLaunchKernelGGL((k_stream_fc<ONECOL, PK, CAPV, PRIVV>), gridf, dim3(kThreads), sizeof(FcLds<CAPV>), g->stream, a, bs, out, is); }
+      // (private replicas: one per block of the launch -- MCX_REP1 >= the grid)
+      if (bs.rep >= gridf.x && bs.rep > 8) MCX_FC_LAUNCH(10, true)
+      else MCX_FC_LAUNCH(10, false)
+#undef MCX_FC_LAUNCH
+      return;
+    }
     static const bool wide = [] { const char *e = getenv("MCX_STREAM_T"); return !e || atoi(e) == 512; }();
     if (wide && bs.nlocal <= 512) {
       using GeoW = Geo<512, 512 * kPosPerLane>;

@@ -22,6 +22,12 @@ NAMES = {
 }
 
 
+if os.environ.get("MCX_STREAM_FC", "0") not in ("", "0"):  # k_stream_fc (mcx_streamfc.h) in place of k_stream_bin
+    NAMES[0] = ("k_stream_fc", ["masks + 16 positions + 16 segment stores", "pool append", "barrier after k-merising",
+                                "reservations issued + next tile staged + pool drained", "wait for reservations + copy-out",
+                                "end barrier", "loop top", "tiles"])
+
+
 def report(L, title):
     buf = (C.c_uint64 * 24)()
     assert L.mcx_debug_phases(buf, 1) == 0
