@@ -1079,11 +1079,18 @@ def main():
     ap.add_argument("--err", type=float, default=0.001, help="experiments only")
     ap.add_argument("--iid", action="store_true", help="experiments only: C2-stress, iid random reads (every k-mer novel)")
     ap.add_argument("--direct", action="store_true", help="insert with HBM atomics instead of partition + LDS insert")
-    ap.add_argument("--defer-tuples", type=int, default=DEFER_TUPLES)
+    ap.add_argument("--defer-tuples", type=int, default=0,
+                    help="k-mer occurrences buffered per flush; default: the whole timed region in ONE flush (one pass over the "
+                         "table) when that fits 16 G occurrences = 136 GB of the part's 288 GB, never below %d" % DEFER_TUPLES)
     ap.add_argument("--inprocess-multi", type=int, default=0,
                     help="(used by the N > 1 run itself, as a subprocess) the C ABI's one-process table over devices 0..N-1 "
                          "(mcx_graph_create_multi: what `mccortex31 build -D 0,1,..` runs) on the same reads; prints its own JSON line")
     args = ap.parse_args()
+    if not args.defer_tuples:
+        # one flush for the timed region (20 steps x 5 M reads = 12 G occurrences -> 12.4 G): the part has the HBM for it
+        # (bins 8.5 B per occurrence), and every flush streams the 16 GiB table through LDS once
+        occ = args.steps * args.batch_reads * (READ_LEN - K + 1)
+        args.defer_tuples = max(DEFER_TUPLES, min(int(occ * 1.03), 16_000_000_000))
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 (make,
     # RCCL's version banner, ...) is sent to stderr

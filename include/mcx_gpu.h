@@ -226,6 +226,16 @@ int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void *d_keys,
 /* Owner of a canonical key in the exchange above (host-side helper for tests). */
 uint32_t mcx_key_owner(const uint64_t *key_words, int kmer_size, int nparts);
 
+/* `mccortex<K> hashtest` (src/commands/ctx_exp_hashtest.c:40-69: `bkmer.b[0] = i; hash_table_find_or_insert(...)`):
+ * find-or-insert of the n BinaryKmers whose most significant word is i, i in [first, first + n), all other words 0 --
+ * generated on the device, no edges, colour 0.  Ends with the table drained (mcx_graph_sync); MCX_ERR_FULL when the
+ * table cannot hold them. */
+int mcx_graph_hashtest(mcx_graph *g, uint64_t first, uint64_t n);
+/* The command's -F mode (hash function only, nothing stored): the reference splits [0, n) into `nparts` ranges
+ * (one per thread: range i starts at i * (n / nparts), the last one ends at n), XORs binary_kmer_hash(bkmer, 0) =
+ * bklk3_hashlittle over each range and ADDS the ranges' results (ctx_exp_hashtest.c:61-66,160-175). */
+int mcx_hashtest_func(int device, int kmer_size, uint64_t n, uint32_t nparts, uint64_t *hash_out);
+
 /* Like mcx_graph_insert_tuples_dev for tuples that sit in `nseg` segments of `seg_cap` slots with
  * the fills in device memory (d_counts[nseg], u64; a fill above seg_cap is read as seg_cap), so the
  * caller needs no host round trip to learn how many arrived: the overflow bins of the sharded

@@ -1324,6 +1324,83 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
   return MCX_OK;
 }
 
+// ---- `hashtest` (src/commands/ctx_exp_hashtest.c:40-69) ----
+template <int W> __global__ void k_hashtest_keys(uint64_t *keys, uint64_t first, uint64_t n)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    keys[i * W] = first + i;  // bkmer.b[0] = i
+    if (W == 2) keys[i * W + 1] = 0;
+  }
+}
+template <int W> __global__ void k_hashtest_func(uint64_t lo, uint64_t hi, unsigned int *out)
+{
+  uint32_t h = 0;
+  for (uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * blockDim.x) {
+    Kmer<W> key;
+    key.w[0] = i;
+    if (W == 2) key.w[W - 1] = 0;
+    h ^= kmer_hash<W>(key, 0, nullptr);
+  }
+  for (int d = 32; d; d >>= 1) h ^= __shfl_xor(h, d, 64);
+  if ((threadIdx.x & 63) == 0 && h) atomicXor(out, h);
+}
+
+extern "C" int mcx_graph_hashtest(mcx_graph *g, uint64_t first, uint64_t n)
+{
+  NO_GROUP(g, "mcx_graph_hashtest");
+  if (!g) return fail(MCX_ERR_ARG, "null graph");
+  if (first + n < first) return fail(MCX_ERR_ARG, "key range wraps");
+  HIP_TRY(hipSetDevice(g->device));
+  const uint64_t chunk = std::min<uint64_t>(n, 1ull << 26);  // 64 M keys = 512 MiB (W = 1) of scratch
+  if (!chunk) return mcx_graph_sync(g);
+  uint64_t *d_keys = nullptr;
+  uint8_t *d_edges = nullptr;
+  if (hipMalloc((void **)&d_keys, chunk * 8 * g->W) != hipSuccess || hipMalloc((void **)&d_edges, chunk) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(d_keys); (void)hipFree(d_edges);
+    return fail(MCX_ERR_NOMEM, "out of device memory for the hashtest key buffer");
+  }
+  int rc = MCX_OK;
+  if (hipMemsetAsync(d_edges, 0, chunk, g->stream) != hipSuccess) rc = fail(MCX_ERR_HIP, "hipMemsetAsync failed");
+  for (uint64_t lo = 0; lo < n && rc == MCX_OK; lo += chunk) {
+    const uint64_t cnt = std::min(chunk, n - lo);
+    if (g->W == 1) hipLaunchKernelGGL(k_hashtest_keys<1>, dim3(4096), dim3(256), 0, g->stream, d_keys, first + lo, cnt);
+    else hipLaunchKernelGGL(k_hashtest_keys<2>, dim3(4096), dim3(256), 0, g->stream, d_keys, first + lo, cnt);
+    rc = mcx_graph_insert_tuples_dev(g, 0, d_keys, d_edges, cnt);
+    // (the binning kernel that reads the buffer runs on the same stream as the generator of the next chunk)
+  }
+  const int rc2 = mcx_graph_sync(g);
+  (void)hipFree(d_keys); (void)hipFree(d_edges);
+  return rc != MCX_OK ? rc : rc2;
+}
+
+extern "C" int mcx_hashtest_func(int device, int kmer_size, uint64_t n, uint32_t nparts, uint64_t *hash_out)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(MCX_ERR_NODEVICE, "no HIP device %d", device);
+  if (kmer_size < 3 || kmer_size > 63 || !(kmer_size & 1)) return fail(MCX_ERR_ARG, "kmer size %d", kmer_size);
+  if (!nparts || !hash_out) return fail(MCX_ERR_ARG, "nparts / hash_out");
+  HIP_TRY(hipSetDevice(device));
+  unsigned int *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, (size_t)nparts * 4));
+  std::vector<unsigned int> h(nparts, 0);
+  bool ok = hipMemset(d, 0, (size_t)nparts * 4) == hipSuccess;
+  const int W = words_for_k(kmer_size);
+  for (uint32_t p = 0; p < nparts && ok; p++) {
+    const uint64_t lo = (uint64_t)p * (n / nparts), hi = p + 1 == nparts ? n : lo + n / nparts;
+    if (hi <= lo) continue;
+    const unsigned grid = (unsigned)std::min<uint64_t>((hi - lo + 255) / 256, 8192);
+    if (W == 1) hipLaunchKernelGGL(k_hashtest_func<1>, dim3(grid), dim3(256), 0, 0, lo, hi, d + p);
+    else hipLaunchKernelGGL(k_hashtest_func<2>, dim3(grid), dim3(256), 0, 0, lo, hi, d + p);
+  }
+  ok = ok && hipMemcpy(h.data(), d, (size_t)nparts * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) { (void)hipGetLastError(); return fail(MCX_ERR_HIP, "hashtest kernels failed"); }
+  uint64_t sum = 0;
+  for (uint32_t p = 0; p < nparts; p++) sum += h[p];
+  *hash_out = sum;
+  return MCX_OK;
+}
+
 extern "C" int mcx_graph_insert_tuple_segments_dev(mcx_graph *g, int colour, const void *d_keys, const void *d_edges,
                                                    const void *d_counts, uint32_t nseg, uint64_t seg_cap)
 {

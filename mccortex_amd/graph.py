@@ -20,7 +20,7 @@ SYMBOLS = [
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
     "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash", "mcx_pack_bases", "mcx_pack_reads_host", "mcx_pack_stream_dev", "mcx_graph_add_packed_dev",
-    "mcx_ubench_stream", "mcx_ubench_random_rmw", "mcx_graph_insert_stats", "mcx_multi_exchange_bytes",
+    "mcx_ubench_stream", "mcx_ubench_random_rmw", "mcx_graph_insert_stats", "mcx_multi_exchange_bytes", "mcx_graph_hashtest", "mcx_hashtest_func",
 ]
 
 
@@ -122,6 +122,8 @@ def lib():
     L.mcx_graph_add_packed_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
     L.mcx_graph_partition_stream_dev.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp, vp, vp]
     L.mcx_graph_insert_tuples_dev.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
+    L.mcx_graph_hashtest.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.mcx_hashtest_func.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
     L.mcx_key_owner.restype = C.c_uint32
     L.mcx_key_owner.argtypes = [u64p, C.c_int, C.c_int]
     L.mcx_graph_sync.argtypes = [vp]
@@ -327,6 +329,10 @@ class Graph:
     def partition_stream_dev(self, d_stream, nbytes, nparts, bin_capacity, d_keys, d_edges, d_counts):
         _check(self.L.mcx_graph_partition_stream_dev(self.h, _ptr(d_stream), nbytes, nparts, bin_capacity,
                                                      _ptr(d_keys), _ptr(d_edges), _ptr(d_counts)))
+
+    def hashtest(self, first, n):
+        """The reference's `hashtest`: find-or-insert of the keys whose top word is first .. first + n - 1."""
+        _check(self.L.mcx_graph_hashtest(self.h, first, n))
 
     def insert_tuples_dev(self, colour, d_keys, d_edges, n):
         _check(self.L.mcx_graph_insert_tuples_dev(self.h, colour, _ptr(d_keys), _ptr(d_edges), n))

@@ -126,5 +126,6 @@ void ctx_reader_close(ctx_reader *r);
 int ctx_build(int argc, char **argv);
 int ctx_sort(int argc, char **argv);
 int ctx_index(int argc, char **argv);
+int ctx_hashtest(int argc, char **argv); /* src/commands/ctx_exp_hashtest.c */
 
 #endif

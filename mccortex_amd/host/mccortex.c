@@ -1,6 +1,6 @@
 /* mccortex.c -- `mccortex<K> <command>` dispatcher (src/main/mccortex.c:15-28,279-332).
  * `build` (the hot path this repository replaces) and the two commands next to it that run on the
- * same device code: `sort` and `index`. */
+ * same device code: `sort` and `index`, and the reference's benchmark of this path's table, `hashtest`. */
 #include "host.h"
 
 #include <stdlib.h>
@@ -15,6 +15,7 @@ static const char usage[] =
 "Commands:   build       construct cortex graph from FASTA/FASTQ\n"
 "            sort        sort the kmers in a graph file\n"
 "            index       index a sorted cortex graph file\n"
+"            hashtest    test hash table speed\n"
 "\n"
 "  Type a command with no arguments to see help.\n"
 "\n"
@@ -50,8 +51,9 @@ int main(int argc, char **argv)
   if (!strcmp(argv[1], "build")) func = ctx_build;
   else if (!strcmp(argv[1], "sort")) func = ctx_sort;
   else if (!strcmp(argv[1], "index")) func = ctx_index;
+  else if (!strcmp(argv[1], "hashtest")) func = ctx_hashtest;
   if (!func) {
-    fprintf(stderr, "%s: command '%s' is not part of this build (build, sort and index are)\n\n", CMD_NAME, argv[1]);
+    fprintf(stderr, "%s: command '%s' is not part of this build (build, sort, index and hashtest are)\n\n", CMD_NAME, argv[1]);
     fputs(usage, stderr);
     return EXIT_FAILURE;
   }

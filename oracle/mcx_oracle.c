@@ -151,6 +151,27 @@ uint32_t orc_kmer_hash(orc_bkmer key, int k, uint32_t initval)
   return c;
 }
 
+/* ctx_exp_hashtest.c:61-66 (hash_loop, no graph: `bkmer.b[0] = i; hash ^= binary_kmer_hash(bkmer, 0);`) and
+ * :160-175 (one job per thread over [start, end), `hash += jobs[i].hash`) */
+uint64_t orc_hashtest_func(int k, uint64_t n, uint32_t nparts)
+{
+  uint64_t sum = 0, i;
+  uint32_t p;
+  for(p = 0; p < nparts; p++) {
+    const uint64_t start = (uint64_t)p * (n / nparts);
+    const uint64_t end = (p + 1 == nparts) ? n : start + (n / nparts);
+    uint32_t hash = 0;
+    orc_bkmer bkmer;
+    memset(&bkmer, 0, sizeof(bkmer));
+    for(i = start; i < end; i++) {
+      bkmer.b[0] = i;
+      hash ^= orc_kmer_hash(bkmer, k, 0);
+    }
+    sum += hash;
+  }
+  return sum;
+}
+
 void orc_kmer_to_str(orc_bkmer x, int k, char *out)
 {
   static const char nuc2c[4] = {'A', 'C', 'G', 'T'};

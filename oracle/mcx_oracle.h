@@ -39,6 +39,9 @@ orc_bkmer orc_kmer_shift_add(orc_bkmer x, int k, int nuc);         /* binary_kme
 orc_bkmer orc_kmer_revcomp(orc_bkmer x, int k);                    /* binary_kmer.c:102-133 */
 orc_bkmer orc_kmer_get_key(orc_bkmer x, int k);                    /* binary_kmer.c:43-57 */
 uint32_t  orc_kmer_hash(orc_bkmer key, int k, uint32_t initval);   /* kmer_hash.h:162-211 */
+/* `hashtest -F` (src/commands/ctx_exp_hashtest.c:61-66,160-175): [0, n) in nparts ranges (range i starts at
+ * i * (n / nparts), the last one ends at n); per range the XOR of binary_kmer_hash(bkmer with b[0] = i, 0); the sum. */
+uint64_t  orc_hashtest_func(int k, uint64_t n, uint32_t nparts);
 void      orc_kmer_to_str(orc_bkmer x, int k, char *out);          /* binary_kmer.c:190-.. */
 int       orc_rehash_limit(void);     /* REHASH_LIMIT, src/basic/hash_mem.h:4 */
 int       orc_max_bucket_size(void);  /* MAX_BUCKET_SIZE, src/basic/hash_mem.h:8 */

@@ -56,6 +56,8 @@ def lib():
     L.orc_kmer_get_key.argtypes = [BKmer, C.c_int]
     L.orc_kmer_hash.restype = C.c_uint32
     L.orc_kmer_hash.argtypes = [BKmer, C.c_int, C.c_uint32]
+    L.orc_hashtest_func.restype = C.c_uint64
+    L.orc_hashtest_func.argtypes = [C.c_int, C.c_uint64, C.c_uint32]
     L.orc_kmer_to_str.argtypes = [BKmer, C.c_int, C.c_char_p]
     L.orc_hash_table_cap.restype = C.c_uint64
     L.orc_hash_table_cap.argtypes = [C.c_uint64, u64p, C.POINTER(C.c_uint8)]

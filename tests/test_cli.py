@@ -66,6 +66,45 @@ def test_usage_and_argument_errors(built, tmp_path):
     assert rc == 1 and "Invalid kmer-size (30)" in err
 
 
+def test_hashtest_usage_and_argument_errors(built):
+    """`hashtest` (src/commands/ctx_exp_hashtest.c:78-122): option rules and messages, no device needed."""
+    rc, _, err = run(31, "hashtest")
+    assert rc == 1 and "usage: mccortex31 hashtest [options] <num_ops>" in err and "31 >= k >= 3" in err
+    for args, msg in [(["hashtest", "1000"], "kmer size not set with -k <K>"),
+                      (["hashtest", "-k", "33", "1000"], "Please recompile with correct kmer size (33)"),
+                      (["hashtest", "-k", "30", "1000"], "Invalid kmer-size (30): requires odd number 3 <= k <= 31"),
+                      (["hashtest", "-k", "31", "-k", "21", "1000"], "given twice"),
+                      (["hashtest", "-k", "31"], "usage: mccortex31 hashtest"),
+                      (["hashtest", "-k", "31", "12x"], "Invalid <num_ops>"),
+                      (["hashtest", "-k", "31", "-m", "12XB", "10"], "Invalid memory argument"),
+                      (["hashtest", "-k", "31", "--bogus", "10"], "Bad option")]:
+        rc, _, err = run(31, *args)
+        assert rc == 1 and msg in err, (args, err)
+    rc, _, err = run(63, "hashtest", "-k", "31", "10")
+    assert rc == 1 and "Please recompile" in err
+
+
+@pytest.mark.gpu
+def test_hashtest_command(built, orc):
+    """Integer keys 0..N-1 into the table on the device: every key is new, so `filled` must be N; the -F mode must
+    print the reference's sum-of-XORs of bklk3 hashes for the same -t (oracle: orc_kmer_hash, pinned against the
+    reference's own kmer_hash.h / lookup3.h in tests/test_oracle.py)."""
+    n = 200_000
+    rc, _, err = run(31, "hashtest", "-k", "31", "-n", "1M", str(n))
+    assert rc == 0, err
+    assert "filled: 0 / 1,048,576 (0.00%)" in err and "filled: 200,000 / 1,048,576 (19.07%)" in err
+    assert "using 1 thread (single-threaded code)" in err and "Output hash: 0" in err
+    rc, _, err = run(63, "hashtest", "-k", "63", "-n", "1M", "-t", "4", str(n))
+    assert rc == 0 and "filled: 200,000 / 1,048,576" in err and "using 4 threads (multi-threaded code)" in err, err
+    # more keys than the table holds: the reference's message
+    rc, _, err = run(31, "hashtest", "-k", "31", "-n", "64K", str(n))
+    assert rc == 1 and "Hash table is full" in err, err
+    for maxk, k, t in ((31, 31, 1), (31, 21, 3), (63, 63, 4)):
+        want = orc.lib().orc_hashtest_func(k, n, t)
+        rc, _, err = run(maxk, "hashtest", "-k", str(k), "-F", "-t", str(t), str(n))
+        assert rc == 0 and ("Output hash: %d" % want) in err, (k, t, want, err[-300:])
+
+
 def _write_inputs(tmp_path, bases, offs, name, fmt, gz=False, qual=None, width=0):
     reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(len(offs) - 1)]
     out = []
