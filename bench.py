@@ -1087,10 +1087,12 @@ def main():
                          "(mcx_graph_create_multi: what `mccortex31 build -D 0,1,..` runs) on the same reads; prints its own JSON line")
     args = ap.parse_args()
     if not args.defer_tuples:
-        # one flush for the timed region (20 steps x 5 M reads = 12 G occurrences -> 12.4 G): the part has the HBM for it
-        # (bins 8.5 B per occurrence), and every flush streams the 16 GiB table through LDS once
-        occ = args.steps * args.batch_reads * (READ_LEN - K + 1)
-        args.defer_tuples = max(DEFER_TUPLES, min(int(occ * 1.03), 16_000_000_000))
+        # One flush for the timed region: every flush streams the 16 GiB table through LDS once, and the part has the HBM
+        # for it (bins 8.5 B per reserved occurrence).  A launch reserves one occurrence per START POSITION of its piece of
+        # stream (an upper bound of the k-mers it yields: 151 positions per 120 k-mers here), so the window is counted in
+        # positions: 20 steps x 5 M reads x 151 = 15.1 G -> 128 GB of bins beside the table, the inputs and the sub-table bins.
+        pos = args.steps * args.batch_reads * (READ_LEN + 1)
+        args.defer_tuples = max(DEFER_TUPLES, min(int(pos * 1.01), 16_000_000_000))
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 (make,
     # RCCL's version banner, ...) is sent to stderr

@@ -1064,9 +1064,23 @@ static int l2_reserve(mcx_graph *g, int colour, uint64_t ub)
   return MCX_OK;
 }
 
+// "Hash table is full" while input is still coming in: the device's flag (raised by the first insert that finds neither its
+// sub-table nor the overflow area free, mcx_kernels.h table_flag_full) follows every submitted piece of stream to pinned
+// memory; a later submission that finds it set ends the call -- the reference dies at that insert (hash_table.c:119-123),
+// this build within a few pieces of it.  Every stream entry point comes through here (ASCII, packed, -Q/-H, PCR, device
+// streams); the shards of a multi-GPU table report at their sync.
+static int full_poll(mcx_graph *g)
+{
+  if (!g->h_full || !g->t.touch) return MCX_OK;
+  if (*g->h_full) return fail(MCX_ERR_FULL, "Hash table is full");
+  HIP_TRY(hipMemcpyAsync(g->h_full, g->t.touch - 2, sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+  return MCX_OK;
+}
+
 static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
 {
   if (g->group) return group_submit_stream(g->group, g->gidx, L, colour);  // shard of a multi-GPU table
+  { int rc = full_poll(g); if (rc != MCX_OK) return rc; }
   if (g->defer) { int rc = ensure_defer(g); if (rc != MCX_OK) return rc; }
   if (!g->defer) {
     DISPATCH_WC(g, launch_direct_t, g, L, colour);
@@ -2180,20 +2194,15 @@ static int add_reads_packed(mcx_graph *g, int colour, const uint8_t *bases, cons
     g->ev_wait_used[b] = true;
     StreamLaunch SL{nullptr, J.total, kCarry - (uint64_t)g->k, J.total - (uint64_t)g->k, J.piece_of >= 0 ? d_flags + J.piece_of : nullptr,
                     reinterpret_cast<const uint32_t *>(ds), reinterpret_cast<const uint16_t *>(ds + inv_at)};
-    int rc = submit_stream(g, SL, colour);
-    if (rc != MCX_OK) return rc;
+    int rc = submit_stream(g, SL, colour);  // (polls the table's "full" flag: full_poll)
+    // whatever happens, the staging buffer's event follows the copies already queued on it: a caller that goes on after
+    // an error must not reuse the buffer unordered
+    if (rc != MCX_OK) { (void)hipEventRecord(g->ev[b], g->stream); return rc; }
     HIP_TRY(hipSetDevice(g->device));
     if (J.nwhole) {
       hipLaunchKernelGGL(k_read_flags_packed, dim3((unsigned)((J.nwhole + 255) / 256)), dim3(256), 0, g->stream,
                          reinterpret_cast<const uint16_t *>(ds + inv_at), (const uint64_t *)(ds + off_region), J.nwhole, g->k, d_flags + J.r0);
-      HIP_TRY(hipGetLastError());
-    }
-    // "Hash table is full" while reads are still coming in: the flag of the device (raised by the first insert that finds
-    // neither its sub-table nor the overflow area free) follows every chunk to pinned memory; a later chunk that finds it
-    // set ends the call -- the reference dies at that insert (hash_table.c:119-123), this build within a few chunks of it.
-    if (g->h_full && g->t.touch) {
-      if (*g->h_full) return fail(MCX_ERR_FULL, "Hash table is full");
-      HIP_TRY(hipMemcpyAsync(g->h_full, g->t.touch - 2, sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+      if (hipGetLastError() != hipSuccess) { (void)hipEventRecord(g->ev[b], g->stream); return fail(MCX_ERR_HIP, "k_read_flags_packed launch failed"); }
     }
     HIP_TRY(hipEventRecord(g->ev[b], g->stream));
     g_stage_timing.chunks++;

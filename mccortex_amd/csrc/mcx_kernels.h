@@ -74,13 +74,22 @@ __device__ __forceinline__ void table_mark_written(const TableView &t)
 {
   if (t.touch) t.touch[0] = 1u;
 }
+// One atomic per wave, not per lane: these counters sit on ONE 8-byte address, and the paths that bump them are the ones a
+// hot k-mer takes hundreds of thousands of times in a row (poly-A: every lane of every wave).  The lanes that are active
+// here elect the lowest one, which adds the count of all of them.
+__device__ __forceinline__ void table_count_slow(unsigned long long *ctr)
+{
+  const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+  const uint32_t lane = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+  if (lane == 0) atomicAdd(ctr, (unsigned long long)__popcll(act));  // (mbcnt: active lanes below this one)
+}
 __device__ __forceinline__ void table_count_fallback(const TableView &t)
 {
-  if (t.touch) atomicAdd(reinterpret_cast<unsigned long long *>(t.touch) - 4, 1ULL);
+  if (t.touch) table_count_slow(reinterpret_cast<unsigned long long *>(t.touch) - 4);
 }
 __device__ __forceinline__ void table_count_foreign(const TableView &t)
 {
-  if (t.touch) atomicAdd(reinterpret_cast<unsigned long long *>(t.touch) - 3, 1ULL);
+  if (t.touch) table_count_slow(reinterpret_cast<unsigned long long *>(t.touch) - 3);
 }
 // "Hash table is full", fail fast (round 5).  A key whose sub-table is full scans the overflow area linearly, the whole
 // of it (1 / 32 of the table) before it gives up -- and once that area is full EVERY further new key does: a build whose
