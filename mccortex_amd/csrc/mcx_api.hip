@@ -320,8 +320,7 @@ extern "C" int mcx_device_memory(int device, uint64_t *free_bytes, uint64_t *tot
 
 static int check_k(int k)
 {
-  if (k < 3 || k > 63 || !(k & 1)) return fail(MCX_ERR_ARG, "kmer size must be odd and 3..63 (got %d)", k);
-  if (k == 32) return MCX_ERR_ARG;
+  if (k < 3 || k > 127 || !(k & 1)) return fail(MCX_ERR_ARG, "kmer size must be odd and 3..127 (got %d)", k);
   return MCX_OK;
 }
 
@@ -349,6 +348,8 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1)) || part < 0 || part >= nparts)
     return fail(MCX_ERR_ARG, "shards must be a power of two <= 32 and 0 <= part < shards (got %d of %d)", part, nparts);
   if (ncols < 1 || ncols > 4096) return fail(MCX_ERR_ARG, "ncols out of range: %d", ncols);
+  if (kmer_size > 63 && nparts != 1)
+    return fail(MCX_ERR_ARG, "k > 63 (three- and four-word keys) builds on one device: the exchange formats carry at most two key words");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(MCX_ERR_NODEVICE, "no HIP device available (this library has no CPU path)");
@@ -395,6 +396,9 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   // one colour: records [key words, value]; several: key array, then one value array per colour
   g->t.max_probe = (uint32_t)sub_slots;  // a probe sequence never leaves its sub-table
   { const char *e = getenv("MCX_DEFER"); if (e) g->defer = atoi(e) != 0; }
+  // k = 65 .. 127 (mccortex95 / mccortex127: three- and four-word keys) takes the fused kernel with one HBM atomic per
+  // occurrence: the partition path's tuple formats and LDS images are laid out for one and two key words
+  if (g->W > 2) g->defer = false;
   { const char *e = getenv("MCX_GRID_STREAM"); if (e) g->grid_stream = atoi(e); }  // experiments
   { const char *e = getenv("MCX_REP1"); if (e && atoi(e) >= 1 && atoi(e) <= 4096) g->rep1 = (uint32_t)atoi(e); }
   { const char *e = getenv("MCX_GRID_SPLIT"); if (e) g->grid_split = atoi(e); }
@@ -537,6 +541,28 @@ struct StreamLaunch {
     if ((g)->W == 1) { if ((g)->ncols == 1) F<1, true>(__VA_ARGS__); else F<1, false>(__VA_ARGS__); } \
     else { if ((g)->ncols == 1) F<2, true>(__VA_ARGS__); else F<2, false>(__VA_ARGS__); }            \
   } while (0)
+
+// ... for what exists for keys of three and four words as well (k = 65 .. 127: the fused insert, record load, export)
+#define DISPATCH_WC4(g, F, ...)                                                       \
+  do {                                                                                \
+    const bool one_ = (g)->ncols == 1;                                                \
+    switch ((g)->W) {                                                                 \
+      case 1: if (one_) F<1, true>(__VA_ARGS__); else F<1, false>(__VA_ARGS__); break; \
+      case 2: if (one_) F<2, true>(__VA_ARGS__); else F<2, false>(__VA_ARGS__); break; \
+      case 3: if (one_) F<3, true>(__VA_ARGS__); else F<3, false>(__VA_ARGS__); break; \
+      default: if (one_) F<4, true>(__VA_ARGS__); else F<4, false>(__VA_ARGS__); break; \
+    }                                                                                 \
+  } while (0)
+#define LAUNCH_W4(W_, KERNEL, ...)                                       \
+  do {                                                                   \
+    switch (W_) {                                                        \
+      case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;       \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break;       \
+      case 3: hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__); break;       \
+      default: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;      \
+    }                                                                    \
+  } while (0)
+#define NO_WIDE(g, what) do { if ((g) && (g)->W > 2) return fail(MCX_ERR_ARG, what " is not available for k > 63"); } while (0)
 
 // optional per-kernel timing with HIP events on the handle's stream
 struct SpanGuard {
@@ -1083,7 +1109,7 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
   { int rc = full_poll(g); if (rc != MCX_OK) return rc; }
   if (g->defer) { int rc = ensure_defer(g); if (rc != MCX_OK) return rc; }
   if (!g->defer) {
-    DISPATCH_WC(g, launch_direct_t, g, L, colour);
+    DISPATCH_WC4(g, launch_direct_t, g, L, colour);
     HIP_TRY(hipGetLastError());
     return MCX_OK;
   }
@@ -1135,7 +1161,7 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
   if (!strcmp(key, "defer")) {
     int rc = flush_deferred(g);
     if (rc != MCX_OK) return rc;
-    g->defer = value != 0;
+    g->defer = value != 0 && g->W <= 2;  // (k > 63: the fused kernel only)
     return MCX_OK;
   }
   if (!strcmp(key, "defer_tuples")) {
@@ -1296,6 +1322,7 @@ extern "C" int mcx_graph_partition_stream_dev(mcx_graph *g, const void *d_stream
 {
   NO_GROUP(g, "mcx_graph_partition_stream_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
+  NO_WIDE(g, "mcx_graph_partition_stream_dev");
   if (nparts < 1 || nparts > kMaxBins) return fail(MCX_ERR_ARG, "nparts must be 1..%d", kMaxBins);
   if (bin_capacity >= 0xFFFFFFFFull) return fail(MCX_ERR_ARG, "bin capacity must be below 2^32 tuples");
   if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
@@ -1319,7 +1346,7 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
   HIP_TRY(hipSetDevice(g->device));
   if (g->defer) { int rc = ensure_defer(g); if (rc != MCX_OK) return rc; }
   if (!g->defer) {
-    DISPATCH_WC(g, launch_insert_tuples_t, g, colour, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n);
+    DISPATCH_WC4(g, launch_insert_tuples_t, g, colour, (const uint64_t *)d_keys, (const uint8_t *)d_edges, n);
     HIP_TRY(hipGetLastError());
     return MCX_OK;
   }
@@ -1343,7 +1370,7 @@ template <int W> __global__ void k_hashtest_keys(uint64_t *keys, uint64_t first,
 {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     keys[i * W] = first + i;  // bkmer.b[0] = i
-    if (W == 2) keys[i * W + 1] = 0;
+    for (int w = 1; w < W; w++) keys[i * W + w] = 0;
   }
 }
 template <int W> __global__ void k_hashtest_func(uint64_t lo, uint64_t hi, unsigned int *out)
@@ -1352,7 +1379,7 @@ template <int W> __global__ void k_hashtest_func(uint64_t lo, uint64_t hi, unsig
   for (uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * blockDim.x) {
     Kmer<W> key;
     key.w[0] = i;
-    if (W == 2) key.w[W - 1] = 0;
+    for (int w = 1; w < W; w++) key.w[w] = 0;
     h ^= kmer_hash<W>(key, 0, nullptr);
   }
   for (int d = 32; d; d >>= 1) h ^= __shfl_xor(h, d, 64);
@@ -1377,8 +1404,7 @@ extern "C" int mcx_graph_hashtest(mcx_graph *g, uint64_t first, uint64_t n)
   if (hipMemsetAsync(d_edges, 0, chunk, g->stream) != hipSuccess) rc = fail(MCX_ERR_HIP, "hipMemsetAsync failed");
   for (uint64_t lo = 0; lo < n && rc == MCX_OK; lo += chunk) {
     const uint64_t cnt = std::min(chunk, n - lo);
-    if (g->W == 1) hipLaunchKernelGGL(k_hashtest_keys<1>, dim3(4096), dim3(256), 0, g->stream, d_keys, first + lo, cnt);
-    else hipLaunchKernelGGL(k_hashtest_keys<2>, dim3(4096), dim3(256), 0, g->stream, d_keys, first + lo, cnt);
+    LAUNCH_W4(g->W, k_hashtest_keys, dim3(4096), dim3(256), 0, g->stream, d_keys, first + lo, cnt);
     rc = mcx_graph_insert_tuples_dev(g, 0, d_keys, d_edges, cnt);
     // (the binning kernel that reads the buffer runs on the same stream as the generator of the next chunk)
   }
@@ -1391,7 +1417,7 @@ extern "C" int mcx_hashtest_func(int device, int kmer_size, uint64_t n, uint32_t
 {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(MCX_ERR_NODEVICE, "no HIP device %d", device);
-  if (kmer_size < 3 || kmer_size > 63 || !(kmer_size & 1)) return fail(MCX_ERR_ARG, "kmer size %d", kmer_size);
+  if (kmer_size < 3 || kmer_size > 127 || !(kmer_size & 1)) return fail(MCX_ERR_ARG, "kmer size %d", kmer_size);
   if (!nparts || !hash_out) return fail(MCX_ERR_ARG, "nparts / hash_out");
   HIP_TRY(hipSetDevice(device));
   unsigned int *d = nullptr;
@@ -1403,8 +1429,7 @@ extern "C" int mcx_hashtest_func(int device, int kmer_size, uint64_t n, uint32_t
     const uint64_t lo = (uint64_t)p * (n / nparts), hi = p + 1 == nparts ? n : lo + n / nparts;
     if (hi <= lo) continue;
     const unsigned grid = (unsigned)std::min<uint64_t>((hi - lo + 255) / 256, 8192);
-    if (W == 1) hipLaunchKernelGGL(k_hashtest_func<1>, dim3(grid), dim3(256), 0, 0, lo, hi, d + p);
-    else hipLaunchKernelGGL(k_hashtest_func<2>, dim3(grid), dim3(256), 0, 0, lo, hi, d + p);
+    LAUNCH_W4(W, k_hashtest_func, dim3(grid), dim3(256), 0, 0, lo, hi, d + p);
   }
   ok = ok && hipMemcpy(h.data(), d, (size_t)nparts * 4, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(d);
@@ -1449,6 +1474,7 @@ extern "C" int mcx_graph_shard_layout(mcx_graph *g, uint64_t tuples_per_call, ui
 {
   NO_GROUP(g, "mcx_graph_shard_layout");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
+  NO_WIDE(g, "mcx_graph_shard_layout");
   const uint32_t nparts = 1u << g->t.lbo, b1 = 1u << g->t.lb1;
   const uint64_t nseg = (uint64_t)nparts * kShardRep * b1;
   if (segs_per_owner) *segs_per_owner = kShardRep * b1;
@@ -1467,6 +1493,7 @@ extern "C" int mcx_graph_shard_bins_dev(mcx_graph *g, const void *d_stream, uint
                                         void *d_ov_counts, uint64_t ov_cap)
 {
   if (!g) return fail(MCX_ERR_ARG, "null graph");
+  NO_WIDE(g, "mcx_graph_shard_bins_dev");
   if (g->as_group) return fail(MCX_ERR_ARG, "device-pointer exchange calls take a shard, not the multi-GPU handle");
   if (!nbytes) return MCX_OK;
   StreamLaunch L{(const uint8_t *)d_stream, nbytes, 0, nbytes, nullptr};
@@ -1495,6 +1522,7 @@ extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *
 {
   NO_GROUP(g, "mcx_graph_add_segments_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
+  NO_WIDE(g, "mcx_graph_add_segments_dev");
   if (colour < 0 || colour >= g->ncols) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (!nseg) return MCX_OK;
   HIP_TRY(hipSetDevice(g->device));
@@ -1535,6 +1563,7 @@ extern "C" int mcx_graph_superk_layout(mcx_graph *g, int nparts, uint64_t positi
 {
   NO_GROUP(g, "mcx_graph_superk_layout");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
+  NO_WIDE(g, "mcx_graph_superk_layout");
   if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1))) return fail(MCX_ERR_ARG, "shards must be a power of two <= 32");
   if (segs_per_owner) *segs_per_owner = kSuperkRep;
   // ~2.3 records per 16 positions on random reads; room for 4 (a bin that overflows is reported as
@@ -1548,6 +1577,7 @@ extern "C" int mcx_graph_superk_bins_dev(mcx_graph *g, const void *d_stream, uin
 {
   NO_GROUP(g, "mcx_graph_superk_bins_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
+  NO_WIDE(g, "mcx_graph_superk_bins_dev");
   if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..63 (got %d)", kSuperkMinK, g->k);
   if (nparts < 1 || nparts > 32 || (nparts & (nparts - 1))) return fail(MCX_ERR_ARG, "shards must be a power of two <= 32");
   if (((uintptr_t)d_stream & 15) != 0) return fail(MCX_ERR_ARG, "stream must be 16-byte aligned");
@@ -1616,6 +1646,7 @@ extern "C" int mcx_graph_add_superk_dev(mcx_graph *g, int colour, const void *d_
 {
   NO_GROUP(g, "mcx_graph_add_superk_dev");
   if (!g) return fail(MCX_ERR_ARG, "null graph");
+  NO_WIDE(g, "mcx_graph_add_superk_dev");
   if (colour < 0 || colour >= g->ncols_vis) return fail(MCX_ERR_ARG, "colour %d out of range", colour);
   if (!mcx_superk_supported(g->k)) return fail(MCX_ERR_ARG, "super-k-mer records need an odd k in %d..63 (got %d)", kSuperkMinK, g->k);
   if (g->t.lbo) return fail(MCX_ERR_ARG, "super-k-mer shards use ordinary (unsharded) tables");
@@ -1643,6 +1674,7 @@ extern "C" uint32_t mcx_graph_key_owner(const mcx_graph *g, const uint64_t *key_
 {
   if (!g) return 0;
   if (g->as_group) g = grp_part(g->as_group, 0);
+  if (g->W > 2) return 0;  // (k > 63: one device)
   if (g->own_lbo) return g->W == 1 ? superk_owner(0, key_words[0], g->k, g->own_lbo) : superk_owner(key_words[0], key_words[1], g->k, g->own_lbo);
   const uint32_t lbq = g->t.lb1 + g->t.lbo;
   uint32_t r = 0, m;
@@ -2390,12 +2422,8 @@ static int add_reads_must_exist(mcx_graph *g, int colour, const uint8_t *bases, 
   const unsigned blocks = (unsigned)((nreads + 127) / 128);
   {
     SpanGuard sp(g, "k_reads_must_exist");
-    if (g->W == 1)
-      hipLaunchKernelGGL((k_reads_must_exist<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
-                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u, owner_spec(g));
-    else
-      hipLaunchKernelGGL((k_reads_must_exist<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
-                         (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u, owner_spec(g));
+    LAUNCH_W4(g->W, k_reads_must_exist, dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)d_bases,
+              (const uint8_t *)d_quals, (const uint64_t *)d_off, nreads, g->k, (uint32_t)fq, (uint32_t)hp, (uint32_t)colour, g->d_ctr, (uint8_t *)nullptr, 0u, owner_spec(g));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g->stream));
@@ -2517,12 +2545,8 @@ static int cut_starts(CutJob &J)
     CUT_TRY(hipMemsetAsync(g->d_readstrt, 0xff, g->t.nslots * 8, g->stream));
   }
   const unsigned blocks = (unsigned)((J.nreads + 127) / 128);
-  if (g->W == 1)
-    hipLaunchKernelGGL((k_pcr_starts<1>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
-                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr, owner_spec(g));
-  else
-    hipLaunchKernelGGL((k_pcr_starts<2>), dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
-                       (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr, owner_spec(g));
+  LAUNCH_W4(g->W, k_pcr_starts, dim3(blocks), dim3(128), 0, g->stream, g->t, (const uint8_t *)J.d_bases, (const uint8_t *)J.d_quals,
+            (const uint64_t *)J.d_off, J.nreads, g->k, J.fq1, J.fq2, J.pmask, J.hp, g->d_readstrt, J.d_node, g->d_ctr, owner_spec(g));
   CUT_TRY(hipGetLastError());
   return MCX_OK;
 }
@@ -2759,12 +2783,8 @@ extern "C" int mcx_graph_add_records(mcx_graph *g, const void *recs, uint64_t nr
     HIP_TRY(hipMemcpyAsync(g->d_stage[cur], g->h_stage[cur], n * rec_bytes, hipMemcpyHostToDevice, g->stream));
     const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)g->grid);
     SpanGuard sp(g, "k_load_records");
-    if (g->W == 1)
-      hipLaunchKernelGGL((k_load_records<1>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p, owner_spec(g));
-    else
-      hipLaunchKernelGGL((k_load_records<2>), dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
-                         d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p, owner_spec(g));
+    LAUNCH_W4(g->W, k_load_records, dim3(grid), dim3(256), 0, g->stream, g->t, g->d_stage[cur], n, r0, (uint32_t)file_ncols,
+              d_into.p, d_into.p + nmap, (uint32_t)nmap, flags & MCX_RECORDS_MUST_EXIST, (flags & MCX_RECORDS_MASK_EDGES) ? g->hidden : -1, g->k, g->d_ctr, d_st.p, owner_spec(g));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->ev[cur], g->stream));
   }
@@ -2818,7 +2838,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   hipStream_t st = g->stream;
   const uint32_t recsz = 8u * W + 5u * (uint32_t)g->ncols_vis;
   const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / recsz);
-  const uint64_t per_kmer = 8 * (uint64_t)W + 8 + 32 + (W == 2 ? 8 : 0) + 8 /* radix temporary, roughly */;
+  const uint64_t per_kmer = 8 * (uint64_t)W + 8 + 32 + (W >= 2 ? 8 : 0) + 8 /* radix temporary, roughly */;
   const uint64_t fixed = 2 * chunk * recsz + (64ull << 20);
   auto free_bytes = []() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? (uint64_t)f : 0; };
   uint32_t pbits = 0;
@@ -2941,7 +2961,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
     export_clock("compacted");
     // permutation of the compacted entries: by key (sorted) or by slot (table order)
     size_t tmp_bytes = 0;
-    const uint64_t *first_key = sorted ? (W == 2 ? d_k1 : d_k0) : d_slot;
+    const uint64_t *first_key = sorted ? (W == 2 ? d_k1 : d_k0) : d_slot;  // (W > 2: a throw-away pass, see below)
     // (the sort's own temporary first: it is the largest block -- two more arrays of m words -- and the bump allocator
     // fills the first pool in order; the smaller arrays find room in what is left or in the second pool)
     EXP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, first_key, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, m, 0, 64, st));
@@ -2949,7 +2969,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
     EXP_TRY(salloc((void **)&d_idx, m * 8));
     EXP_TRY(salloc((void **)&d_idx2, m * 8));
     EXP_TRY(salloc((void **)&d_ks, m * 8));
-    if (sorted && W == 2) EXP_TRY(salloc((void **)&d_ks2, m * 8));
+    if (sorted && W >= 2) EXP_TRY(salloc((void **)&d_ks2, m * 8));
     const unsigned gb = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, m);
     EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, first_key, d_ks, d_idx, d_idx2, m, 0, 64, st));
@@ -2958,6 +2978,18 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
       hipLaunchKernelGGL(k_gather_u64, dim3(gb), dim3(256), 0, st, (const uint64_t *)d_k0, (const uint64_t *)d_idx2, d_ks2, m);
       EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, d_idx2, d_idx, m, 0, 64, st));
       perm = d_idx;
+    }
+    if (sorted && W > 2) {
+      // k > 63: the pass above ordered by the top word only (d_k0).  Redo as an LSD sort over all W words, least
+      // significant first, every pass stable; a pass fetches its word from the table through the permutation so far.
+      hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, m);
+      uint64_t *cur = d_idx, *nxt = d_idx2;
+      for (int w = W - 1; w >= 0; w--) {
+        hipLaunchKernelGGL(k_gather_keyword, dim3(gb), dim3(256), 0, st, g->t, (const uint64_t *)d_slot, (const uint64_t *)cur, (uint32_t)w, d_ks2, m);
+        EXP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, cur, nxt, m, 0, 64, st));
+        std::swap(cur, nxt);
+      }
+      perm = cur;
     }
     EXP_TRY(hipStreamSynchronize(st));
     export_clock("sorted");
@@ -2994,7 +3026,12 @@ extern "C" int mcx_graph_export(mcx_graph *g, int sorted, mcx_sink_fn sink, void
   if (g && sink && g->as_group) return grp_export(g->as_group, g, sorted, sink, ctx);
   if (!g || !sink) return fail(MCX_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(g->device));
-  return g->W == 1 ? export_t<1>(g, sorted, sink, ctx) : export_t<2>(g, sorted, sink, ctx);
+  switch (g->W) {
+    case 1: return export_t<1>(g, sorted, sink, ctx);
+    case 2: return export_t<2>(g, sorted, sink, ctx);
+    case 3: return export_t<3>(g, sorted, sink, ctx);
+    default: return export_t<4>(g, sorted, sink, ctx);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -3072,7 +3109,7 @@ extern "C" uint64_t mcx_records_checksum(const void *recs, uint64_t nrecs, int k
   uint64_t sum = 0;
   std::vector<uint32_t> cv((size_t)ncols);
   for (uint64_t i = 0; i < nrecs; i++, p += rb) {
-    uint64_t kw[2] = {0, 0};
+    uint64_t kw[4] = {0, 0, 0, 0};
     memcpy(kw, p, 8 * (size_t)W);
     memcpy(cv.data(), p + 8 * W, 4 * (size_t)ncols);
     sum += record_hash(kw, W, cv.data(), p + 8 * W + 4 * ncols, (uint32_t)ncols);
@@ -3222,7 +3259,8 @@ static int sort_records_t(uint8_t *recs, uint64_t n, uint32_t rec_bytes, int dev
     unsigned long long bad = ~0ULL;
     SRT_TRY(hipMalloc((void **)&d_bad, 8));
     SRT_TRY(hipMemcpyAsync(d_bad, &bad, 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((k_check_sorted<W>), dim3(gb), dim3(256), 0, st, d_k0, d_k1, n, d_bad);
+    if (W > 2) hipLaunchKernelGGL(k_check_sorted_records, dim3(gb), dim3(256), 0, st, (const uint8_t *)d_in, rec_bytes, (uint32_t)W, n, d_bad);
+    else hipLaunchKernelGGL((k_check_sorted<W>), dim3(gb), dim3(256), 0, st, d_k0, d_k1, n, d_bad);
     SRT_TRY(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, st));
     SRT_TRY(hipStreamSynchronize(st));
     *first_unsorted = bad == ~0ULL ? -1 : (int64_t)bad;
@@ -3244,6 +3282,17 @@ static int sort_records_t(uint8_t *recs, uint64_t n, uint32_t rec_bytes, int dev
     SRT_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, d_idx2, d_idx, n, 0, 64, st));
     perm = d_idx;
   }
+  if (W > 2) {  // k > 63: LSD over all W words, least significant first, each word fetched through the permutation so far
+    SRT_TRY(hipMalloc((void **)&d_ks2, n * 8));
+    hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, st, d_idx, n);
+    uint64_t *cur = d_idx, *nxt = d_idx2;
+    for (int w = W - 1; w >= 0; w--) {
+      hipLaunchKernelGGL(k_gather_record_word, dim3(gb), dim3(256), 0, st, (const uint8_t *)d_in, rec_bytes, (const uint64_t *)cur, (uint32_t)w, d_ks2, n);
+      SRT_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_ks2, d_ks, cur, nxt, n, 0, 64, st));
+      std::swap(cur, nxt);
+    }
+    perm = cur;
+  }
   (void)hipFree(d_ks); d_ks = nullptr;
   SRT_TRY(hipMalloc((void **)&d_out, bytes));
   hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, st, d_in, (const uint64_t *)perm, n, rec_bytes, d_out);
@@ -3257,7 +3306,7 @@ static int sort_records_t(uint8_t *recs, uint64_t n, uint32_t rec_bytes, int dev
 
 static int sort_args(const void *recs, uint64_t nrecs, int kmer_size, int ncols, uint32_t *rec_bytes)
 {
-  if (kmer_size < 3 || kmer_size > 63 || !(kmer_size & 1)) return fail(MCX_ERR_ARG, "kmer size must be odd and within 3..63 (got %d)", kmer_size);
+  if (kmer_size < 3 || kmer_size > 127 || !(kmer_size & 1)) return fail(MCX_ERR_ARG, "kmer size must be odd and within 3..127 (got %d)", kmer_size);
   if (ncols < 1 || ncols > 10000) return fail(MCX_ERR_ARG, "bad number of colours: %d", ncols);
   if (nrecs && !recs) return fail(MCX_ERR_ARG, "null records");
   if (nrecs >= (1ull << 32) * 16) return fail(MCX_ERR_ARG, "too many records for one call");
@@ -3271,8 +3320,12 @@ extern "C" int mcx_sort_records(void *recs, uint64_t nrecs, int kmer_size, int n
   int rc = sort_args(recs, nrecs, kmer_size, ncols, &rb);
   if (rc != MCX_OK || nrecs < 2) return rc;
   int64_t dummy;
-  return words_for_k(kmer_size) == 1 ? sort_records_t<1>((uint8_t *)recs, nrecs, rb, device, false, &dummy)
-                                     : sort_records_t<2>((uint8_t *)recs, nrecs, rb, device, false, &dummy);
+  switch (words_for_k(kmer_size)) {
+    case 1: return sort_records_t<1>((uint8_t *)recs, nrecs, rb, device, false, &dummy);
+    case 2: return sort_records_t<2>((uint8_t *)recs, nrecs, rb, device, false, &dummy);
+    case 3: return sort_records_t<3>((uint8_t *)recs, nrecs, rb, device, false, &dummy);
+    default: return sort_records_t<4>((uint8_t *)recs, nrecs, rb, device, false, &dummy);
+  }
 }
 
 extern "C" int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_size, int ncols, int device, int64_t *first_unsorted)
@@ -3282,8 +3335,12 @@ extern "C" int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_siz
   *first_unsorted = -1;
   int rc = sort_args(recs, nrecs, kmer_size, ncols, &rb);
   if (rc != MCX_OK || nrecs < 2) return rc;
-  return words_for_k(kmer_size) == 1 ? sort_records_t<1>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted)
-                                     : sort_records_t<2>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted);
+  switch (words_for_k(kmer_size)) {
+    case 1: return sort_records_t<1>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted);
+    case 2: return sort_records_t<2>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted);
+    case 3: return sort_records_t<3>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted);
+    default: return sort_records_t<4>((uint8_t *)recs, nrecs, rb, device, true, first_unsorted);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -3292,35 +3349,47 @@ extern "C" int mcx_records_sorted(const void *recs, uint64_t nrecs, int kmer_siz
 extern "C" void mcx_kmer_from_str(const char *seq, int k, uint64_t *out)
 {
   const int W = words_for_k(k);
-  uint64_t hi = 0, lo = 0;  // 128-bit shift register, lo = least significant
+  uint64_t w[4] = {0, 0, 0, 0};  // 256-bit shift register, w[3] = least significant
   for (int i = 0; i < k; i++) {
-    hi = (hi << 2) | (lo >> 62);
-    lo = (lo << 2) | base_code((unsigned char)seq[i]);
+    for (int j = 0; j < 3; j++) w[j] = (w[j] << 2) | (w[j + 1] >> 62);
+    w[3] = (w[3] << 2) | base_code((unsigned char)seq[i]);
   }
-  if (W == 1) out[0] = lo;
-  else { out[0] = hi; out[1] = lo; }
+  for (int j = 0; j < W; j++) out[j] = w[4 - W + j];
 }
 
+template <int W> static void kmer_canonical_t(const uint64_t *in, int k, uint64_t *key_out, uint32_t &o)
+{
+  Kmer<W> fw;
+  for (int i = 0; i < W; i++) fw.w[i] = in[i];
+  const Kmer<W> key = canonical<W>(fw, revcomp<W>(fw, k), o);
+  for (int i = 0; i < W; i++) key_out[i] = key.w[i];
+}
 extern "C" void mcx_kmer_canonical(const uint64_t *in, int k, uint64_t *key_out, int *orient_out)
 {
   uint32_t o = 0;
-  if (words_for_k(k) == 1) {
-    Kmer<1> fw{{in[0]}};
-    Kmer<1> key = canonical<1>(fw, revcomp<1>(fw, k), o);
-    key_out[0] = key.w[0];
-  } else {
-    Kmer<2> fw{{in[0], in[1]}};
-    Kmer<2> key = canonical<2>(fw, revcomp<2>(fw, k), o);
-    key_out[0] = key.w[0]; key_out[1] = key.w[1];
+  switch (words_for_k(k)) {
+    case 1: kmer_canonical_t<1>(in, k, key_out, o); break;
+    case 2: kmer_canonical_t<2>(in, k, key_out, o); break;
+    case 3: kmer_canonical_t<3>(in, k, key_out, o); break;
+    default: kmer_canonical_t<4>(in, k, key_out, o); break;
   }
   if (orient_out) *orient_out = (int)o;
 }
 
+template <int W> static uint32_t kmer_hash_t(const uint64_t *key, uint32_t initval)
+{
+  Kmer<W> x;
+  for (int i = 0; i < W; i++) x.w[i] = key[i];
+  return kmer_hash<W>(x, initval, nullptr);
+}
 extern "C" uint32_t mcx_kmer_hash(const uint64_t *key, int k, uint32_t initval)
 {
-  if (words_for_k(k) == 1) { Kmer<1> x{{key[0]}}; return kmer_hash<1>(x, initval, nullptr); }
-  Kmer<2> x{{key[0], key[1]}};
-  return kmer_hash<2>(x, initval, nullptr);
+  switch (words_for_k(k)) {
+    case 1: return kmer_hash_t<1>(key, initval);
+    case 2: return kmer_hash_t<2>(key, initval);
+    case 3: return kmer_hash_t<3>(key, initval);
+    default: return kmer_hash_t<4>(key, initval);
+  }
 }
 
 #include "mcx_multi.h"

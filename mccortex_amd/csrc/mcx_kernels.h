@@ -142,6 +142,8 @@ template <int W> __device__ __host__ __forceinline__ uint32_t region_mix(const K
   // (2 instructions for a one-word key; the upper half of the 64-bit product cost 4)
   uint32_t x = (uint32_t)q.w[0] ^ (uint32_t)(q.w[0] >> 32);
   if (W == 2) x ^= ((uint32_t)q.w[W - 1] ^ (uint32_t)(q.w[W - 1] >> 32)) * 0x85EBCA6Bu;
+  if (W > 2)  // (three- and four-word keys, k > 63: every further word folded in with its own odd multiplier)
+    for (int i = 1; i < W; i++) x ^= ((uint32_t)q.w[i] ^ (uint32_t)(q.w[i] >> 32)) * (0x85EBCA6Bu + 0x9E3779B2u * (uint32_t)(i - 1));
   return x * 0x9E3779B1u;
 }
 // Second hash of the quotient: picks the sub-table inside the region (through mulhi: its top bits
@@ -154,6 +156,8 @@ template <int W> __device__ __host__ __forceinline__ uint32_t sub_hash(const Kme
 {
   uint32_t x = (uint32_t)q.w[0] + (uint32_t)(q.w[0] >> 32) * 0xC2B2AE35u;
   if (W == 2) x += (uint32_t)q.w[W - 1] * 0x27D4EB2Fu + (uint32_t)(q.w[W - 1] >> 32) * 0x165667B1u;
+  if (W > 2)
+    for (int i = 1; i < W; i++) x += (uint32_t)q.w[i] * (0x27D4EB2Fu + 0x3C6EF372u * (uint32_t)(i - 1)) + (uint32_t)(q.w[i] >> 32) * (0x165667B1u + 0x7F4A7C16u * (uint32_t)(i - 1));
   x *= 0x85EBCA6Bu;
   x ^= x >> 15;
   return x * 0x2C1B3C6Du;
@@ -177,6 +181,8 @@ template <int W> __device__ __host__ __forceinline__ Kmer<W> key_quot(const Kmer
   if (lb1) {
     r = (uint32_t)key.w[W - 1] & ((1u << lb1) - 1u);
     if (W == 2) q.w[W - 1] = (key.w[W - 1] >> lb1) | (key.w[0] << (64 - lb1));
+    if (W > 2)
+      for (int i = W - 1; i >= 1; i--) q.w[i] = (key.w[i] >> lb1) | (key.w[i - 1] << (64 - lb1));
     q.w[0] = key.w[0] >> lb1;
   }
   return q;
@@ -191,6 +197,8 @@ template <int W> __device__ __host__ __forceinline__ Kmer<W> key_unquot(const Km
   if (lb1) {
     key.w[0] = q.w[0] << lb1;
     if (W == 2) { key.w[0] |= q.w[W - 1] >> (64 - lb1); key.w[W - 1] = q.w[W - 1] << lb1; }
+    if (W > 2)
+      for (int i = 0; i < W; i++) key.w[i] = (q.w[i] << lb1) | (i + 1 < W ? q.w[i + 1] >> (64 - lb1) : 0ull);
     key.w[W - 1] |= r;
   }
   return key;
@@ -283,7 +291,7 @@ struct OwnerSpec {
 };
 template <int W> __device__ __forceinline__ bool owner_is_me(const TableView &t, const OwnerSpec &os, const Kmer<W> &key)
 {
-  if (os.mode == 2) return superk_owner(W == 1 ? 0ULL : key.w[0], key.w[W - 1], os.k, os.lbo) == os.part;
+  if (os.mode == 2) return W > 2 ? true : superk_owner(W == 1 ? 0ULL : key.w[0], key.w[W - 1], os.k, os.lbo) == os.part;  // (k > 63: one device only)
   if (os.mode == 1) return key_owner<W>(t, key) == t.part;
   return true;
 }
@@ -381,9 +389,9 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
       uint64_t expected = 0;
       const uint64_t desired = (W == 1) ? want : (want | kPending);
       if (__hip_atomic_compare_exchange_strong(r, &expected, desired, MCX_RLX, MCX_RLX, MCX_AGENT)) {
-        if (W == 2) {
-          // publish the low word write-through, drain, then clear kPending
-          __hip_atomic_store(r + 1, key.w[W - 1], MCX_RLX, MCX_AGENT);
+        if (W >= 2) {
+          // publish the lower word(s) write-through, drain, then clear kPending
+          for (int i = 1; i < W; i++) __hip_atomic_store(r + i, key.w[i], MCX_RLX, MCX_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __hip_atomic_store(r, want, MCX_RLX, MCX_AGENT);
         }
@@ -395,15 +403,16 @@ __device__ __forceinline__ void probe_insert(const TableView &t, const Kmer<W> &
       hint = 0;
     }
     if ((cur & ~kPending) == want) {
-      if (W == 2) {
+      if (W >= 2) {
         if (cur & kPending) {  // owner has not published word 1 yet: re-read at agent scope
           cur = __hip_atomic_load(r, MCX_RLX, MCX_AGENT);
           fresh = true; hint = 0;
           if (++probes > limit * 64u) { full = 1; return; }
           continue;
         }
-        const uint64_t w1 = __hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT);
-        if (w1 == key.w[W - 1]) { update_value<W>(v, *v, e); return; }
+        bool same = true;
+        for (int i = 1; i < W; i++) same = same && __hip_atomic_load(r + i, MCX_RLX, MCX_AGENT) == key.w[i];
+        if (same) { update_value<W>(v, *v, e); return; }
       } else {
         if (!ONECOL) hint = *v;
         update_value<W>(v, hint, e);
@@ -448,8 +457,8 @@ __device__ __forceinline__ uint64_t find_or_insert_rec(const TableView &t, const
       uint64_t expected = 0;
       const uint64_t desired = (W == 1) ? want : (want | kPending);
       if (__hip_atomic_compare_exchange_strong(r, &expected, desired, MCX_RLX, MCX_RLX, MCX_AGENT)) {
-        if (W == 2) {
-          __hip_atomic_store(r + 1, key.w[W - 1], MCX_RLX, MCX_AGENT);
+        if (W >= 2) {
+          for (int i = 1; i < W; i++) __hip_atomic_store(r + i, key.w[i], MCX_RLX, MCX_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __hip_atomic_store(r, want, MCX_RLX, MCX_AGENT);
         }
@@ -464,7 +473,9 @@ __device__ __forceinline__ uint64_t find_or_insert_rec(const TableView &t, const
         if (++probes > limit * 64u) { full = 1; return kNoSlot; }
         continue;
       }
-      if (__hip_atomic_load(r + 1, MCX_RLX, MCX_AGENT) == key.w[W - 1]) return slot;
+      bool same = true;
+      for (int i = 1; i < W; i++) same = same && __hip_atomic_load(r + i, MCX_RLX, MCX_AGENT) == key.w[i];
+      if (same) return slot;
     }
     if (++probes >= limit) {  // sub-table full: the key is in the overflow area or nowhere (see ovf_start)
       if (ovf || t.nslots == t.nmain) { if (!must_exist) { full = 1; table_flag_full(t); } return kNoSlot; }
@@ -801,6 +812,35 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t h2, uint32_t nparts)
   return (uint32_t)(((uint64_t)h2 * nparts) >> 32);
 }
 
+// Keys of three and four words (k = 65 .. 127: mccortex95 / mccortex127): which of a lane's 16 positions start a k-mer of
+// valid bases (ok16, position j at bit 15 - j) and which have a valid base behind that k-mer (nok16), from the invalid
+// flags of bases pl .. pl + 191 -- the OR of k shifted copies, built by doubling, as the binning kernels do for one
+// and two words (mcx_defer.h).
+__device__ __forceinline__ void lane_masks_wide(const uint32_t *s_inv, uint32_t pl, int k, uint32_t &ok16, uint32_t &nok16)
+{
+  const uint64_t V0 = inv_win64(s_inv, pl), V1 = inv_win64(s_inv, pl + 64), V2 = inv_win64(s_inv, pl + 128);
+  uint64_t M0 = V0, M1 = V1, M2 = V2;
+  for (int c = 1; c < k;) {  // uniform
+    const int s = min(c, k - c);
+    if (s < 64) {
+      M0 |= (M0 << s) | (M1 >> (64 - s));
+      M1 |= (M1 << s) | (M2 >> (64 - s));
+      M2 |= M2 << s;
+    } else {  // (s = 64 only for k = 127 .. : a whole word, then the rest)
+      const int t = s - 64;
+      M0 |= t ? (M1 << t) | (M2 >> (64 - t)) : M1;
+      M1 |= M2 << t;
+    }
+    c += s;
+  }
+  ok16 = ~(uint32_t)(M0 >> 48) & 0xFFFFu;
+  // base j + k: bit j + k of the window, counted from the top
+  const int wi = k >> 6, sh = k & 63;
+  const uint64_t a = wi == 0 ? V0 : V1, b = wi == 0 ? V1 : V2;
+  const uint64_t nx = sh ? (a << sh) | (b >> (64 - sh)) : a;
+  nok16 = ~(uint32_t)(nx >> 48) & 0xFFFFu;
+}
+
 // Fused build kernel: k-merise a stream tile by tile and insert straight into the table
 // (direct path; the deferred path of mcx_defer.h shares the front end helpers).
 template <int W, bool ONECOL, bool PK>
@@ -814,8 +854,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_stream(StreamArgs a, InsertSink
   const int k = a.k;
   uint32_t n_kmers = 0, n_contigs = 0, n_novel = 0, full = 0;
 
-  const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
-  const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);  // bit position of base 0 in w[0]
+  const uint64_t top_mask = ~0ULL >> (64 * W - 2 * k);
+  const int first_shift = 2 * k - 2 - 64 * (W - 1);  // bit position of base 0 in w[0]
 
   for (uint64_t tile = a.tile0 + blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
@@ -829,7 +869,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_stream(StreamArgs a, InsertSink
 
     const uint32_t pl = 16u * (uint32_t)(tid + 1);  // region index of this lane's first position
     const uint64_t Vh = inv_win64(s_inv, pl);
-    const uint64_t Vl = (W == 2) ? inv_win64(s_inv, pl + 64) : 0;
     const uint32_t prev_chunk_inv = (s_inv[(pl - 1) >> 5] >> (31 - ((pl - 1) & 31))) & 1u;
 
     // positions of this lane owned by the launch: j in [j_lo, j_hi)
@@ -837,6 +876,50 @@ __global__ __launch_bounds__(kThreads, 1) void k_stream(StreamArgs a, InsertSink
     const int j_lo = a.pos_lo > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_lo - P0) : 0;
     const int j_hi = a.pos_hi > P0 ? (int)min((uint64_t)kPosPerLane, a.pos_hi - P0) : 0;
 
+    if constexpr (W > 2) {
+      // three- and four-word keys: the same walk with the validity masks of lane_masks_wide and word loops
+      uint32_t ok16, nok16;
+      lane_masks_wide(s_inv, pl, k, ok16, nok16);
+      ok16 &= ((0x10000u >> j_lo) - 1u) & ~((0x10000u >> j_hi) - 1u);
+      const uint32_t pok16 = ~((prev_chunk_inv << 15) | (uint32_t)(Vh >> 49)) & 0xFFFFu;
+      Occ<W> occ[kBatch];
+      bool ov[kBatch];
+      if (ok16) {
+        Kmer<W> fw, rc;
+        const int topb = k - 32 * (W - 1);  // bases in the top word
+        fw.w[0] = code_win64(s_code, pl) >> (64 - 2 * topb);
+        for (int i = 1; i < W; i++) fw.w[i] = code_win64(s_code, pl + (uint32_t)(topb + 32 * (i - 1)));
+        rc = revcomp<W>(fw, k);
+        const uint64_t feed = code_win64(s_code, pl + (uint32_t)k);
+        const int fs = 2 * topb - 2;  // bit position of base 0 in w[0]
+        uint32_t prev_nuc = s_code[(pl - 1) >> 4] & 3u;
+#pragma unroll
+        for (int j = 0; j < kPosPerLane; j++) {
+          const bool valid = (ok16 >> (15 - j)) & 1u;
+          const bool next_ok = (nok16 >> (15 - j)) & 1u, prev_ok = (pok16 >> (15 - j)) & 1u;
+          const uint32_t nuc_next = (uint32_t)(feed >> (62 - 2 * j)) & 3u;
+          ov[j % kBatch] = valid;
+          if (valid) {
+            uint32_t o;
+            Occ<W> &x = occ[j % kBatch];
+            x.key = canonical<W>(fw, rc, o);
+            uint32_t e = 0;
+            if (next_ok) e |= 1u << (nuc_next + 4u * o);
+            if (prev_ok) e |= 1u << ((3u - prev_nuc) + 4u * (1u - o));
+            x.e = e;
+            n_kmers++;
+            n_contigs += prev_ok ? 0u : 1u;
+          }
+          if (j % kBatch == kBatch - 1) flush_batch<W, ONECOL>(isink, occ, ov, n_novel, full);
+          prev_nuc = kmer_first_base<W>(fw, k);
+          kmer_push<W>(fw, nuc_next, k);
+          for (int i = W - 1; i >= 1; i--) rc.w[i] = (rc.w[i] >> 2) | (rc.w[i - 1] << 62);
+          rc.w[0] = (rc.w[0] >> 2) | ((uint64_t)(3u - nuc_next) << fs);
+        }
+      }
+      continue;
+    }
+    const uint64_t Vl = (W == 2) ? inv_win64(s_inv, pl + 64) : 0;
     // any valid k-mer among this lane's 16 positions?
     bool any = false;
 #pragma unroll
@@ -927,8 +1010,7 @@ __global__ __launch_bounds__(kThreads) void k_insert_tuples(InsertSink<W, ONECOL
       ov[b] = i < n;
       if (i < n) {
         Occ<W> &x = occ[b];
-        x.key.w[0] = keys[i * W];
-        if (W == 2) x.key.w[W - 1] = keys[i * W + 1];
+        for (int w = 0; w < W; w++) x.key.w[w] = keys[i * W + w];
         x.e = edges[i];
         if (only_own && key_owner<W>(sink.t, x.key) != sink.t.part) ov[b] = false;
       }
@@ -1125,14 +1207,9 @@ __global__ void k_pcr_starts(TableView t, const uint8_t *bases, const uint8_t *q
   const uint64_t cs = qh_contig_start(seq, len, qual, 0, (uint64_t)k, qcut, hcut);
   uint64_t node = kNoNode;
   if (cs < len) {
-    const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
     Kmer<W> fw;
-    fw.w[0] = 0; if (W == 2) fw.w[W - 1] = 0;
-    for (uint64_t i = cs; i < cs + (uint64_t)k; i++) {
-      const uint32_t nuc = ((seq[i] >> 1) ^ (seq[i] >> 2)) & 3u;
-      if (W == 1) fw.w[0] = ((fw.w[0] << 2) | nuc) & top_mask;
-      else { fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask; fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc; }
-    }
+    for (int w = 0; w < W; w++) fw.w[w] = 0;
+    for (uint64_t i = cs; i < cs + (uint64_t)k; i++) kmer_push<W>(fw, ((seq[i] >> 1) ^ (seq[i] >> 2)) & 3u, k);
     const Kmer<W> rc = revcomp<W>(fw, k);
     uint32_t o, novel = 0, full = 0;
     const Kmer<W> key = canonical<W>(fw, rc, o);
@@ -1237,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_checksum(TableView t, uint32_t W, uint3
     if (!(r[0] & kFlag)) continue;
     uint64_t h = 0x9E3779B97F4A7C15ULL;
     h = mix64(h ^ (r[0] & kKeyMask));
-    if (W == 2) h = mix64(h ^ r[1]);
+    for (uint32_t w = 1; w < W; w++) h = mix64(h ^ r[w]);
     for (uint32_t c = 0; c < ncols; c++) {
       const uint64_t v = *val_ptr(t, slot, c);
       uint64_t cv = v >> 8;
@@ -1274,26 +1351,23 @@ __global__ void k_reads_must_exist(TableView t, const uint8_t *bases, const uint
   const uint8_t *seq = bases + off[r];
   const uint8_t *qual = (quals && qcut > 0) ? quals + off[r] : nullptr;
   const uint64_t len = off[r + 1] - off[r];
-  const uint64_t top_mask = (W == 1) ? (~0ULL >> (64 - 2 * k)) : (~0ULL >> (128 - 2 * k));
-  const int first_shift = (W == 1) ? (2 * k - 2) : (2 * k - 66);
   unsigned long long n_kmers = 0, n_contigs = 0, n_absent = 0;
   uint32_t dummy_novel = 0, full = 0;
   uint64_t cs, ce, search = 0;
   while ((cs = qh_contig_start(seq, len, qual, search, (uint64_t)k, qcut, hcut)) < len) {
     ce = qh_contig_end(seq, len, qual, cs, (uint64_t)k, qcut, hcut, &search);
     Kmer<W> fw;
-    fw.w[0] = 0; if (W == 2) fw.w[W - 1] = 0;
+    for (int w = 0; w < W; w++) fw.w[w] = 0;
     uint64_t prev_slot = kNoSlot;
     uint32_t prev_o = 0, prev_first = 0;
     for (uint64_t i = cs; i < ce; i++) {
       const uint32_t nuc = ((seq[i] >> 1) ^ (seq[i] >> 2)) & 3u;  // A C G T (either case) -> 0 1 2 3
-      if (W == 1) fw.w[0] = ((fw.w[0] << 2) | nuc) & top_mask;
-      else { fw.w[0] = ((fw.w[0] << 2) | (fw.w[W - 1] >> 62)) & top_mask; fw.w[W - 1] = (fw.w[W - 1] << 2) | nuc; }
+      kmer_push<W>(fw, nuc, k);
       if (i + 1 < cs + (uint64_t)k) continue;  // first k - 1 bases
       const Kmer<W> rc = revcomp<W>(fw, k);
       uint32_t o;
       const Kmer<W> key = canonical<W>(fw, rc, o);
-      const uint32_t first = (uint32_t)(fw.w[0] >> first_shift) & 3u;  // first base of this k-mer, read strand
+      const uint32_t first = kmer_first_base<W>(fw, k);  // first base of this k-mer, read strand
       if (phase == 0) {
         const uint64_t slot = find_or_insert_rec<W>(t, key, true, dummy_novel, full);
         if (slot != kNoSlot) {
@@ -1399,7 +1473,7 @@ __global__ __launch_bounds__(kThreads) void k_compact(TableView t, uint64_t *key
         const int nb0 = 2 * kmer_size - 64 * (W - 1);  // key bits in the top word
         uint64_t top;
         if ((int)pbits <= nb0) top = kw >> (nb0 - (int)pbits);
-        else top = (kw << ((int)pbits - nb0)) | (key_ptr(t, s0 + i)[W - 1] >> (64 - ((int)pbits - nb0)));
+        else top = (kw << ((int)pbits - nb0)) | (key_ptr(t, s0 + i)[1] >> (64 - ((int)pbits - nb0)));  // (pbits <= 30: the top word and the next)
         take = top == prefix;
       }
       occ |= (uint32_t)take << i;
@@ -1441,6 +1515,35 @@ __global__ void k_iota(uint64_t *dst, uint64_t n)
   if (i < n) dst[i] = i;
 }
 
+// Keys of more than two words (k > 63): the LSD passes of a sort fetch one key word at a time, through the permutation
+// so far, from the table (export) or from byte-packed records (`sort`).
+__global__ void k_gather_keyword(TableView t, const uint64_t *slot_of, const uint64_t *perm, uint32_t w, uint64_t *dst, uint64_t n)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const uint64_t x = key_ptr(t, slot_of[perm[i]])[w]; dst[i] = w ? x : (x & kKeyMask); }
+}
+__global__ void k_gather_record_word(const uint8_t *recs, uint32_t rec_bytes, const uint64_t *perm, uint32_t w, uint64_t *dst, uint64_t n)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *p = recs + perm[i] * rec_bytes + 8 * w;
+  dst[i] = (uint64_t)load_le32(p) | (uint64_t)load_le32(p + 4) << 32;
+}
+// strictly increasing W-word keys of byte-packed records?  flags the first violation
+__global__ void k_check_sorted_records(const uint8_t *recs, uint32_t rec_bytes, uint32_t W, uint64_t n, unsigned long long *first_bad)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 >= n) return;
+  const uint8_t *a = recs + i * rec_bytes, *b = a + rec_bytes;
+  bool lt = false;
+  for (uint32_t w = 0; w < W; w++) {
+    const uint64_t x = (uint64_t)load_le32(a + 8 * w) | (uint64_t)load_le32(a + 8 * w + 4) << 32;
+    const uint64_t y = (uint64_t)load_le32(b + 8 * w) | (uint64_t)load_le32(b + 8 * w + 4) << 32;
+    if (x != y) { lt = x < y; break; }
+  }
+  if (!lt) atomicMin(first_bad, (unsigned long long)(i + 1));
+}
+
 // Final gather in sorted order: record i comes from compact index perm[i].
 // Writes .ctx body records (W*8 key bytes, ncols u32 covg, ncols u8 edges;
 // graph_writer.c:116-127) for records [first, first+count).
@@ -1454,9 +1557,9 @@ __global__ void k_emit_records(TableView t, const uint64_t *slot_of, const uint6
   const uint64_t *r = key_ptr(t, s);
   const uint32_t recsz = 8u * W + 5u * ncols;
   uint8_t *o = out + i * recsz;
-  uint64_t kw[2];
+  uint64_t kw[W];
   kw[0] = r[0] & kKeyMask;
-  if (W == 2) kw[1] = r[1];
+  for (int w = 1; w < W; w++) kw[w] = r[w];
   for (int w = 0; w < W; w++)
     for (int b = 0; b < 8; b++) o[w * 8 + b] = (uint8_t)(kw[w] >> (8 * b));
   for (uint32_t c = 0; c < ncols; c++) {

@@ -1,6 +1,6 @@
 // mcx_kmer.h -- k-mer primitives shared by the gfx950 kernels and the host
 // helpers of the C ABI.  W = number of 64-bit words (1 for k<=31, 2 for
-// 33<=k<=63); w[0] is the most significant (partial) word, first base at the
+// 33<=k<=63, 3 for 65<=k<=95, 4 for 97<=k<=127); w[0] is the most significant (partial) word, first base at the
 // top, exactly the BinaryKmer layout of the reference
 // (src/graph/binary_kmer.h:10-18, :39-45).
 #pragma once
@@ -57,14 +57,20 @@ template <int W> struct Kmer { uint64_t w[W]; };
 template <int W> MCX_HD Kmer<W> revcomp(const Kmer<W> &x, int k)
 {
   Kmer<W> r;
-  const int shift = 64 * W - 2 * k;  // unused high bits of w[0]
+  const int shift = 64 * W - 2 * k;  // unused high bits of w[0]: 2..62 for the odd k of a W-word build
   if (W == 1) {
     r.w[0] = revcomp_word(x.w[0]) >> shift;
-  } else {
+  } else if (W == 2) {
     const uint64_t hi = revcomp_word(x.w[W - 1]);  // becomes most significant
     const uint64_t lo = revcomp_word(x.w[0]);
     r.w[0] = hi >> shift;
     r.w[W - 1] = (lo >> shift) | (hi << (64 - shift));  // 2 <= shift <= 62 for odd k in 33..63
+  } else {
+    // the words in reverse order, each reverse-complemented, then the 64 W-bit number moved down by `shift`
+    uint64_t t[W];
+    for (int i = 0; i < W; i++) t[i] = revcomp_word(x.w[W - 1 - i]);
+    r.w[0] = t[0] >> shift;
+    for (int i = 1; i < W; i++) r.w[i] = (t[i] >> shift) | (t[i - 1] << (64 - shift));
   }
   return r;
 }
@@ -72,7 +78,28 @@ template <int W> MCX_HD Kmer<W> revcomp(const Kmer<W> &x, int k)
 template <int W> MCX_HD bool kmer_less(const Kmer<W> &a, const Kmer<W> &b)
 {
   if (W == 1) return a.w[0] < b.w[0];
-  return a.w[0] != b.w[0] ? a.w[0] < b.w[0] : a.w[W - 1] < b.w[W - 1];
+  if (W == 2) return a.w[0] != b.w[0] ? a.w[0] < b.w[0] : a.w[W - 1] < b.w[W - 1];
+  for (int i = 0; i < W - 1; i++)
+    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+  return a.w[W - 1] < b.w[W - 1];
+}
+template <int W> MCX_HD bool kmer_equal(const Kmer<W> &a, const Kmer<W> &b)
+{
+  bool e = true;
+  for (int i = 0; i < W; i++) e = e && a.w[i] == b.w[i];
+  return e;
+}
+
+// Roll a k-mer one base on (binary_kmer.h:139-167, binary_kmer_left_shift_add): the first base leaves, nuc is appended
+template <int W> MCX_HD void kmer_push(Kmer<W> &x, uint32_t nuc, int k)
+{
+  for (int i = 0; i < W - 1; i++) x.w[i] = (x.w[i] << 2) | (x.w[i + 1] >> 62);
+  x.w[W - 1] = (x.w[W - 1] << 2) | nuc;
+  x.w[0] &= ~0ULL >> (64 * W - 2 * k);
+}
+template <int W> MCX_HD uint32_t kmer_first_base(const Kmer<W> &x, int k)
+{
+  return (uint32_t)(x.w[0] >> (2 * k - 2 - 64 * (W - 1))) & 3u;
 }
 
 // binary_kmer.c:43-57 + db_node.h:109-110: key = min(kmer, revcomp), orient =
@@ -121,12 +148,24 @@ template <int W> MCX_HD uint32_t kmer_hash(const Kmer<W> &key, uint32_t initval,
 {
   uint32_t a, b, c;
   a = b = c = 0xdeadbeefu + 8u * W + initval;
-  a += (uint32_t)key.w[0];
-  b += (uint32_t)(key.w[0] >> 32);
-  if (W == 2) {
-    c += (uint32_t)key.w[W - 1];
-    lk3_mix(a, b, c);
-    a += (uint32_t)(key.w[W - 1] >> 32);
+  if (W <= 2) {
+    a += (uint32_t)key.w[0];
+    b += (uint32_t)(key.w[0] >> 32);
+    if (W == 2) {
+      c += (uint32_t)key.w[W - 1];
+      lk3_mix(a, b, c);
+      a += (uint32_t)(key.w[W - 1] >> 32);
+    }
+  } else {
+    // 2 W 32-bit halves in memory order (low half of w[0] first): blocks of three are mixed while more than three
+    // are left ("while (length > 12)" of hashlittle), the last one to three go into a, b, c before final()
+    uint32_t h[2 * W];
+    for (int i = 0; i < W; i++) { h[2 * i] = (uint32_t)key.w[i]; h[2 * i + 1] = (uint32_t)(key.w[i] >> 32); }
+    int p = 0, n = 2 * W;
+    while (n > 3) { a += h[p]; b += h[p + 1]; c += h[p + 2]; lk3_mix(a, b, c); p += 3; n -= 3; }
+    if (n >= 1) a += h[p];
+    if (n >= 2) b += h[p + 1];
+    if (n >= 3) c += h[p + 2];
   }
   lk3_final(a, b, c);
   if (second) *second = b;

@@ -626,6 +626,8 @@ extern "C" int mcx_graph_create_multi(mcx_graph **out, int kmer_size, int ncols,
   if (ndevices > 32 || (ndevices & (ndevices - 1)))
     return fail(MCX_ERR_ARG, "the table is split by hash prefix: the number of devices must be a power of two <= 32 (got %d)", ndevices);
   if (check_k(kmer_size) != MCX_OK) return MCX_ERR_ARG;
+  if (kmer_size > 63)
+    return fail(MCX_ERR_ARG, "k > 63 (three- and four-word keys) builds on one device: the exchange formats carry at most two key words");
   const int W = words_for_k(kmer_size);
   // every shard needs the partitioned insert path (>= 64 regions of one sub-table each)
   const uint64_t min_shard = 64ull << sub_shift_for_words(W);

@@ -156,21 +156,21 @@ def _words(k):
 
 
 def kmer_from_str(s, k):
-    out = (C.c_uint64 * 2)()
+    out = (C.c_uint64 * 4)()
     lib().mcx_kmer_from_str(s.encode() if isinstance(s, str) else s, k, out)
     return [int(out[i]) for i in range(_words(k))]
 
 
 def kmer_canonical(words, k):
-    a = (C.c_uint64 * 2)(*words)
-    out = (C.c_uint64 * 2)()
+    a = (C.c_uint64 * 4)(*words)
+    out = (C.c_uint64 * 4)()
     o = C.c_int()
     lib().mcx_kmer_canonical(a, k, out, C.byref(o))
     return [int(out[i]) for i in range(_words(k))], int(o.value)
 
 
 def kmer_hash(words, k, initval=0):
-    a = (C.c_uint64 * 2)(*words)
+    a = (C.c_uint64 * 4)(*words)
     return int(lib().mcx_kmer_hash(a, k, initval))
 
 

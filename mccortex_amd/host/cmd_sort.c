@@ -212,7 +212,7 @@ int ctx_index(int argc, char **argv)
 
   fputs("#block_start\tnext_block\tfirst_kmer\tkmer_idx\tnext_kmer_idx\n", fout);
   unsigned char *blk = malloc(block_size);
-  unsigned char prev[16] = {0};
+  unsigned char prev[8 * ((2 * MAX_KMER_SIZE + 63) / 64)] = {0}; /* the previous block's first k-mer */
   char kstr[2 * MAX_KMER_SIZE + 8];
   if (!blk) die("Out of memory");
   size_t nblocks = 0, bl_bytes = 0, bl_kmers = 0, bl_byte_offset = r.hdr_size, bl_kmer_offset = 0;

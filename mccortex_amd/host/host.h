@@ -12,10 +12,17 @@
 #ifndef MAX_KMER_SIZE
 #define MAX_KMER_SIZE 31
 #endif
+/* MIN_KMER_SIZE = MAXK - 30, and 3 for MAXK = 31 (reference Makefile:33-48); literals, because the usage texts print them */
 #if MAX_KMER_SIZE == 31
-#define MIN_KMER_SIZE 3 /* reference Makefile:48 */
+#define MIN_KMER_SIZE 3
+#elif MAX_KMER_SIZE == 63
+#define MIN_KMER_SIZE 33
+#elif MAX_KMER_SIZE == 95
+#define MIN_KMER_SIZE 65
+#elif MAX_KMER_SIZE == 127
+#define MIN_KMER_SIZE 97
 #else
-#define MIN_KMER_SIZE (MAX_KMER_SIZE - 30)
+#error "MAX_KMER_SIZE must be 31, 63, 95 or 127 (three- and four-word keys are the widest the backend builds)"
 #endif
 #define MCX_STR_(x) #x
 #define MCX_STR(x) MCX_STR_(x)

@@ -55,10 +55,10 @@ def test_hash_matches_reference_lookup3(orc):
             assert L.orc_kmer_hash(x, k, iv) == R.ref_lk3_hashlittle(a.ctypes.data, 8 * W, iv)
 
 
-@pytest.mark.parametrize("k", [3, 15, 29, 31, 33, 47, 63])
+@pytest.mark.parametrize("k", [3, 15, 29, 31, 33, 47, 63, 65, 79, 95, 97, 111, 127])
 def test_hash_matches_reference_kmer_hash_h(orc, mcx, k):
     """The reference's own BinaryKmer hash -- bklk3_hashlittle, src/kmer/kmer_hash.h:162-211, compiled unmodified
-    into oracle/_ref with NUM_BKMER_WORDS = 1 and 2 -- against the oracle's orc_kmer_hash and the product's host
+    into oracle/_ref with NUM_BKMER_WORDS = 1 .. 4 -- against the oracle's orc_kmer_hash and the product's host
     template mcx_kmer_hash (the device uses the same template: mcx_kmer.h kmer_hash<W>), on canonical keys and
     arbitrary seeds (hash_table.c:132-145 rehashes with seed + i)."""
     L = orc.lib()
@@ -77,13 +77,13 @@ def test_hash_matches_reference_kmer_hash_h(orc, mcx, k):
             assert mcx.kmer_hash([int(w) for w in a], k, iv) == want
 
 
-@pytest.mark.parametrize("k", list(range(3, 64, 2)))
+@pytest.mark.parametrize("k", list(range(3, 128, 2)))
 def test_revcomp_matches_reference_revcmp(orc, mcx, k):
     """orc_kmer_revcomp / orc_kmer_get_key and the product's host template mcx_kmer_canonical against
     the reference's own code: dev/bkmer_revcmp/revcmp.c (all four binary_kmer_reverse_complement{1..4};
     number 2 is src/graph/binary_kmer.c:102-133 line for line), compiled unmodified with
-    NUM_BKMER_WORDS = 1 and 2 into oracle/_ref.  Pins the b[0]-is-the-top-word layout, the base order
-    inside a word and the shift across words for every odd k up to 63."""
+    NUM_BKMER_WORDS = 1 .. 4 into oracle/_ref.  Pins the b[0]-is-the-top-word layout, the base order
+    inside a word and the shift across words for every odd k up to 127 (mccortex95 / mccortex127)."""
     L = orc.lib()
     W = L.orc_words_for_k(k)
     R = orc.ref_revcmp(W)
@@ -91,7 +91,7 @@ def test_revcomp_matches_reference_revcmp(orc, mcx, k):
         pytest.skip("oracle/_ref/librevcmp%d.so not built (needs /root/reference at build time)" % W)
     rng = np.random.default_rng(100 + k)
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
-    buf = C.create_string_buffer(128)
+    buf = C.create_string_buffer(160)
     cases = [_rand_kmer(rng, k) for _ in range(60)] + ["A" * k, "T" * k, "C" * k, "G" * k, "AC" * (k // 2) + "G"]
     for s in cases:
         x = L.orc_kmer_from_str(s.encode(), k)
