@@ -1088,11 +1088,12 @@ def main():
     args = ap.parse_args()
     if not args.defer_tuples:
         # One flush for the timed region: every flush streams the 16 GiB table through LDS once, and the part has the HBM
-        # for it (bins 8.5 B per reserved occurrence).  A launch reserves one occurrence per START POSITION of its piece of
-        # stream (an upper bound of the k-mers it yields: 151 positions per 120 k-mers here), so the window is counted in
-        # positions: 20 steps x 5 M reads x 151 = 15.1 G -> 128 GB of bins beside the table, the inputs and the sub-table bins.
-        pos = args.steps * args.batch_reads * (READ_LEN + 1)
-        args.defer_tuples = max(DEFER_TUPLES, min(int(pos * 1.01), 16_000_000_000))
+        # for it (bins 8.5 B per buffered occurrence).  A launch is booked with one occurrence per START POSITION of its
+        # piece of stream (151 per 120 k-mers here) and the excess comes off the books when the launch has settled --
+        # before a full-looking window costs a flush the library waits for that (settle_for_room), so the window is counted
+        # in k-mers plus the launches that may be in flight: 20 steps x 5 M reads = 12.0 G -> 12.4 G (105 GB of bins).
+        occ = args.steps * args.batch_reads * (READ_LEN - K + 1)
+        args.defer_tuples = max(DEFER_TUPLES, min(int(occ * 1.035), 16_000_000_000))
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 (make,
     # RCCL's version banner, ...) is sent to stderr

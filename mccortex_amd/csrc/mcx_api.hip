@@ -1048,12 +1048,36 @@ static void snap_poll(mcx_graph *g)
   }
 }
 
+// Is there a bin set that takes `need` more occurrences of `colour`?
+static bool defer_has_room(const mcx_graph *g, int colour, uint64_t need)
+{
+  for (uint32_t s = 0; s < g->nsets; s++)
+    if (g->set_colour[s] < 0 || (g->set_colour[s] == colour && g->set_pending[s] + need <= g->set_cap)) return true;
+  return false;
+}
+// A launch is booked with an upper bound (one occurrence per start position of its piece of stream; every position of a
+// piece for an owner of exchange v3) and the excess comes off the books when the launch has settled (snap_poll).  The
+// host runs ahead of the device, so a window can look full while most of it is such unsettled excess: before that costs
+// a flush -- a pass over the whole table -- wait for the oldest launches, one at a time, until there is room or
+// nothing is left to settle.  (C2: 151 booked positions per 120 k-mers; 20 steps fit a 12.4 G window instead of 15.3 G.)
+static void settle_for_room(mcx_graph *g, int colour, uint64_t need)
+{
+  if (!g->h_snap) return;
+  while (!defer_has_room(g, colour, need) && g->snap_tail != g->snap_head) {
+    if (hipEventSynchronize(g->snap[g->snap_tail % mcx_graph::kSnap].ev) != hipSuccess) { (void)hipGetLastError(); return; }
+    const uint32_t before = g->snap_tail;
+    snap_poll(g);
+    if (g->snap_tail == before) return;  // (cannot happen: the event has completed)
+  }
+}
+
 static int defer_reserve(mcx_graph *g, int colour, uint64_t ub, int *set_out = nullptr)
 {
   if (set_out) *set_out = 0;
   int rc = ensure_defer(g);
   if (rc != MCX_OK || !g->defer) return rc;
   snap_poll(g);
+  settle_for_room(g, colour, ub);
   for (int pass = 0; pass < 2; pass++) {
     int free_set = -1;
     for (uint32_t s = 0; s < g->nsets; s++) {
@@ -1116,6 +1140,7 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
   // pieces of at most defer_tuples start positions (an upper bound of the tuples they yield)
   snap_poll(g);
   for (uint64_t lo = L.pos_lo; lo < L.pos_hi;) {
+    settle_for_room(g, colour, std::min<uint64_t>(L.pos_hi - lo, g->set_cap));
     // a piece goes to ONE set: what is left of the colour's current set, or a fresh set
     uint64_t room = g->set_cap;
     for (uint32_t s = 0; s < g->nsets; s++)
