@@ -62,8 +62,12 @@ int mcx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* Replaces db_graph_alloc (src/graph/db_graph.c:23) + hash_table_alloc
  * (src/graph/hash_table.c:16-52) for the build path.
- *   kmer_size       odd, 3..63 (W = 1 word for k<=31, 2 words for 33..63;
- *                   src/graph/binary_kmer.h:10-18)
+ *   kmer_size       odd, 3..127 (W = 1 word for k<=31, 2 words for 33..63, 3 for
+ *                   65..95, 4 for 97..127: the reference's MAXK = 31 / 63 / 95 / 127
+ *                   builds, src/graph/binary_kmer.h:10-18, Makefile:33-48).  k > 63
+ *                   builds on one device with the fused insert kernel (one HBM
+ *                   atomic per occurrence); the partitioned insert, the exchange
+ *                   formats and mcx_graph_create_multi are for k <= 63.
  *   ncols           colours (>=1); coverage and edges are kept per colour
  *   capacity_kmers  minimum number of k-mer slots (the reference's -n); the
  *                   slot layout, probe sequence and seed are free because

@@ -189,7 +189,12 @@ struct mcx_graph {
   uint32_t nsub = 0;            // sub-tables
   uint32_t b1 = 0, subs_per_bin = 0;
   uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 (replica, bin) segment / per L2 (sub-table) bin
-  uint32_t rep1 = 8;            // replicas of every L1 bin (one per XCD); MCX_REP1: experiments (k_stream_fc with private replicas)
+  // Replicas of every L1 bin.  A block appends to replica blockIdx % rep1; all blocks of a replica reserve from the same 64
+  // counter lines once per tile.  8 (one per XCD) until round 6; 32 for a one-colour graph with a large flush window since:
+  // k_stream_bin 23.3 -> 21.2 ms per 6 G occurrences at C2 (16: 21.7, 64: 20.6, 128: 20.5, but the split then pays for its
+  // many short segments: 21.9 / 22.3 / 22.9 ms; profiles/r06_experiments.md).  Chosen in ensure_defer; MCX_REP1 forces it.
+  uint32_t rep1 = 8;
+  bool rep1_forced = false;
   uint64_t *l1_keys = nullptr, *l2_keys = nullptr;  // packed tuples: W words each
   uint64_t l2_off = 0;            // first sub-table bin the next split / insert launch uses (flush overlap: two halves)
   hipStream_t stream2 = nullptr;  // flush overlap: the LDS insert of group g runs beside the split of group g + 1
@@ -400,7 +405,7 @@ extern "C" int mcx_graph_create_shard(mcx_graph **out, int kmer_size, int ncols,
   // occurrence: the partition path's tuple formats and LDS images are laid out for one and two key words
   if (g->W > 2) g->defer = false;
   { const char *e = getenv("MCX_GRID_STREAM"); if (e) g->grid_stream = atoi(e); }  // experiments
-  { const char *e = getenv("MCX_REP1"); if (e && atoi(e) >= 1 && atoi(e) <= 4096) g->rep1 = (uint32_t)atoi(e); }
+  { const char *e = getenv("MCX_REP1"); if (e && atoi(e) >= 1 && atoi(e) <= 4096) { g->rep1 = (uint32_t)atoi(e); g->rep1_forced = true; } }
   { const char *e = getenv("MCX_GRID_SPLIT"); if (e) g->grid_split = atoi(e); }
   { const char *e = getenv("MCX_GRID_INSERT"); if (e) g->grid_insert = atoi(e); }
   g->table_bytes = slots * g->t.S * 8;
@@ -856,6 +861,8 @@ static int ensure_defer(mcx_graph *g)
     g->nsets = g->ncols > 1 ? kL1Sets : 1;
     if (const char *e = getenv("MCX_L1_SETS")) { const int v = atoi(e); if (v >= 1 && v <= 32) g->nsets = (uint32_t)v; }  // tests / experiments
     g->set_cap = tcap / g->nsets;
+    // (32 replicas only where a segment still holds many tiles: the split reads segments tile by tile)
+    if (!g->rep1_forced) g->rep1 = (g->nsets == 1 && g->set_cap / g->b1 / 32 >= (1u << 16)) ? 32 : 8;
     g->cap1 = (uint64_t)((double)g->set_cap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + (g->nsets > 1 ? 2048 : 8192);
     g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
     g->cap1 = (g->cap1 + 1) & ~1ull;  // even: every segment starts 16-byte aligned (vector loads)

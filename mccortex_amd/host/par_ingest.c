@@ -203,6 +203,15 @@ static void *worker_main(void *arg)
  * tools/exp_parse.sh: parse alone 80 ms, teardown 150 ms) -- a third of the whole ingest.  A detached thread does it
  * while the caller goes on to flush, sort and write the graph. */
 typedef struct { worker *w; int nw; void *base; size_t size; } teardown_job;
+/* (One teardown at a time: the next file's par_ingest joins the previous one before it allocates its own buffers --
+ * with several --seq inputs the two sets, 2 x nthreads x up to 64 MB each, would otherwise overlap for a moment,
+ * outside what -m accounts for.  The last input's teardown is simply left behind at exit.) */
+static pthread_t g_teardown_th;
+static bool g_teardown_live = false;
+static void join_teardown(void)
+{
+  if (g_teardown_live) { pthread_join(g_teardown_th, NULL); g_teardown_live = false; }
+}
 static void *teardown_main(void *arg)
 {
   teardown_job *j = arg;
@@ -249,6 +258,7 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
   pthread_cond_init(&c.cv_ready, NULL);
   pthread_cond_init(&c.cv_free, NULL);
   c.nw = nthreads;
+  join_teardown(); /* the previous input's buffers are back before this one's are taken */
   c.w = calloc((size_t)nthreads, sizeof(worker));
   const unsigned char *prev = base;
   for (int t = 0; t < nthreads; t++) {
@@ -314,14 +324,10 @@ int par_ingest(const char *path, seq_fmt fmt, int nthreads, bool want_quals, siz
   pthread_cond_destroy(&c.cv_free);
   {
     teardown_job *j = malloc(sizeof(*j));
-    pthread_t th;
-    pthread_attr_t at;
     if (!j) die("Out of memory");
     *j = (teardown_job){c.w, nthreads, (void *)base, size};
-    pthread_attr_init(&at);
-    pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
-    if (getenv("MCX_SYNC_TEARDOWN") || pthread_create(&th, &at, teardown_main, j) != 0) teardown_main(j);
-    pthread_attr_destroy(&at);
+    if (getenv("MCX_SYNC_TEARDOWN") || pthread_create(&g_teardown_th, NULL, teardown_main, j) != 0) teardown_main(j);
+    else g_teardown_live = true;
   }
   if (timing)
     fprintf(stderr, "[timing] par_ingest %s: %d threads, %.1f MB: set-up %.1f ms, parse + submit %.1f ms (of which inside submit %.1f), teardown %.1f ms\n",

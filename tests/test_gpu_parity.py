@@ -69,6 +69,16 @@ def test_random_reads_match_oracle(mcx, orc, k):
     _compare(mcx, orc, k, 1, [(0, bases, offs)])
 
 
+@pytest.mark.parametrize("rep", [1, 16, 32])
+def test_replicas_of_the_region_bins(mcx, orc, rep, monkeypatch):
+    """The region bins exist in `rep` replicas (8, or 32 for a large one-colour window: mcx_api.hip rep1); MCX_REP1
+    forces the count, so the small graphs of this suite meet the other layouts too."""
+    monkeypatch.setenv("MCX_REP1", str(rep))
+    bases, offs = synth.reads(4000, 120, genome_len=30000, seed=70 + rep, n_frac=0.05, lower_frac=0.1)
+    _compare(mcx, orc, 31, 1, [(0, bases, offs)])
+    _compare(mcx, orc, 55, 2, [(0, bases, offs), (1, bases[: int(offs[1500])], offs[:1501])], names=["a", "b"])
+
+
 def test_ragged_and_empty_reads(mcx, orc):
     bases, offs = synth.reads(5000, 40, genome_len=5000, seed=3, n_frac=0.2, var_len=True)
     _compare(mcx, orc, 31, 1, [(0, bases, offs)])
