@@ -45,7 +45,8 @@ TABLE_SLOTS = 1 << 30
 ALG_BYTES_PER_KMER = 21.25   # 1.25 input + 8 key + 8 covg RMW + ~4 edge RMW
 ALG_BYTES_PER_NOVEL = 8.0    # key write when the node is new
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-DEFER_TUPLES = 8_000_000_000  # k-mer occurrences buffered per flush of the partition->LDS-insert path
+DEFER_TUPLES = 8_000_000_000  # k-mer occurrences buffered per flush of the partition->LDS-insert path (the least `value` uses)
+HEADLINE_DEFER = DEFER_TUPLES  # what `value` was measured with (main() sets it: the whole timed region in one flush)
 # algorithmic bytes per k-mer occurrence of every kernel of that path
 KERNEL_ALG_BYTES = {"k_stream": 21.25, "k_stream_bin": 1.25 + 8.0, "k_tuples_bin": 16.0, "k_lds_insert": 8.0,
                     "k_insert_tuples": 29.0, "k_stream_superk": 1.25 + 2.3, "k_superk_bin": 2.3 + 8.0}
@@ -477,25 +478,26 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
     r["what"] = "as `value`, but with the library's default flush size instead of %d occurrences" % DEFER_TUPLES
     out["default_defer"] = r
     if pk is not None:  # the same build from the ASCII form of the stream (what `value` is by default)
-        r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, DEFER_TUPLES, None)
+        r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, HEADLINE_DEFER, None)
         r["what"] = "as `value`, but the resident stream is ASCII (1 byte per position; the kernel encodes it in its tile prologue)"
         out["ascii_resident"] = r
     else:               # ... and from the packed form the host entry stages (packing outside the clock: round 2's `value`)
         pk2 = pack_batches(mcx, steps)
-        r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, DEFER_TUPLES, pk2)
+        r = run_config(mcx, steps, K, 1, [0] * len(steps), table_slots, HEADLINE_DEFER, pk2)
         r["what"] = "as `value`, but the resident stream is already packed (2-bit codes + invalid flags, 3 bits per position): the packing is OUTSIDE this clock"
         out["packed_resident"] = r
         del pk2
         torch.cuda.empty_cache()
     # (e) C4: k = 63 (two-word keys); C5-like: 4 colours on one GPU
-    # (flush size: the stream positions of all steps -- the library books a device-resident stream launch with the
-    # positions it covers, 1.7x the k-mers it yields at k = 63 -- so that the build makes ONE table pass like C2's)
-    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, max(5_000_000_000, len(steps) * B * (READ_LEN + 1) + (1 << 26)), pk, isolated=True)
+    # (flush size: the k-mers of all steps + the launches in flight, as for `value` -- the library books a stream launch with
+    # the positions it covers, 1.7x the k-mers it yields at k = 63, and takes the excess off the books as launches settle --
+    # so that the build makes ONE table pass like C2's: 9.1 G two-word tuples = 154 GB of bins at 20 steps)
+    r = run_config(mcx, steps, 63, 1, [0] * len(steps), table_slots, max(5_000_000_000, int(len(steps) * B * (READ_LEN - 63 + 1) * 1.035) + B * (READ_LEN + 1)), pk, isolated=True)
     r["workload"] = "C4: k=63 (2-word BinaryKmer), 1 colour, %d reads x %d bp per step, table %d slots, 1 GPU" % (B, READ_LEN, table_slots)
     out["other_configs"] = {"C4_k63": r}
     # (4 colours: the L1 workspace is a pool of bin sets shared by the colours, sized here to hold all 20 steps,
     # so that the build makes one table pass per colour however the samples are ordered)
-    c5_defer = max(6_000_000_000, len(steps) * B * (READ_LEN + 1) + (1 << 28))
+    c5_defer = max(6_000_000_000, int(len(steps) * B * (READ_LEN - K + 1) * 1.035) + 2 * B * (READ_LEN + 1))
     cols = [min(3, 4 * i // max(1, len(steps))) for i in range(len(steps))]
     r = run_config(mcx, steps, K, 4, cols, table_slots, c5_defer, pk)
     r["workload"] = "C5-like: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
@@ -1094,6 +1096,8 @@ def main():
         # in k-mers plus the launches that may be in flight: 20 steps x 5 M reads = 12.0 G -> 12.4 G (105 GB of bins).
         occ = args.steps * args.batch_reads * (READ_LEN - K + 1)
         args.defer_tuples = max(DEFER_TUPLES, min(int(occ * 1.035), 16_000_000_000))
+    global HEADLINE_DEFER
+    HEADLINE_DEFER = args.defer_tuples
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 (make,
     # RCCL's version banner, ...) is sent to stderr
