@@ -497,7 +497,7 @@ def extras(mcx, batches, packed, nsteps, table_slots, oracle_steps=0, full_e2e=T
     out["other_configs"] = {"C4_k63": r}
     # (4 colours: the L1 workspace is a pool of bin sets shared by the colours, sized here to hold all 20 steps,
     # so that the build makes one table pass per colour however the samples are ordered)
-    c5_defer = max(6_000_000_000, int(len(steps) * B * (READ_LEN - K + 1) * 1.035) + 2 * B * (READ_LEN + 1))
+    c5_defer = max(6_000_000_000, len(steps) * B * (READ_LEN + 1) + (1 << 28))  # (counted in start positions: a colour's bookings are spread over its bin sets)
     cols = [min(3, 4 * i // max(1, len(steps))) for i in range(len(steps))]
     r = run_config(mcx, steps, K, 4, cols, table_slots, c5_defer, pk)
     r["workload"] = "C5-like: k=31, 4 colours (steps dealt out to samples %s), table %d slots, ONE GPU" % (cols, table_slots)
