@@ -46,6 +46,8 @@ ALG_BYTES_PER_KMER = 21.25   # 1.25 input + 8 key + 8 covg RMW +
 ALG_BYTES_PER_NOVEL = 8.0    # key write when the node is new
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DEFER_TUPLES = 8_000_000_000  # k-mer occurrences buffered per flush of the partition->LDS-insert path (the least `value` uses)
+PLACE_BINS = 8  # mcx_graph_configure("place_bins"): each half of the sub-table bins is the best of up to this many allocations by the
+                # split's write-pattern probe (where 8 GB of bins lie in HBM decides 13 % of the split: profiles/r06_experiments.md)
 HEADLINE_DEFER = DEFER_TUPLES  # what `value` was measured with (main() sets it: the whole timed region in one flush)
 # algorithmic bytes per k-mer occurrence of every kernel of that path
 KERNEL_ALG_BYTES = {"k_stream": 21.25, "k_stream_bin": 1.25 + 8.0, "k_tuples_bin": 16.0, "k_lds_insert": 8.0,
@@ -293,6 +295,7 @@ def run_config(mcx, batches, k, ncols, colours, table_slots, defer_tuples, packe
     per-kernel durations that mean something; `value` is the first pass (overlap on, the default)."""
     import torch
     g = mcx.Graph(k, ncols, table_slots)
+    g.configure("place_bins", PLACE_BINS)
     if defer_tuples:
         g.configure("defer_tuples", defer_tuples)
     for key, v in (cfg or {}).items():
@@ -1174,6 +1177,7 @@ def main():
     if args.direct:
         graph.configure("defer", 0)
     else:
+        graph.configure("place_bins", PLACE_BINS)
         graph.configure("defer_tuples", args.defer_tuples)
         # the bin workspace is allocated on first use (the library halves the flush size by itself
         # if HBM is short): touch it outside the timed region
@@ -1258,6 +1262,7 @@ def main():
                        "table_slots_per_gpu": slots_per_gpu, "table_slots_total": slots_per_gpu,
                        "sharding": "none",
                        "insert_path": "direct HBM atomics" if args.direct else "partition + LDS insert, %d occurrences per flush" % args.defer_tuples,
+                       "sub_table_bins": "each half of the flush overlap the best of up to %d allocations by the split's write-pattern probe (mcx_graph_configure place_bins: where the bins lie in HBM decides 13 %% of the split)" % PLACE_BINS,
                        "kmers_inserted": int(kmers_total), "distinct_kmers_rank0": int(st.num_kmers_novel),
                        "distinct_kmers_total": nodes_total, "graph_checksum": "%016x" % cs_total,
                        "table_passes_rank0": ist["flushes"], "fallback_inserts_rank0": ist["fallback_inserts"], "foreign_inserts_rank0": ist["foreign_inserts"]},

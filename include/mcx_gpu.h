@@ -100,6 +100,11 @@ int mcx_graph_reset(mcx_graph *g);
  *                  background, one group of table regions at a time (MCX_IDLE_FLUSH=0: off).
  *   "flush_regions" table regions split + applied per step of a flush (0 = automatic: 16 K sub-tables
  *                  per step); bounds the sub-table bin workspace to that share of the table
+ *   "place_bins"   1 (default) .. 8: the sub-table bin workspace is the best of up to n allocations -- each half of the
+ *                  flush overlap chosen by itself -- by a probe that writes the split kernel's pattern (16 K fronts,
+ *                  128-byte runs) into them: where 8 GB of bins happen to lie in HBM decides 13 % of that kernel
+ *                  (37.9-38.6 against 43.8-44.3 ms per 12 G occurrences at C2).  Costs n allocations and ~3 ms of probes
+ *                  each at the first use of the workspace; candidates are held while HBM has room for them.
  *   "intersect"    1: `build --intersect` (ctx_build.c:341-363,384-413).  The graph must have been
  *                  created with ONE colour more than the output: the last colour becomes hidden (not
  *                  exported, not scanned) and holds the union of the intersection graphs' edges,
@@ -239,6 +244,10 @@ int mcx_graph_hashtest(mcx_graph *g, uint64_t first, uint64_t n);
  * (one per thread: range i starts at i * (n / nparts), the last one ends at n), XORs binary_kmer_hash(bkmer, 0) =
  * bklk3_hashlittle over each range and ADDS the ranges' results (ctx_exp_hashtest.c:61-66,160-175). */
 int mcx_hashtest_func(int device, int kmer_size, uint64_t n, uint32_t nparts, uint64_t *hash_out);
+
+/* Diagnostics (tools/exp_hbm_map.py): the split kernel's write pattern -- nregions x spb fronts `cap_words` apart,
+ * 128-byte runs, `iters` x 64 runs per front -- on any device buffer, timed (the second of two runs, ms). */
+int mcx_debug_probe(void *d_buf, uint64_t cap_words, uint32_t nregions, uint32_t spb, uint32_t iters, uint32_t jit_mask, float *ms_out);
 
 /* Like mcx_graph_insert_tuples_dev for tuples that sit in `nseg` segments of `seg_cap` slots with
  * the fills in device memory (d_counts[nseg], u64; a fill above seg_cap is read as seg_cap), so the

@@ -196,6 +196,10 @@ struct mcx_graph {
   uint32_t rep1 = 8;
   bool rep1_forced = false;
   uint64_t *l1_keys = nullptr, *l2_keys = nullptr;  // packed tuples: W words each
+  uint64_t *l2_hi = nullptr;    // placed bins (place_bins > 1): the second half of the flush overlap is an allocation of its own;
+  uint64_t l2_hi_off = 0;       // bins >= l2_hi_off live there (l2_ptr)
+  uint64_t *l2_base = nullptr;  // the allocation l2_keys lies in
+  int place_tries = 1;          // > 1: the sub-table bins are the best of this many allocations by the split's write-pattern probe (ensure_l2)
   uint64_t l2_off = 0;            // first sub-table bin the next split / insert launch uses (flush overlap: two halves)
   hipStream_t stream2 = nullptr;  // flush overlap: the LDS insert of group g runs beside the split of group g + 1
   hipEvent_t ev_split[2] = {nullptr, nullptr}, ev_ins[2] = {nullptr, nullptr};
@@ -740,13 +744,20 @@ template <int W, bool ONECOL> static void launch_bin_received(mcx_graph *g, Tupl
   else launch_bin_tuples_t<W, ONECOL, true, false>(g, in, colour, bs, out);
 }
 
+// sub-table bin `off` and the ones behind it in its half (the two halves of the flush overlap may be two allocations)
+static uint64_t *l2_ptr(const mcx_graph *g, uint64_t off)
+{
+  if (g->l2_hi && off >= g->l2_hi_off) return g->l2_hi + (off - g->l2_hi_off) * g->cap2 * g->W;
+  return g->l2_keys + off * g->cap2 * g->W;
+}
+
 template <int W, bool ONECOL> static void launch_lds_insert_t(mcx_graph *g, int colour, uint32_t sub0, uint32_t nsub)
 {
   const size_t lds = Sub<W>::kSlots * (W + 1) * 8 + LdsQueue<W>::kTuples * 8 * W;
   static bool once_dev[64] = {false};  // per device: the attribute belongs to the function on one device
   bool &once = once_dev[g->device & 63];
   if (!once) { allow_lds(k_lds_insert<W, ONECOL>, lds); once = true; }
-  BinOut bins{g->l2_keys + g->l2_off * g->cap2 * W, nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
+  BinOut bins{l2_ptr(g, g->l2_off), nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
   SpanGuard sp(g, "k_lds_insert");
   hipLaunchKernelGGL((k_lds_insert<W, ONECOL>), dim3((unsigned)std::min<uint64_t>(nsub, (uint64_t)(g->grid_insert ? g->grid_insert : g->grid * 4))),
                      dim3(LdsCfg<W>::kThreads), lds, g->stream, g->t, (uint32_t)colour, bins, sub0, nsub, g->d_ctr);
@@ -765,8 +776,8 @@ static void launch_insert_tuples_t(mcx_graph *g, int colour, const uint64_t *key
 static void free_defer(mcx_graph *g)
 {
   (void)hipFree(g->l1_keys); (void)hipFree(g->l1_cnt);
-  (void)hipFree(g->l2_keys); (void)hipFree(g->l2_cnt);
-  g->l1_keys = g->l2_keys = nullptr; g->l1_cnt = g->l2_cnt = nullptr;
+  (void)hipFree(g->l2_base); (void)hipFree(g->l2_hi); (void)hipFree(g->l2_cnt);
+  g->l1_keys = g->l2_keys = g->l2_base = g->l2_hi = nullptr; g->l1_cnt = g->l2_cnt = nullptr;
   g->cap1 = g->cap2 = 0;
   g->l2_regions = 0;
   g->set_colour.clear(); g->set_pending.clear();
@@ -777,21 +788,104 @@ static void free_defer(mcx_graph *g)
 // next group -- so the bins take a fraction (group / regions) of what bins for the whole table
 // would (80 GB for 8 G occurrences per flush on the bench shape).  Blocks received from other shards are split on arrival
 // (mcx_graph_add_segments_dev), which needs bins for all regions at once.
-static int ensure_l2(mcx_graph *g, uint32_t regions)
+// The write pattern of the split without the split: every block appends 128-byte runs to the sub-table bins of its
+// region, the blocks of a region interleaved.  Where an allocation of sub-table bins happens to lie in HBM decides
+// whether the split runs at 22.0 or at 19.5-20.5 ms per 6 G occurrences (round 6: constant for an allocation whatever
+// the offset inside it, different from one allocation to the next, profiles/r06_experiments.md), and this probe's
+// time follows it (5.3 ms where the split takes 20.5, 6.05 where it takes 22.2): ensure_l2 uses it to choose.
+__global__ __launch_bounds__(512) void k_l2_probe(uint64_t *keys, uint64_t cap, uint32_t nregions, uint32_t spb, uint32_t iters,
+                                                  uint32_t jit_mask = 0 /* experiment: every bin starts a pseudo-random (hash & mask) words late */)
 {
-  if (g->l2_keys && g->l2_regions >= regions) return MCX_OK;
+  const uint32_t region = blockIdx.x % nregions, blk = blockIdx.x / nregions, nblk = gridDim.x / nregions;
+  const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+  for (uint32_t it = 0; it < iters; it++)
+    for (uint32_t k = 0; k < spb / 32u; k++) {
+      const uint32_t front = w * 4u + (l >> 4) + 32u * k;
+      const uint32_t seg = region * spb + front;
+      const uint64_t jit = ((seg * 0x9E3779B1u) >> 8) & jit_mask & ~1u;
+      const uint64_t at = (uint64_t)seg * cap + jit + ((uint64_t)it * nblk + blk) * 16u + (l & 15u);
+      if (jit + ((uint64_t)it * nblk + blk) * 16u + 16u <= cap) keys[at] = at;
+    }
+}
+
+// One allocation of `bytes` for `nreg` regions of sub-table bins, or the best of `tries` by the probe (losers are held
+// until the choice is made -- a freed one would be handed out again -- as far as HBM has room; `taken`: allocations
+// the caller holds meanwhile).  *ms_out: the winner's probe time (0: not probed).
+static uint64_t *l2_place(mcx_graph *g, size_t bytes, uint32_t nreg, int tries, float *ms_out)
+{
+  std::vector<uint64_t *> cand;
+  std::vector<float> ms;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (tries > 1 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) { (void)hipGetLastError(); tries = 1; }
+  const uint32_t iters = (uint32_t)std::max<uint64_t>(8, g->cap2 * g->W / 1024);  // (the whole depth of the bins)
+  for (int i = 0; i < std::max(tries, 1); i++) {
+    if (i > 0) {
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + (size_t)(tot / 16)) { (void)hipGetLastError(); break; }
+    }
+    uint64_t *p = nullptr;
+    if (hipMalloc((void **)&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    cand.push_back(p);
+    float t = 0.f;
+    if (tries > 1)
+      for (int rep = 0; rep < 2; rep++) {  // (the second run counts)
+        (void)hipEventRecord(e0, g->stream);
+        hipLaunchKernelGGL(k_l2_probe, dim3(nreg * 64), dim3(512), 0, g->stream, p, g->cap2 * g->W, nreg, g->subs_per_bin, iters);
+        (void)hipEventRecord(e1, g->stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
+      }
+    ms.push_back(t);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (cand.empty()) return nullptr;
+  size_t best = 0;
+  for (size_t i = 1; i < cand.size(); i++) if (ms[i] > 0.f && (ms[best] <= 0.f || ms[i] < ms[best])) best = i;
+  for (size_t i = 0; i < cand.size(); i++) if (i != best) (void)hipFree(cand[i]);
+  if (getenv("MCX_TIMING") && cand.size() > 1) {
+    fprintf(stderr, "[timing] sub-table bins (%u regions): %zu placements probed:", nreg, cand.size());
+    for (size_t i = 0; i < cand.size(); i++) fprintf(stderr, " %.3f%s", ms[i], i == best ? "*" : "");
+    fprintf(stderr, " ms\n");
+  }
+  if (ms_out) *ms_out = ms[best];
+  return cand[best];
+}
+
+static uint32_t flush_group(const mcx_graph *g);
+// whole: the caller walks the bins as ONE array (split on arrival): no halves
+static int ensure_l2(mcx_graph *g, uint32_t regions, bool whole = false)
+{
+  if (g->l2_keys && g->l2_regions >= regions && !(g->l2_hi && (whole || (regions > g->l2_regions / 2 && regions != g->l2_regions)))) return MCX_OK;
   if (g->pending_l2) return fail(MCX_ERR_ARG, "internal: sub-table bins resized while in use");
   HIP_TRY(hipStreamSynchronize(g->stream));
-  (void)hipFree(g->l2_keys); (void)hipFree(g->l2_cnt);
-  g->l2_keys = nullptr; g->l2_cnt = nullptr; g->l2_regions = 0;
+  (void)hipFree(g->l2_base); (void)hipFree(g->l2_hi); (void)hipFree(g->l2_cnt);
+  g->l2_keys = g->l2_base = g->l2_hi = nullptr; g->l2_cnt = nullptr; g->l2_regions = 0; g->l2_hi_off = 0;
   const uint64_t nb = (uint64_t)regions * g->subs_per_bin;
-  if (hipMalloc((void **)&g->l2_keys, nb * g->cap2 * 8 * g->W) != hipSuccess ||
-      hipMalloc((void **)&g->l2_cnt, nb * 8) != hipSuccess) {
+  int tries = g->place_tries;
+  { const char *e = getenv("MCX_PLACE_BINS"); if (e) tries = atoi(e); }
+  if (g->subs_per_bin % 32 || regions < 8) tries = 1;  // (the probe's pattern needs whole rows of fronts)
+  // Placed bins for the two halves of the flush overlap: each half an allocation of its own, chosen by itself (a place
+  // in HBM that is good for 16 GB at a stretch is rarer than one that is good for 8).  Only when the caller asked for
+  // exactly the two groups of a flush (never for the whole-table bins of the sharded receive path: those are walked as
+  // one array).
+  const uint32_t G = flush_group(g);
+  const bool halves = !whole && tries > 1 && regions == 2 * G && !g->t.lbo && !g->group;
+  if (halves) {
+    const size_t hbytes = (nb / 2) * g->cap2 * 8 * g->W;
+    g->l2_base = l2_place(g, hbytes, G, tries, nullptr);
+    if (g->l2_base) g->l2_hi = l2_place(g, hbytes, G, tries, nullptr);
+    if (g->l2_base && !g->l2_hi) { (void)hipFree(g->l2_base); g->l2_base = nullptr; }
+    g->l2_hi_off = nb / 2;
+  } else {
+    g->l2_base = l2_place(g, nb * g->cap2 * 8 * g->W, std::min<uint32_t>(regions, 32), tries, nullptr);
+  }
+  if (!g->l2_base || hipMalloc((void **)&g->l2_cnt, nb * 8) != hipSuccess) {
     (void)hipGetLastError();
-    (void)hipFree(g->l2_keys); g->l2_keys = nullptr;
+    (void)hipFree(g->l2_base); (void)hipFree(g->l2_hi); g->l2_base = g->l2_hi = nullptr;
     return fail(MCX_ERR_NOMEM, "out of device memory for the sub-table bins (%llu regions)", (unsigned long long)regions);
   }
   HIP_TRY(hipMemsetAsync(g->l2_cnt, 0, nb * 8, g->stream));
+  g->l2_keys = g->l2_base;
   g->l2_regions = regions;
   return MCX_OK;
 }
@@ -864,7 +958,8 @@ static int ensure_defer(mcx_graph *g)
     // (32 replicas only where a segment still holds many tiles: the split reads segments tile by tile)
     if (!g->rep1_forced) g->rep1 = (g->nsets == 1 && g->set_cap / g->b1 / 32 >= (1u << 16)) ? 32 : 8;
     g->cap1 = (uint64_t)((double)g->set_cap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + (g->nsets > 1 ? 2048 : 8192);
-    g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * 1.25) + 1024;
+    static const double cap2_slack = [] { const char *e = getenv("MCX_CAP2_SLACK"); const double v = e ? atof(e) : 0; return v >= 1.0 && v <= 4.0 ? v : 1.25; }();  // experiments
+    g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * cap2_slack) + 1024;
     g->cap1 = (g->cap1 + 1) & ~1ull;  // even: every segment starts 16-byte aligned (vector loads)
     g->cap2 = (g->cap2 + 1) & ~1ull;
     if (g->cap1 >= 0xFFFFFFFFull || g->cap2 >= 0xFFFFFFFFull) continue;
@@ -967,7 +1062,7 @@ static int flush_deferred(mcx_graph *g)
         in.seg_stride = g->b1;
         in.set_rep = g->nsets > 1 ? g->rep1 : 0;
         BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, ng * g->subs_per_bin, ng, 0, r0};
-        BinOut out{g->l2_keys + g->l2_off * g->cap2 * g->W, nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
+        BinOut out{l2_ptr(g, g->l2_off), nullptr, g->l2_cnt + g->l2_off, g->cap2, nullptr, nullptr, nullptr, 0};
         DISPATCH_WC(g, launch_split_regions, g, in, colour, bs, out);
         HIP_TRY(hipGetLastError());
       }
@@ -1171,6 +1266,8 @@ static int submit_stream(mcx_graph *g, const StreamLaunch &L, int colour)
 
 static int ensure_stage(mcx_graph *g);
 
+
+
 extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value)
 {
   if (g && key && g->as_group) {
@@ -1194,6 +1291,28 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     int rc = flush_deferred(g);
     if (rc != MCX_OK) return rc;
     g->defer = value != 0 && g->W <= 2;  // (k > 63: the fused kernel only)
+    return MCX_OK;
+  }
+  if (!strcmp(key, "debug_realloc_l2")) {
+    // experiment (tools/exp_split_var.py): move the sub-table bins to another place in HBM, leaving a hole of `value`
+    // bytes behind -- the split's time follows the placement of its output (profiles/r06_experiments.md)
+    int rc = flush_deferred(g);
+    if (rc != MCX_OK) return rc;
+    if (!g->l2_keys || g->l2_hi) return MCX_OK;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (g->stream2) HIP_TRY(hipStreamSynchronize(g->stream2));
+    static std::vector<void *> holes;
+    void *hole = nullptr;
+    if (value && hipMalloc(&hole, value) == hipSuccess) holes.push_back(hole);
+    uint64_t *nk = nullptr;
+    HIP_TRY(hipMalloc((void **)&nk, (uint64_t)g->l2_regions * g->subs_per_bin * g->cap2 * 8 * g->W));
+    (void)hipFree(g->l2_base);
+    g->l2_base = g->l2_keys = nk;
+    return MCX_OK;
+  }
+  if (!strcmp(key, "place_bins")) {  // 1 = take the first allocation of sub-table bins; n = the best of n by the write-pattern probe
+    if (value < 1 || value > 8) return fail(MCX_ERR_ARG, "place_bins: 1..8");
+    g->place_tries = (int)value;
     return MCX_OK;
   }
   if (!strcmp(key, "defer_tuples")) {
@@ -1397,6 +1516,24 @@ extern "C" int mcx_graph_insert_tuples_dev(mcx_graph *g, int colour, const void 
   return MCX_OK;
 }
 
+// experiments (tools/exp_hbm_map.py): the split's write-pattern probe on any device buffer, timed
+extern "C" int mcx_debug_probe(void *d_buf, uint64_t cap_words, uint32_t nregions, uint32_t spb, uint32_t iters, uint32_t jit_mask, float *ms_out)
+{
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  float t = 0.f;
+  for (int rep = 0; rep < 2; rep++) {
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_l2_probe, dim3(nregions * 64), dim3(512), 0, 0, (uint64_t *)d_buf, cap_words, nregions, spb, iters, jit_mask);
+    (void)hipEventRecord(e1, 0);
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_out) *ms_out = t;
+  return MCX_OK;
+}
+
 // ---- `hashtest` (src/commands/ctx_exp_hashtest.c:40-69) ----
 template <int W> __global__ void k_hashtest_keys(uint64_t *keys, uint64_t first, uint64_t n)
 {
@@ -1564,7 +1701,7 @@ extern "C" int mcx_graph_add_segments_dev(mcx_graph *g, int colour, const void *
   if (nseg % g->b1) return fail(MCX_ERR_ARG, "segments must cover whole sets of %u regions", g->b1);
   rc = l2_reserve(g, colour, ntuples);
   if (rc != MCX_OK) return rc;
-  rc = ensure_l2(g, g->b1);  // split on arrival: bins for every region
+  rc = ensure_l2(g, g->b1, true);  // split on arrival: bins for every region
   if (rc != MCX_OK) return rc;
   TupleIn in{(const uint64_t *)d_keys, nullptr, (const unsigned long long *)d_counts, seg_cap, nseg, nseg, nseg};
   BinSpec bs{BIN_SUBLOCAL, 0, g->subs_per_bin, 1, g->nsub, g->b1, 0, 0};
@@ -2905,7 +3042,7 @@ static int export_t(mcx_graph *g, int sorted, mcx_sink_fn sink, void *ctx)
   const bool bins_idle = g->l1_keys && !g->pending && !g->pending_l2;
   uint8_t *pool[2] = {bins_idle ? reinterpret_cast<uint8_t *>(g->l1_keys) : nullptr, bins_idle ? reinterpret_cast<uint8_t *>(g->l2_keys) : nullptr};
   const uint64_t pool_bytes[2] = {pool[0] ? (uint64_t)g->nsets * g->b1 * g->rep1 * g->cap1 * 8 * g->W : 0,
-                                  pool[1] ? (uint64_t)g->l2_regions * g->subs_per_bin * g->cap2 * 8 * g->W : 0};
+                                  pool[1] ? (uint64_t)(g->l2_hi ? g->l2_regions / 2 : g->l2_regions) * g->subs_per_bin * g->cap2 * 8 * g->W : 0};  // (placed bins: the first half's allocation)
   uint64_t pool_off[2] = {0, 0};
   std::vector<void *> owned;
   auto salloc = [&](void **p, size_t bytes) -> hipError_t {

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mcx_graph_partition_stream_dev", "mcx_graph_insert_tuples_dev", "mcx_key_owner", "mcx_graph_sync",
     "mcx_graph_nkmers", "mcx_graph_device_stats", "mcx_graph_stream", "mcx_graph_export",
     "mcx_kmer_from_str", "mcx_kmer_canonical", "mcx_kmer_hash", "mcx_pack_bases", "mcx_pack_reads_host", "mcx_pack_stream_dev", "mcx_graph_add_packed_dev",
-    "mcx_ubench_stream", "mcx_ubench_random_rmw", "mcx_graph_insert_stats", "mcx_multi_exchange_bytes", "mcx_graph_hashtest", "mcx_hashtest_func",
+    "mcx_ubench_stream", "mcx_ubench_random_rmw", "mcx_graph_insert_stats", "mcx_multi_exchange_bytes", "mcx_graph_hashtest", "mcx_hashtest_func", "mcx_debug_probe",
 ]
 
 

@@ -108,6 +108,7 @@ def test_benchmark_geometry_matches_oracle(mcx, orc, c2_batches, k):
     del body, og
     assert want[1] > 150_000_000
     for name, kw, cfg in (("deferred", {}, {"defer_tuples": 1_000_000_000}),
+                          ("deferred, placed bins", {}, {"place_bins": 3, "defer_tuples": 1_000_000_000}),  # (two allocations, one per half of the flush overlap)
                           ("direct", {}, {"defer": 0}),
                           ("8 in-process shards", {"devices": [0] * 8}, {"defer_tuples": 125_000_000})):
         g = mcx.Graph(k, 1, SLOTS, **kw)

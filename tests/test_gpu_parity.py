@@ -79,6 +79,15 @@ def test_replicas_of_the_region_bins(mcx, orc, rep, monkeypatch):
     _compare(mcx, orc, 55, 2, [(0, bases, offs), (1, bases[: int(offs[1500])], offs[:1501])], names=["a", "b"])
 
 
+def test_placed_sub_table_bins(mcx, orc, monkeypatch):
+    """place_bins: the sub-table bins are the best of n allocations by the write-pattern probe (one allocation for a
+    small table; at the benchmark geometry -- tests/test_gpu_fullsize.py -- one per half of the flush overlap)."""
+    monkeypatch.setenv("MCX_PLACE_BINS", "3")
+    bases, offs = synth.reads(4000, 120, genome_len=30000, seed=91, n_frac=0.05)
+    _compare(mcx, orc, 31, 1, [(0, bases, offs)])
+    _compare(mcx, orc, 63, 1, [(0, bases, offs)], cap=1 << 22)
+
+
 def test_ragged_and_empty_reads(mcx, orc):
     bases, offs = synth.reads(5000, 40, genome_len=5000, seed=3, n_frac=0.2, var_len=True)
     _compare(mcx, orc, 31, 1, [(0, bases, offs)])
