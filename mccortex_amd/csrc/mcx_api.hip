@@ -190,9 +190,10 @@ struct mcx_graph {
   uint32_t b1 = 0, subs_per_bin = 0;
   uint64_t cap1 = 0, cap2 = 0;  // tuples per L1 (replica, bin) segment / per L2 (sub-table) bin
   // Replicas of every L1 bin.  A block appends to replica blockIdx % rep1; all blocks of a replica reserve from the same 64
-  // counter lines once per tile.  8 (one per XCD) until round 6; 32 for a one-colour graph with a large flush window since:
-  // k_stream_bin 23.3 -> 21.2 ms per 6 G occurrences at C2 (16: 21.7, 64: 20.6, 128: 20.5, but the split then pays for its
-  // many short segments: 21.9 / 22.3 / 22.9 ms; profiles/r06_experiments.md).  Chosen in ensure_defer; MCX_REP1 forces it.
+  // counter lines once per tile.  8 (one per XCD) until round 6; for a one-colour graph with a large flush window 32 or 64
+  // since (segments of >= 64 K tuples): k_stream_bin 23.3 -> 21.2 (32) -> 20.4 ms (64) per 6 G occurrences at C2.  The split
+  // paid for many short segments from 64 on (21.9 / 22.3 / 22.9 ms at 32 / 64 / 128) until its output was placed
+  // (place_bins: 19.4 at 32 and at 64, 20.2 at 128); profiles/r06_experiments.md.  Chosen in ensure_defer; MCX_REP1 forces it.
   uint32_t rep1 = 8;
   bool rep1_forced = false;
   uint64_t *l1_keys = nullptr, *l2_keys = nullptr;  // packed tuples: W words each
@@ -956,7 +957,7 @@ static int ensure_defer(mcx_graph *g)
     if (const char *e = getenv("MCX_L1_SETS")) { const int v = atoi(e); if (v >= 1 && v <= 32) g->nsets = (uint32_t)v; }  // tests / experiments
     g->set_cap = tcap / g->nsets;
     // (32 replicas only where a segment still holds many tiles: the split reads segments tile by tile)
-    if (!g->rep1_forced) g->rep1 = (g->nsets == 1 && g->set_cap / g->b1 / 32 >= (1u << 16)) ? 32 : 8;
+    if (!g->rep1_forced) g->rep1 = g->nsets != 1 ? 8 : g->set_cap / g->b1 / 64 >= (1u << 16) ? 64 : g->set_cap / g->b1 / 32 >= (1u << 16) ? 32 : 8;
     g->cap1 = (uint64_t)((double)g->set_cap / g->b1 / g->rep1 * (g->b1 == 1 ? 1.02 : 1.06)) + (g->nsets > 1 ? 2048 : 8192);
     static const double cap2_slack = [] { const char *e = getenv("MCX_CAP2_SLACK"); const double v = e ? atof(e) : 0; return v >= 1.0 && v <= 4.0 ? v : 1.25; }();  // experiments
     g->cap2 = g->nsub == 1 ? tcap + 8192 : (uint64_t)((double)tcap / g->nsub * cap2_slack) + 1024;

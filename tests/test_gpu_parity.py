@@ -69,7 +69,7 @@ def test_random_reads_match_oracle(mcx, orc, k):
     _compare(mcx, orc, k, 1, [(0, bases, offs)])
 
 
-@pytest.mark.parametrize("rep", [1, 16, 32])
+@pytest.mark.parametrize("rep", [1, 16, 32, 64])
 def test_replicas_of_the_region_bins(mcx, orc, rep, monkeypatch):
     """The region bins exist in `rep` replicas (8, or 32 for a large one-colour window: mcx_api.hip rep1); MCX_REP1
     forces the count, so the small graphs of this suite meet the other layouts too."""
