@@ -46,7 +46,7 @@ ALG_BYTES_PER_KMER = 21.25   # 1.25 input + 8 key + 8 covg RMW +
 ALG_BYTES_PER_NOVEL = 8.0    # key write when the node is new
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DEFER_TUPLES = 8_000_000_000  # k-mer occurrences buffered per flush of the partition->LDS-insert path (the least `value` uses)
-PLACE_BINS = 8  # mcx_graph_configure("place_bins"): each half of the sub-table bins is the best of up to this many allocations by the
+PLACE_BINS = 16  # mcx_graph_configure("place_bins"): each half of the sub-table bins is the best of up to this many allocations by the
                 # split's write-pattern probe (where 8 GB of bins lie in HBM decides 13 % of the split: profiles/r06_experiments.md)
 HEADLINE_DEFER = DEFER_TUPLES  # what `value` was measured with (main() sets it: the whole timed region in one flush)
 # algorithmic bytes per k-mer occurrence of every kernel of that path

@@ -836,6 +836,11 @@ static uint64_t *l2_place(mcx_graph *g, size_t bytes, uint32_t nreg, int tries, 
         if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
       }
     ms.push_back(t);
+    // (two kinds of places: ~1.5 ms and ~2.25 ms at C2's size.  One that is a quarter faster than the slowest seen is of
+    // the fast kind: no need to look further)
+    float worst = 0.f;
+    for (float x : ms) worst = std::max(worst, x);
+    if (tries > 1 && t > 0.f && t < 0.75f * worst) break;
   }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
@@ -1312,7 +1317,7 @@ extern "C" int mcx_graph_configure(mcx_graph *g, const char *key, uint64_t value
     return MCX_OK;
   }
   if (!strcmp(key, "place_bins")) {  // 1 = take the first allocation of sub-table bins; n = the best of n by the write-pattern probe
-    if (value < 1 || value > 8) return fail(MCX_ERR_ARG, "place_bins: 1..8");
+    if (value < 1 || value > 32) return fail(MCX_ERR_ARG, "place_bins: 1..32");
     g->place_tries = (int)value;
     return MCX_OK;
   }
