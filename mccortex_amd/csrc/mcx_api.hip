@@ -803,7 +803,7 @@ __global__ __launch_bounds__(512) void k_l2_probe(uint64_t *keys, uint64_t cap, 
     for (uint32_t k = 0; k < spb / 32u; k++) {
       const uint32_t front = w * 4u + (l >> 4) + 32u * k;
       const uint32_t seg = region * spb + front;
-      const uint64_t jit = ((seg * 0x9E3779B1u) >> 8) & jit_mask & ~1u;
+      const uint64_t jit = ((seg * 0x9E3779B1u) >> 8) & jit_mask & ~15u;  // (whole 128-byte lines)
       const uint64_t at = (uint64_t)seg * cap + jit + ((uint64_t)it * nblk + blk) * 16u + (l & 15u);
       if (jit + ((uint64_t)it * nblk + blk) * 16u + 16u <= cap) keys[at] = at;
     }
