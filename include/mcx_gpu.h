@@ -105,7 +105,7 @@ int mcx_graph_reset(mcx_graph *g);
  *                  128-byte runs) into them: where 8 GB of bins happen to lie in HBM decides 13 % of that kernel
  *                  (37.9-38.6 against 43.8-44.3 ms per 12 G occurrences at C2).  Costs n allocations and ~3 ms of probes
  *                  each at the first use of the workspace; candidates are held while HBM has room for them, and the search ends
- *                  at the first one that is a quarter faster than the slowest seen (about one place in five is).
+ *                  as soon as one is 30 % faster than the slowest seen (about one place in five is).
  *   "intersect"    1: `build --intersect` (ctx_build.c:341-363,384-413).  The graph must have been
  *                  created with ONE colour more than the output: the last colour becomes hidden (not
  *                  exported, not scanned) and holds the union of the intersection graphs' edges,
