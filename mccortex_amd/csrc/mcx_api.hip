@@ -2009,6 +2009,8 @@ __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi2,popcnt"))) static v
   uint64_t next_sep = n ? R.start_of(i) + R.len_of(i) : kNever;
   while (next_sep < p_lo) { i++; next_sep = i < n ? R.start_of(i) + R.len_of(i) : kNever; }  // (p_lo behind the last read)
   const uint8_t *src = n ? R.ptr_of(0) + (std::min(p_lo, end_pos) - R.pos0 - std::min(i, n)) : nullptr;
+  const uint8_t *const src_begin = n ? R.ptr_of(0) : nullptr;                                  // the chunk's bases:
+  const uint8_t *const src_end = n ? src_begin + (end_pos - R.pos0 - n) : nullptr;             // [src_begin, src_end)
   for (uint64_t P = p_lo; P < p_hi; P += 64) {
     uint64_t sepm = 0;  // lanes that hold a separator
     while (next_sep < P + 64) {
@@ -2020,7 +2022,19 @@ __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi2,popcnt"))) static v
     if (P < R.pos0) sepm |= R.pos0 >= P + 64 ? ~0ULL : (1ULL << (R.pos0 - P)) - 1;  // (the carry's positions: not ours)
     const unsigned nsrc = 64u - (unsigned)__builtin_popcountll(sepm);
     __m512i v = nl;
-    if (nsrc) {
+    // The masked load + byte expand costs 2.8x the rest of the block on the boxes' hosts (Zen 5: 9.0 against 25 GB/s
+    // of bases per thread, tools/pk/pack_variants.cpp, round 6), and most blocks do not need it: no separator at all
+    // (58 % of the blocks of 150-base reads) is one plain load, exactly one separator is two plain loads one byte apart
+    // and two blends.  Plain loads read 64 bytes whatever is needed: only where the source has them.
+    if (sepm == 0 && src + 64 <= src_end) {
+      v = _mm512_loadu_si512((const void *)src);
+      src += 64;
+    } else if (sepm && !(sepm & (sepm - 1)) && src > src_begin && src + 64 <= src_end) {
+      const __mmask64 from = (__mmask64)(~0ULL << __builtin_ctzll(sepm));  // the separator's lane and the ones behind it
+      v = _mm512_mask_blend_epi8(from, _mm512_loadu_si512((const void *)src), _mm512_loadu_si512((const void *)(src - 1)));
+      v = _mm512_mask_blend_epi8((__mmask64)sepm, v, nl);
+      src += 63;
+    } else if (nsrc) {
       const __m512i x = _mm512_maskz_loadu_epi8(nsrc == 64 ? ~0ULL : (1ULL << nsrc) - 1, (const void *)src);
       v = _mm512_mask_expand_epi8(nl, (__mmask64)~sepm, x);
       src += nsrc;
